@@ -1,0 +1,32 @@
+# Build libprcg.so (gfx950 only) and the oracle's C helpers.  `make` or `python -c
+# "import __graft_entry__ as g; g.build()"`.  hipcc cross-compiles without a GPU.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := new_cg_variants_amd/csrc
+OUT := new_cg_variants_amd/libprcg.so
+# -ffp-contract=off: the reference's arithmetic is "multiply, round, add, round"
+# (NumPy ufuncs, scipy csr_matvec); an FMA would change the bits.
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
+OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
+
+all: $(OUT)
+
+$(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_plan.o: $(CSRC)/prcg_plan.cpp $(CSRC)/prcg_plan.h
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_rccl.o: $(CSRC)/prcg_rccl.cpp $(CSRC)/prcg_rccl.h
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
+
+clean:
+	rm -f $(OBJS) $(OUT)
+
+.PHONY: all clean

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pipelined predict-and-recompute CG iterations/second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|s2|s1] [--variant pipe_pr_cg|hs_cg|pr_cg]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+one rank per GPU.  torch.distributed (gloo) carries only the control plane (RCCL unique
+id, barriers, max-over-ranks of the time); every per-iteration byte -- the halo of the
+SpMM input and the single 5-double all-reduce -- moves over RCCL/xGMI inside libprcg.so.
+
+A "step" is one CG iteration (fused update + two-vector SpMM + reduction) on the
+synthetic workload, inputs resident in HBM before the clock starts, no convergence test
+(as the reference's PETSc runs: -ksp_norm_type none, strong_scaling_tests.py:70).
+The workload is fixed as N grows (strong scaling): S3 = the reference's ex2b banded
+model matrix at n = 1e7, 15 diagonals, ~150 M nonzeros, split into row blocks.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md section 6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def spmv_bytes(n, nnz):     # B1: val + col, row_ptr, x read once, y written   
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def spmm2_bytes(n, nnz):    # B2: A once, two input and two output vectors
+    return 12 * nnz + 4 * (n + 1) + 32 * n
+
+
+def cpu_baseline(A, b, x0, family, seconds=15.0):
+    """The CPU line: the NumPy/SciPy restatement of the reference's loop (oracle/, pinned
+    bitwise against the imported reference in the build container) timed on this host."""
+    from oracle import ne_oracle as orc
+    start, advance, has_flavour = orc.FAMILIES[family]
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info() if p.get('user_api') == 'blas'] or [1])
+    except Exception:
+        threads = 1
+    st = start(A, b, x0)
+    step = (lambda: advance(A, st, 'pr')) if has_flavour else (lambda: advance(A, st))
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    iters = int(max(3, min(200, seconds / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        for _ in range(iters):
+            step()
+    dt = time.perf_counter() - t0
+    return {'value': iters / dt, 'unit': 'iters/s', 'cores': int(threads), 'kind': 'port',
+            'sample': f'{iters} iterations of the oracle {family} loop (scipy csr_matvec is single-threaded; '
+                      f'BLAS ddot may use up to {threads} threads) on the same matrix, {os.cpu_count()} host cores visible'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--workload', default='s3', choices=['s1', 's2', 's3', 's1_small', 's3_small'])
+    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+
+    import torch                                   # first: its HIP runtime is the process's runtime
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems, scaling
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        comm = scaling.TorchComm()
+    else:
+        comm = scaling.SelfComm()
+
+    # ---- the rank's row block of the synthetic operator, right-hand side as the reference --
+    wl = problems.WORKLOADS[args.workload]
+    n = wl['n']
+    offsets = partition.even_offsets(n, world)
+    lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+    A_rows = wl['make'](rows=(lo, hi))
+    b, x0, x_true = problems.reference_rhs(A_rows, n)
+    nnz_local = int(A_rows.nnz)
+    nnz_total = sum(comm.allgather_obj(nnz_local))
+
+    op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
+    dev = op.dev
+    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR}[args.variant]
+
+    # ---- standalone SpMV rate (north_star: effective SpMV HBM GB/s vs roofline) -----------
+    spmv = None
+    if world == 1:
+        xin = np.random.default_rng(0).standard_normal(n)
+        _, _ = dev.matvec(xin, reps=3)
+        _, ms1 = dev.matvec(xin, reps=20)
+        rs = np.stack([xin, xin[::-1]], axis=1)
+        _, ms2 = dev.matmat2(rs, reps=20)
+        spmv = {'spmv_ms': ms1, 'spmv_GBps': spmv_bytes(n, nnz_total) / ms1 * 1e-6,
+                'spmv_frac_of_peak': spmv_bytes(n, nnz_total) / ms1 * 1e-6 / HBM_PEAK_GBS,
+                'spmm2_ms': ms2, 'spmm2_GBps': spmm2_bytes(n, nnz_total) / ms2 * 1e-6}
+
+    # ---- the timed loop ----------------------------------------------------------------------
+    K, W = args.steps, args.warmup
+    dev.begin(variant, b, x0, W + K + 1)
+    dev.iterate(W)
+    dev.sync()
+    stride = max(1, K // 100)
+    dev.set_profiling(stride)
+    comm.Barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.iterate(K)
+    dev.sync()
+    torch.cuda.synchronize()
+    comm.Barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tim = dev.timings()
+    sc = dev.get_scalars(W + K)
+    finite = bool(np.isfinite(sc[L.S_NU]))
+
+    if rank == 0:
+        n_local = hi - lo
+        if args.variant == 'pipe_pr_cg':
+            kbytes = spmm2_bytes(n_local, nnz_local)
+            kname = 'k_spmv_tiles<2> (two-vector SpMM, interior launch)'
+        else:
+            kbytes = spmv_bytes(n_local, nnz_local)
+            kname = 'k_spmv_tiles<1> (SpMV, interior launch)'
+        achieved = kbytes / tim['spmv_ms'] * 1e-6 if tim['spmv_ms'] > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f'{args.workload}:{args.variant}:{world}')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': f'{args.variant} iterations/sec (synthetic banded CSR, fp64)',
+            'value': K / elapsed, 'unit': 'iters/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
+                       'partition': f'row blocks x{world}', 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
+                       'residual_finite': finite},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': kname,
+                         'algorithmic_bytes_per_launch': kbytes, 'avg_launch_ms': tim['spmv_ms'],
+                         'launches_sampled': tim['spmv_samples'], 'update_kernel_ms': tim['update_ms']},
+        }
+        if spmv:
+            out['spmv'] = spmv
+        if world == 1 and not args.no_cpu_baseline:
+            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr'}[args.variant]
+            out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,977 @@
+// libprcg.so engine: handle, operator upload, solver sessions, multi-GPU schedule.
+// Implements include/prcg.h.  Host code only; kernels live in prcg_kernels.hip.
+//
+// Per-iteration schedule of the pipelined variants (the GPU form of the PETSc plug-in's
+// VecDotBegin / PetscCommSplitReductionBegin / KSP_MatMult / VecDotEnd sequence,
+// scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173):
+//
+//   compute stream : [update k: x,r,p,s + dot partials] -E1-> [SpMM interior rows]
+//                    -wait Eh-> [SpMM rows touching ghosts] -wait Er-> [update k+1]
+//   comm stream    : wait E1 -> [pack halo] [ncclSend/Recv] -Eh-> [reduce partials]
+//                    [ncclAllReduce, 5 doubles] -Er->
+//
+// i.e. ONE reduction per iteration, hidden behind the matrix product.  The host only
+// enqueues; it never synchronises inside prcg_iterate.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/prcg.h"
+#include "prcg_kernels.h"
+#include "prcg_plan.h"
+#include "prcg_rccl.h"
+
+using namespace prcg;
+
+namespace {
+
+std::string g_last_error;   // errors with no handle to hang them on
+
+constexpr int kNS = PRCG_NUM_SCALARS;
+constexpr int kCoefStride = 4;
+constexpr int kMaxProfSamples = 512;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t alloc(size_t nbytes, bool zero = true) {
+        release();
+        if (nbytes == 0) nbytes = 16;
+        hipError_t e = hipMalloc(&p, nbytes);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        bytes = nbytes;
+        if (zero) {
+            // the null stream does not order with our non-blocking streams: wait here
+            e = hipMemset(p, 0, nbytes);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        }
+        return e;
+    }
+    double* d() const { return static_cast<double*>(p); }
+    int* i() const { return static_cast<int*>(p); }
+};
+
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
+
+}  // namespace
+
+struct prcg_handle {
+    int dev = 0;
+    std::string err;
+    hipStream_t sc = nullptr;   // compute
+    hipStream_t sm = nullptr;   // communication / reductions
+    hipEvent_t e_upd = nullptr, e_halo = nullptr, e_red = nullptr;
+
+    // ---- communicator ----
+    Rccl* rccl = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    // ---- operator ----
+    bool have_csr = false;
+    int64_t n = 0, g = 0, nnz = 0;
+    DevBuf indptr, col, val, tiles;
+    int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
+    DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
+    DevBuf t1;                           // 2*n doubles: SpMV output scratch
+    DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues
+
+    // ---- halo plan ----
+    int n_peers = 0;
+    std::vector<int> peer_rank;
+    std::vector<int64_t> send_ptr, recv_ptr;
+    DevBuf send_idx, send_buf;
+    bool have_halo = false;
+
+    // ---- session ----
+    bool in_session = false;
+    int variant = -1;
+    bool prec = false;
+    int max_iter = 0;
+    int k = 0;
+    uint32_t hist_mask = 0;
+    bool have_xtrue = false;
+    DevBuf x, p, rs, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf dots, coef;
+
+    // ---- profiling ----
+    int prof_stride = 0;
+    std::vector<EventPair> ev_spmv, ev_upd;
+    int n_ev_spmv = 0, n_ev_upd = 0;
+    double last_tot_ms = 0.0;
+    int64_t last_iters = 0;
+
+    CsrDev csr() const { return CsrDev{indptr.i(), col.i(), val.d()}; }
+    const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
+    bool multi() const { return nranks > 1; }
+};
+
+namespace {
+
+int fail(prcg_t* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(h, PRCG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define NCCLCHK(h, expr)                                                                      \
+    do {                                                                                      \
+        ncclResult_t r__ = (expr);                                                            \
+        if (r__ != ncclSuccess)                                                               \
+            return fail(h, PRCG_ERCCL, "%s failed: %s (%s:%d)", #expr,                        \
+                        (h)->rccl->GetErrorString(r__), __FILE__, __LINE__);                  \
+    } while (0)
+
+#define LAUNCHCHK(h, grid)                                                                    \
+    do {                                                                                      \
+        if ((grid) < 0) return fail(h, PRCG_EHIP, "kernel launch failed (%s:%d)", __FILE__, __LINE__); \
+    } while (0)
+
+#define CHECK(h, cond, ...)                                                                   \
+    do { if (!(cond)) return fail(h, PRCG_EINVAL, __VA_ARGS__); } while (0)
+
+bool is_pipe(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_P || v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M; }
+bool is_pr(int v) { return v == PRCG_PR || v == PRCG_M; }
+bool pipe_recompute(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_PR_M; }
+bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == PRCG_M; }
+
+// ---- halo exchange of an nc-component extended vector, all on `st` ----------------------
+int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
+    if (!h->multi() || h->g == 0) return PRCG_OK;
+    CHECK(h, h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
+    const int64_t nsend = h->send_ptr[h->n_peers];
+    launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);
+    NCCLCHK(h, h->rccl->GroupStart());
+    for (int q = 0; q < h->n_peers; ++q) {
+        const int64_t ns = h->send_ptr[q + 1] - h->send_ptr[q];
+        const int64_t nr = h->recv_ptr[q + 1] - h->recv_ptr[q];
+        if (ns > 0)
+            NCCLCHK(h, h->rccl->Send(h->send_buf.d() + h->send_ptr[q] * nc, (size_t)(ns * nc), ncclDouble,
+                                     h->peer_rank[q], h->comm, st));
+        if (nr > 0)
+            NCCLCHK(h, h->rccl->Recv(vec_ext + (h->n + h->recv_ptr[q]) * nc, (size_t)(nr * nc), ncclDouble,
+                                     h->peer_rank[q], h->comm, st));
+    }
+    NCCLCHK(h, h->rccl->GroupEnd());
+    return PRCG_OK;
+}
+
+int allreduce(prcg_t* h, double* buf, int count, hipStream_t st) {
+    if (!h->multi()) return PRCG_OK;
+    NCCLCHK(h, h->rccl->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, h->comm, st));
+    return PRCG_OK;
+}
+
+// y = A x (x extended, ghosts exchanged), everything on the compute stream.  Used by the
+// initialisation, the recorders and prcg_spmv -- not by the timed loop.
+int dist_spmv(prcg_t* h, double* x_ext, double* y, SpmvEpilogue epi, const double* ep_r,
+              const double* ep_d, double* ep_st, int* grid_out) {
+    int rc = exchange(h, x_ext, 1, h->sc);
+    if (rc) return rc;
+    const int nt = h->nt_int + h->nt_bnd;
+    const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, x_ext, y, epi, ep_r, ep_d, ep_st,
+                                 h->partB.d());
+    LAUNCHCHK(h, grid);
+    if (grid_out) *grid_out = grid;
+    return PRCG_OK;
+}
+
+double* dots_at(prcg_t* h, int k) { return h->dots.d() + (size_t)k * kNS; }
+double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride; }
+
+// ---- history recorders for the state of iteration k (compute stream) -------------------
+int record(prcg_t* h, int k) {
+    const uint32_t m = h->hist_mask;
+    if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
+    const int64_t n = h->n;
+    int rc;
+    if (m & PRCG_HIST_RESIDUAL_2_NORM) {
+        // |b - A x|   callbacks/residual_2_norm.py:41
+        launch_copy(h->sc, h->tmp_ext.d(), 1, h->x.d(), 1, n);
+        if ((rc = dist_spmv(h, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+        const int grid = launch_diff_sq(h->sc, h->b.d(), h->t1.d(), n, h->partA.d(), PRCG_S_RES2);
+        LAUNCHCHK(h, grid);
+        launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), PRCG_S_RES2, PRCG_S_RES2, 1);
+    }
+    if (m & PRCG_HIST_ERROR_2_NORM) {
+        // |x - x_true|   callbacks/error_2_norm.py:47-48
+        const int grid = launch_diff_sq(h->sc, h->x.d(), h->xt.d(), n, h->partA.d(), PRCG_S_ERR2);
+        LAUNCHCHK(h, grid);
+        launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), PRCG_S_ERR2, PRCG_S_ERR2, 1);
+    }
+    if (m & PRCG_HIST_ERROR_A_NORM) {
+        // e = x - x_true; e'(A e)   callbacks/error_A_norm.py:47-48
+        launch_sub(h->sc, h->e_ext.d(), 1, h->x.d(), 1, h->xt.d(), 1, n);
+        int grid = 0;
+        if ((rc = dist_spmv(h, h->e_ext.d(), h->t1.d(), kEpiDotXY, nullptr, nullptr, nullptr, &grid))) return rc;
+        launch_reduce_final(h->sc, h->partB.d(), grid, dots_at(h, k), 0, PRCG_S_ERRA2, 1);
+    }
+    return allreduce(h, dots_at(h, k) + PRCG_S_RES2, 3, h->sc);
+}
+
+void prof_begin(prcg_t* h, std::vector<EventPair>& evs, int& count, int k, bool& on) {
+    on = h->prof_stride > 0 && (k % h->prof_stride) == 0 && count < kMaxProfSamples;
+    if (!on) return;
+    if ((int)evs.size() <= count) {
+        EventPair ep;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) { on = false; return; }
+        evs.push_back(ep);
+    }
+    (void)hipEventRecord(evs[count].a, h->sc);
+}
+void prof_end(prcg_t* h, std::vector<EventPair>& evs, int& count, bool on) {
+    if (!on) return;
+    (void)hipEventRecord(evs[count].b, h->sc);
+    ++count;
+}
+
+// SpMM of the pipelined loop, overlapped with halo + reduction when multi-rank.
+// `grid_upd` = number of partial blocks the update kernel just wrote to partA.
+int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
+    double* in_ext = h->prec ? h->rst.d() : h->rs.d();
+    const int mask = pipe_recompute(h->variant) ? 3 : 2;
+    bool on = false;
+    if (!h->multi()) {
+        launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
+        if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, in_ext, h->wu.d(), mask));
+        if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        return PRCG_OK;
+    }
+    HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    int rc = exchange(h, in_ext, 2, h->sm);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+    launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
+    if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
+    HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+
+    if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int, in_ext, h->wu.d(), mask));
+    if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
+    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, in_ext, h->wu.d(), mask));
+    HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+    return PRCG_OK;
+}
+
+// single-vector SpMV with an epilogue, interior rows overlapped with the halo of x_ext.
+// partials of the two launches are laid end to end in partB; *nparts = their count.
+int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi, const double* ep_r,
+                    const double* ep_d, double* ep_st, int* nparts) {
+    bool on = false;
+    if (!h->multi()) {
+        prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+        const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, x_ext, y, epi, ep_r,
+                                     ep_d, ep_st, h->partB.d());
+        LAUNCHCHK(h, grid);
+        prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        *nparts = grid;
+        return PRCG_OK;
+    }
+    HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    int rc = exchange(h, x_ext, 1, h->sm);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, x_ext, y, epi, ep_r, ep_d, ep_st,
+                               h->partB.d());
+    LAUNCHCHK(h, g1);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
+    const int g2 = launch_spmv(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, x_ext, y, epi, ep_r, ep_d, ep_st,
+                               h->partB.d() + (size_t)g1 * kPartialStride);
+    LAUNCHCHK(h, g2);
+    *nparts = g1 + g2;
+    return PRCG_OK;
+}
+
+PipeUpdateArgs pipe_args(prcg_t* h, int k) {
+    PipeUpdateArgs a{};
+    a.n = h->n;
+    a.x = h->x.d(); a.p = h->p.d();
+    a.rs = h->rs.d(); a.rst = h->prec ? h->rst.d() : nullptr;
+    a.wu = h->wu.d(); a.wt = h->wt.d();
+    a.d = h->prec ? h->dinv.d() : nullptr;
+    a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
+    a.coef_out = coef_at(h, k);
+    a.partials = h->partA.d();
+    a.meurant = meurant(h->variant);
+    a.recompute_w = pipe_recompute(h->variant);
+    return a;
+}
+
+int iterate_pipe(prcg_t* h, int k) {
+    // pipe_pr_cg.py:61-75 / :169-187
+    PipeUpdateArgs a = pipe_args(h, k);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    const int grid = launch_pipe_update(h->sc, a);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    return pipe_spmm_and_reduce(h, k, grid, true);
+}
+
+HsArgs hs_args(prcg_t* h, int k) {
+    HsArgs a{};
+    a.n = h->n;
+    a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
+    a.p = h->p.d(); a.s = h->s.d(); a.d = h->prec ? h->dinv.d() : nullptr;
+    a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
+    a.dots_cur = dots_at(h, k);
+    a.coef_out = coef_at(h, k);
+    a.partials = h->partA.d();
+    return a;
+}
+
+int iterate_hs(prcg_t* h, int k) {
+    // hs_cg.py:54-61: two dependent reductions per iteration -- nothing to overlap them with
+    HsArgs a = hs_args(h, k);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    const int g1 = launch_hs_update_xr(h->sc, a);
+    LAUNCHCHK(h, g1);
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    launch_reduce_final(h->sc, h->partA.d(), g1, dots_at(h, k), PRCG_S_NU, PRCG_S_NU, 2);
+    int rc = allreduce(h, dots_at(h, k) + PRCG_S_NU, 2, h->sc);          // reduction 1: nu
+    if (rc) return rc;
+    LAUNCHCHK(h, launch_hs_update_p(h->sc, a));
+    int nparts = 0;
+    if ((rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &nparts))) return rc;
+    launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, PRCG_S_MU, 1);
+    return allreduce(h, dots_at(h, k) + PRCG_S_MU, 1, h->sc);           // reduction 2: mu
+}
+
+PrArgs pr_args(prcg_t* h, int k) {
+    PrArgs a{};
+    a.n = h->n;
+    a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
+    a.p = h->p.d(); a.s = h->s.d(); a.st_ = h->prec ? h->st.d() : nullptr;
+    a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
+    a.coef_out = coef_at(h, k);
+    a.partials = h->partA.d();
+    a.meurant = meurant(h->variant);
+    a.precond = h->prec;
+    return a;
+}
+
+int pr_spmv_and_reduce(prcg_t* h, int k, int grid_upd) {
+    // s = A p; s~ = M^-1 s; mu, delta, gamma ride on the SpMV (pr_cg.py:152-157)
+    int nparts = 0;
+    int rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
+                             h->prec ? h->st.d() : nullptr, &nparts);
+    if (rc) return rc;
+    launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), PRCG_S_NU, PRCG_S_NU, 2);
+    launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, 0, 3);
+    return allreduce(h, dots_at(h, k), 5, h->sc);                       // the one reduction
+}
+
+int iterate_pr(prcg_t* h, int k) {
+    PrArgs a = pr_args(h, k);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    const int grid = launch_pr_update(h->sc, a);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    return pr_spmv_and_reduce(h, k, grid);
+}
+
+int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    return PRCG_OK;
+}
+int d2h(prcg_t* h, double* dst, const double* src, int64_t count) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->sc));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    return PRCG_OK;
+}
+
+// where does state vector `which` live?  base pointer + stride (in doubles)
+bool locate(prcg_t* h, int which, double** base, int* stride) {
+    *stride = 1;
+    *base = nullptr;
+    const int v = h->variant;
+    if (which == PRCG_VEC_X) { *base = h->x.d(); return true; }
+    if (which == PRCG_VEC_P) { *base = h->p.d(); return true; }
+    if (is_pipe(v)) {
+        switch (which) {
+        case PRCG_VEC_R: *base = h->rs.d(); *stride = 2; return true;
+        case PRCG_VEC_S: *base = h->rs.d() + 1; *stride = 2; return true;
+        case PRCG_VEC_W: *base = h->wu.d(); *stride = 2; return true;
+        case PRCG_VEC_U: *base = h->wu.d() + 1; *stride = 2; return true;
+        case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rst.d(); *stride = 2; return true;
+        case PRCG_VEC_ST: if (!h->prec) return false; *base = h->rst.d() + 1; *stride = 2; return true;
+        case PRCG_VEC_WT: if (!h->prec || pipe_recompute(v)) return false; *base = h->wt.d(); return true;
+        default: return false;
+        }
+    }
+    switch (which) {
+    case PRCG_VEC_R: *base = h->r.d(); return true;
+    case PRCG_VEC_S: *base = h->s.d(); return true;
+    case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
+    case PRCG_VEC_ST: if (!h->prec || !is_pr(v)) return false; *base = h->st.d(); return true;
+    default: return false;
+    }
+}
+
+void destroy_events(std::vector<EventPair>& evs) {
+    for (auto& e : evs) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+    evs.clear();
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+int prcg_version(void) { return 1; }
+
+const char* prcg_last_error(const prcg_t* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int prcg_create(prcg_t** out, int device_id) {
+    if (!out) return fail(nullptr, PRCG_EINVAL, "prcg_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PRCG_EHIP, "prcg_create: no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, PRCG_EINVAL, "prcg_create: device %d out of range [0,%d)", device_id, ndev);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, PRCG_EHIP, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    prcg_t* h = new (std::nothrow) prcg_handle();
+    if (!h) return fail(nullptr, PRCG_ENOMEM, "out of host memory");
+    h->dev = device_id;
+    // the communication stream outranks the compute stream: its small kernels (halo pack,
+    // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->sc, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->sm, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->e_upd, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->e_red, hipEventDisableTiming) != hipSuccess) {
+        prcg_destroy(h);
+        return fail(nullptr, PRCG_EHIP, "prcg_create: stream/event creation failed");
+    }
+    *out = h;
+    return PRCG_OK;
+}
+
+void prcg_destroy(prcg_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    (void)hipDeviceSynchronize();
+    if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
+    destroy_events(h->ev_spmv);
+    destroy_events(h->ev_upd);
+    if (h->e_upd) (void)hipEventDestroy(h->e_upd);
+    if (h->e_halo) (void)hipEventDestroy(h->e_halo);
+    if (h->e_red) (void)hipEventDestroy(h->e_red);
+    if (h->sc) (void)hipStreamDestroy(h->sc);
+    if (h->sm) (void)hipStreamDestroy(h->sm);
+    delete h;
+}
+
+int prcg_comm_unique_id(const char* rccl_path, void* id128) {
+    if (!id128) return fail(nullptr, PRCG_EINVAL, "prcg_comm_unique_id: null buffer");
+    std::string err;
+    Rccl* r = Rccl::get(rccl_path, err);
+    if (!r) return fail(nullptr, PRCG_ERCCL, "%s", err.c_str());
+    ncclUniqueId id;
+    ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(nullptr, PRCG_ERCCL, "ncclGetUniqueId: %s", r->GetErrorString(rc));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return PRCG_OK;
+}
+
+int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* id128) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, nranks >= 1 && rank >= 0 && rank < nranks, "prcg_comm_init: bad rank %d of %d", rank, nranks);
+    CHECK(h, id128 != nullptr, "prcg_comm_init: null unique id");
+    CHECK(h, h->comm == nullptr, "prcg_comm_init: communicator already initialised");
+    std::string err;
+    h->rccl = Rccl::get(rccl_path, err);
+    if (!h->rccl) return fail(h, PRCG_ERCCL, "%s", err.c_str());
+    HIPCHK(h, hipSetDevice(h->dev));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(h, h->rccl->CommInitRank(&h->comm, nranks, id, rank));
+    h->rank = rank;
+    h->nranks = nranks;
+    return PRCG_OK;
+}
+
+int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const void* indptr, int indptr_is64,
+                 const int32_t* indices, const double* data) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, n_rows >= 0 && n_ghost >= 0 && nnz >= 0, "prcg_set_csr: negative size");
+    CHECK(h, nnz < (int64_t)2147483000, "prcg_set_csr: nnz=%lld does not fit int32 row pointers", (long long)nnz);
+    CHECK(h, n_rows + n_ghost < (int64_t)2147483000, "prcg_set_csr: too many rows for int32 column indices");
+    CHECK(h, indptr && (nnz == 0 || (indices && data)), "prcg_set_csr: null array");
+    h->in_session = false;   // a new operator invalidates any open session
+    HIPCHK(h, hipSetDevice(h->dev));
+
+    // --- validate on the host before anything reaches a kernel ---
+    std::vector<int32_t> ip((size_t)n_rows + 1);
+    for (int64_t i = 0; i <= n_rows; ++i) {
+        const int64_t v = indptr_is64 ? static_cast<const int64_t*>(indptr)[i] : static_cast<const int32_t*>(indptr)[i];
+        CHECK(h, v >= 0 && v <= nnz, "prcg_set_csr: indptr[%lld]=%lld out of [0,nnz]", (long long)i, (long long)v);
+        CHECK(h, i == 0 || v >= ip[i - 1], "prcg_set_csr: indptr not monotone at row %lld", (long long)i);
+        ip[i] = (int32_t)v;
+    }
+    CHECK(h, ip[0] == 0 && ip[n_rows] == nnz, "prcg_set_csr: indptr must run from 0 to nnz");
+    const int64_t ncols = n_rows + n_ghost;
+    std::vector<uint8_t> cls((size_t)n_rows, 0);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        uint8_t c = 0;
+        for (int32_t q = ip[i]; q < ip[i + 1]; ++q) {
+            const int32_t j = indices[q];
+            CHECK(h, j >= 0 && j < ncols, "prcg_set_csr: column index %d out of [0,%lld) in row %lld", j,
+                  (long long)ncols, (long long)i);
+            if (j >= n_rows) c = 1;
+        }
+        cls[i] = c;
+    }
+    std::vector<Tile> t0, t1;
+    plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, kTileCapNnz, kTileCapRows, t0, t1);
+    std::vector<Tile> all(t0);
+    all.insert(all.end(), t1.begin(), t1.end());
+
+    // --- upload (arrays padded so the 16-byte stream loads never leave the allocation) ---
+    const size_t pad = 8;
+    HIPCHK(h, h->indptr.alloc(((size_t)n_rows + 1 + pad) * sizeof(int32_t)));
+    HIPCHK(h, h->col.alloc(((size_t)nnz + pad) * sizeof(int32_t)));
+    HIPCHK(h, h->val.alloc(((size_t)nnz + pad) * sizeof(double)));
+    HIPCHK(h, h->tiles.alloc((all.size() + 1) * sizeof(Tile)));
+    HIPCHK(h, hipMemcpy(h->indptr.p, ip.data(), ((size_t)n_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        HIPCHK(h, hipMemcpy(h->col.p, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->val.p, data, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (!all.empty())
+        HIPCHK(h, hipMemcpy(h->tiles.p, all.data(), all.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
+    h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
+    HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost) * sizeof(double)));
+    HIPCHK(h, h->t1.alloc((size_t)2 * n_rows * sizeof(double)));
+    HIPCHK(h, h->partA.alloc((size_t)8192 * kPartialStride * sizeof(double)));
+    HIPCHK(h, h->partB.alloc((size_t)8192 * kPartialStride * sizeof(double)));
+    h->have_csr = true;
+    h->have_halo = false;
+    return PRCG_OK;
+}
+
+int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank, const int64_t* send_ptr, const int32_t* send_idx,
+                  const int64_t* recv_ptr) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->have_csr, "prcg_set_halo: call prcg_set_csr first");
+    CHECK(h, n_peers >= 0 && (n_peers == 0 || (peer_rank && send_ptr && recv_ptr)), "prcg_set_halo: null array");
+    HIPCHK(h, hipSetDevice(h->dev));
+    h->n_peers = n_peers;
+    h->peer_rank.assign(peer_rank, peer_rank + n_peers);
+    h->send_ptr.assign(1, 0);
+    h->recv_ptr.assign(1, 0);
+    if (n_peers > 0) {
+        h->send_ptr.assign(send_ptr, send_ptr + n_peers + 1);
+        h->recv_ptr.assign(recv_ptr, recv_ptr + n_peers + 1);
+    }
+    CHECK(h, h->send_ptr[0] == 0 && h->recv_ptr[0] == 0, "prcg_set_halo: pointers must start at 0");
+    for (int q = 0; q < n_peers; ++q) {
+        CHECK(h, h->peer_rank[q] >= 0 && h->peer_rank[q] < h->nranks && h->peer_rank[q] != h->rank,
+              "prcg_set_halo: bad peer rank %d", h->peer_rank[q]);
+        CHECK(h, h->send_ptr[q + 1] >= h->send_ptr[q] && h->recv_ptr[q + 1] >= h->recv_ptr[q],
+              "prcg_set_halo: pointers not monotone");
+    }
+    CHECK(h, h->recv_ptr[n_peers] == h->g, "prcg_set_halo: receive counts (%lld) != n_ghost (%lld)",
+          (long long)h->recv_ptr[n_peers], (long long)h->g);
+    const int64_t nsend = h->send_ptr[n_peers];
+    for (int64_t j = 0; j < nsend; ++j)
+        CHECK(h, send_idx[j] >= 0 && send_idx[j] < h->n, "prcg_set_halo: send index %d out of range", send_idx[j]);
+    HIPCHK(h, h->send_idx.alloc((size_t)(nsend + 1) * sizeof(int32_t)));
+    HIPCHK(h, h->send_buf.alloc((size_t)(nsend + 1) * 2 * sizeof(double)));
+    if (nsend > 0)
+        HIPCHK(h, hipMemcpy(h->send_idx.p, send_idx, (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->have_halo = true;
+    return PRCG_OK;
+}
+
+static int timed_product(prcg_t* h, int nc, const double* in, double* out, int reps, double* ms_avg) {
+    CHECK(h, h->have_csr, "no matrix: call prcg_set_csr first");
+    CHECK(h, in && out && reps >= 1, "bad argument");
+    CHECK(h, h->g == 0 || !h->multi() || h->have_halo, "ghost columns without a halo plan");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = h2d(h, h->tmp_ext.d(), in, h->n * nc);
+    if (rc) return rc;
+    if ((rc = exchange(h, h->tmp_ext.d(), nc, h->sc))) return rc;
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a));
+    HIPCHK(h, hipEventCreate(&b));
+    double total = 0.0;
+    const int nt = h->nt_int + h->nt_bnd;
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(h, hipEventRecord(a, h->sc));
+        if (nc == 1)
+            LAUNCHCHK(h, launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr,
+                                     nullptr, nullptr, nullptr));
+        else
+            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), nt, h->tmp_ext.d(), h->t1.d(), 3));
+        HIPCHK(h, hipEventRecord(b, h->sc));
+        HIPCHK(h, hipEventSynchronize(b));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+        total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (ms_avg) *ms_avg = total / reps;
+    return d2h(h, out, h->t1.d(), h->n * nc);
+}
+
+int prcg_spmv(prcg_t* h, const double* x, double* y, int reps, double* ms_avg) {
+    if (!h) return PRCG_EINVAL;
+    return timed_product(h, 1, x, y, reps, ms_avg);
+}
+
+int prcg_spmm2(prcg_t* h, const double* rs, double* wu, int reps, double* ms_avg) {
+    if (!h) return PRCG_EINVAL;
+    return timed_product(h, 2, rs, wu, reps, ms_avg);
+}
+
+int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, int max_iter, const double* x_true,
+                     const double* inv_diag, uint32_t hist_mask) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->have_csr, "prcg_solve_begin: call prcg_set_csr first");
+    CHECK(h, variant >= 0 && variant < PRCG_NUM_VARIANTS, "prcg_solve_begin: unknown variant %d", variant);
+    CHECK(h, b && x0, "prcg_solve_begin: null b or x0");
+    CHECK(h, max_iter >= 1, "prcg_solve_begin: max_iter must be >= 1");
+    CHECK(h, (hist_mask & ~PRCG_HIST_ALL) == 0, "prcg_solve_begin: unknown history bits");
+    CHECK(h, !(hist_mask & (PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) || x_true,
+          "prcg_solve_begin: error histories need x_true");
+    CHECK(h, h->g == 0 || !h->multi() || h->have_halo, "ghost columns without a halo plan");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int64_t n = h->n, ne = h->n + h->g;
+    const size_t D = sizeof(double);
+    h->in_session = false;
+    h->variant = variant;
+    h->prec = inv_diag != nullptr;
+    h->max_iter = max_iter;
+    h->hist_mask = hist_mask;
+    h->have_xtrue = x_true != nullptr;
+    h->k = 0;
+    h->n_ev_spmv = h->n_ev_upd = 0;
+
+    HIPCHK(h, h->x.alloc((size_t)n * D));
+    HIPCHK(h, h->b.alloc((size_t)n * D));
+    HIPCHK(h, h->xt.alloc((size_t)n * D));
+    HIPCHK(h, h->e_ext.alloc((size_t)ne * D));
+    HIPCHK(h, h->dinv.alloc((size_t)n * D));
+    HIPCHK(h, h->dots.alloc((size_t)(max_iter + 1) * kNS * D));
+    HIPCHK(h, h->coef.alloc((size_t)(max_iter + 1) * kCoefStride * D));
+    int rc;
+    if ((rc = h2d(h, h->x.d(), x0, n))) return rc;
+    if ((rc = h2d(h, h->b.d(), b, n))) return rc;
+    if (x_true && (rc = h2d(h, h->xt.d(), x_true, n))) return rc;
+    if (inv_diag && (rc = h2d(h, h->dinv.d(), inv_diag, n))) return rc;
+    hipStream_t sc = h->sc;
+    double* tmp = h->tmp_ext.d();
+    double* t1 = h->t1.d();
+
+    // r0 = b - A x0   (hs_cg.py:23, pipe_pr_cg.py:23)
+    launch_copy(sc, tmp, 1, h->x.d(), 1, n);
+    if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+
+    if (is_pipe(variant)) {
+        HIPCHK(h, h->p.alloc((size_t)n * D));
+        HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
+        HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
+        HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
+        HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
+        double* RS = h->rs.d();
+        double* WU = h->wu.d();
+        launch_sub(sc, RS, 2, h->b.d(), 1, t1, 1, n);                       // r = b - A x
+        if (!h->prec) {
+            launch_copy(sc, h->p.d(), 1, RS, 2, n);                         // p = r          :24
+            launch_copy(sc, tmp, 1, RS, 2, n);
+            if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+            launch_copy(sc, RS + 1, 2, t1, 1, n);                           // s = A p        :26
+            launch_copy(sc, WU, 2, t1, 1, n);                               // w = s          :27
+            launch_copy(sc, tmp, 1, t1, 1, n);
+            if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+            launch_copy(sc, WU + 1, 2, t1, 1, n);                           // u = A w        :28
+        } else {
+            double* RST = h->rst.d();
+            launch_mul(sc, RST, 2, h->dinv.d(), 1, RS, 2, n);               // r~ = M^-1 r    :124
+            launch_copy(sc, h->p.d(), 1, RST, 2, n);                        // p = r~         :125
+            launch_copy(sc, tmp, 1, RST, 2, n);
+            if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+            launch_copy(sc, RS + 1, 2, t1, 1, n);                           // s = A p        :127
+            launch_mul(sc, RST + 1, 2, h->dinv.d(), 1, t1, 1, n);           // s~ = M^-1 s    :128
+            launch_copy(sc, WU, 2, t1, 1, n);                               // w = s          :129
+            launch_copy(sc, h->wt.d(), 1, RST + 1, 2, n);                   // w~ = s~        :130
+            launch_copy(sc, tmp, 1, RST + 1, 2, n);
+            if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
+            launch_copy(sc, WU + 1, 2, t1, 1, n);                           // u = A s~       :131
+        }
+        PipeUpdateArgs a = pipe_args(h, 0);
+        const int grid = launch_pipe_dots(sc, a);                           // nu, mu, delta, gamma
+        LAUNCHCHK(h, grid);
+        launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
+        if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+    } else {
+        // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)
+        HIPCHK(h, h->p.alloc((size_t)ne * D));
+        HIPCHK(h, h->r.alloc((size_t)n * D));
+        HIPCHK(h, h->s.alloc((size_t)n * D));
+        HIPCHK(h, h->rt.alloc(h->prec ? (size_t)n * D : 16));
+        HIPCHK(h, h->st.alloc(h->prec ? (size_t)n * D : 16));
+        launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
+        if (h->prec) {
+            launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r
+            launch_copy(sc, h->p.d(), 1, h->rt.d(), 1, n);                  // p = r~
+        } else {
+            launch_copy(sc, h->p.d(), 1, h->r.d(), 1, n);                   // p = r
+        }
+        if (variant == PRCG_HS) {
+            HsArgs a = hs_args(h, 0);
+            const int g1 = launch_hs_init_dots(sc, a);                      // nu = r.r~      hs_cg.py:25
+            LAUNCHCHK(h, g1);
+            launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), PRCG_S_NU, PRCG_S_NU, 2);
+            if ((rc = allreduce(h, dots_at(h, 0) + PRCG_S_NU, 2, sc))) return rc;
+            int grid = 0;
+            if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &grid))) return rc;
+            launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, PRCG_S_MU, 1);   // mu = p.s  :27
+            if ((rc = allreduce(h, dots_at(h, 0) + PRCG_S_MU, 1, sc))) return rc;
+        } else {
+            PrArgs a = pr_args(h, 0);
+            const int g1 = launch_pr_init_dots(sc, a);                      // nu = r~.r      pr_cg.py:109
+            LAUNCHCHK(h, g1);
+            int grid = 0;
+            if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
+                                h->prec ? h->st.d() : nullptr, &grid))) return rc;        // s, s~, mu, dl, gm
+            launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), PRCG_S_NU, PRCG_S_NU, 2);
+            launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, 0, 3);
+            if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+        }
+    }
+    if ((rc = record(h, 0))) return rc;
+    HIPCHK(h, hipStreamSynchronize(sc));
+    h->in_session = true;
+    return PRCG_OK;
+}
+
+int prcg_iterate(prcg_t* h, int iters) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session, "prcg_iterate: no open session");
+    CHECK(h, iters >= 0, "prcg_iterate: negative count");
+    CHECK(h, h->k + iters <= h->max_iter, "prcg_iterate: %d more iterations exceed max_iter=%d (k=%d)", iters,
+          h->max_iter, h->k);
+    HIPCHK(h, hipSetDevice(h->dev));
+    for (int i = 0; i < iters; ++i) {
+        const int k = h->k + 1;
+        int rc;
+        if (is_pipe(h->variant)) rc = iterate_pipe(h, k);
+        else if (h->variant == PRCG_HS) rc = iterate_hs(h, k);
+        else rc = iterate_pr(h, k);
+        if (rc) return rc;
+        if ((rc = record(h, k))) return rc;
+        h->k = k;
+    }
+    return PRCG_OK;
+}
+
+int prcg_sync(prcg_t* h) {
+    if (!h) return PRCG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->sm));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    return PRCG_OK;
+}
+
+int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
+
+int prcg_set_iteration(prcg_t* h, int k) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session, "prcg_set_iteration: no open session");
+    CHECK(h, k >= 0 && k < h->max_iter, "prcg_set_iteration: k out of range");
+    h->k = k;
+    return PRCG_OK;
+}
+
+int prcg_get_vector(prcg_t* h, int which, double* out) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && out, "prcg_get_vector: no session or null buffer");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    const int64_t n = h->n;
+    double* base; int stride;
+    if (!locate(h, which, &base, &stride)) {
+        // derived tilde vectors of the Jacobi 'pr' flavours: w~ = M^-1 w, u~ = M^-1 u
+        if (is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT)) {
+            launch_mul(h->sc, h->t1.d(), 1, h->dinv.d(), 1, h->wu.d() + (which == PRCG_VEC_UT ? 1 : 0), 2, n);
+            return d2h(h, out, h->t1.d(), n);
+        }
+        return fail(h, PRCG_EINVAL, "prcg_get_vector: vector %d is not part of variant %d", which, h->variant);
+    }
+    if (stride == 1) return d2h(h, out, base, n);
+    launch_copy(h->sc, h->t1.d(), 1, base, stride, n);
+    return d2h(h, out, h->t1.d(), n);
+}
+
+int prcg_set_vector(prcg_t* h, int which, const double* in) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && in, "prcg_set_vector: no session or null buffer");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    const int64_t n = h->n;
+    double* base; int stride;
+    if (!locate(h, which, &base, &stride)) {
+        if (is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT)) return PRCG_OK;  // derived
+        return fail(h, PRCG_EINVAL, "prcg_set_vector: vector %d is not part of variant %d", which, h->variant);
+    }
+    if (stride == 1) return h2d(h, base, in, n);
+    if ((rc = h2d(h, h->t1.d(), in, n))) return rc;
+    launch_copy(h->sc, base, stride, h->t1.d(), 1, n);
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    return PRCG_OK;
+}
+
+int prcg_get_scalars(prcg_t* h, int k, double* out) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && out && k >= 0 && k <= h->max_iter, "prcg_get_scalars: bad argument");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    return d2h(h, out, dots_at(h, k), kNS);
+}
+
+int prcg_set_scalars(prcg_t* h, int k, const double* in) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && in && k >= 0 && k <= h->max_iter, "prcg_set_scalars: bad argument");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    return h2d(h, dots_at(h, k), in, kNS);
+}
+
+int prcg_get_coefficients(prcg_t* h, int k, double* out) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && out && k >= 1 && k <= h->max_iter, "prcg_get_coefficients: bad argument");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    return d2h(h, out, coef_at(h, k), 3);
+}
+
+int prcg_get_history(prcg_t* h, double* hist) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->in_session && hist, "prcg_get_history: no session or null buffer");
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    const int m = h->max_iter;
+    std::vector<double> all((size_t)(m + 1) * kNS);
+    if ((rc = d2h(h, all.data(), h->dots.d(), (int64_t)(m + 1) * kNS))) return rc;
+    static const int slot_of_bit[4] = {PRCG_S_RR, PRCG_S_RES2, PRCG_S_ERRA2, PRCG_S_ERR2};
+    int row = 0;
+    for (int bit = 0; bit < 4; ++bit) {
+        if (!(h->hist_mask & (1u << bit))) continue;
+        double* dst = hist + (size_t)row * m;
+        for (int k = 0; k < m; ++k)
+            dst[k] = k <= h->k ? std::sqrt(all[(size_t)k * kNS + slot_of_bit[bit]]) : 0.0;
+        ++row;
+    }
+    return PRCG_OK;
+}
+
+int prcg_set_profiling(prcg_t* h, int stride) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, stride >= 0, "prcg_set_profiling: negative stride");
+    h->prof_stride = stride;
+    h->n_ev_spmv = h->n_ev_upd = 0;
+    return PRCG_OK;
+}
+
+int prcg_get_timings(prcg_t* h, prcg_timings* t) {
+    if (!h || !t) return PRCG_EINVAL;
+    int rc = prcg_sync(h);
+    if (rc) return rc;
+    memset(t, 0, sizeof *t);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < h->n_ev_spmv; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_spmv[i].a, h->ev_spmv[i].b) == hipSuccess) s1 += ms;
+    }
+    for (int i = 0; i < h->n_ev_upd; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_upd[i].a, h->ev_upd[i].b) == hipSuccess) s2 += ms;
+    }
+    t->spmv_samples = h->n_ev_spmv;
+    t->spmv_ms = h->n_ev_spmv ? s1 / h->n_ev_spmv : 0.0;
+    t->update_ms = h->n_ev_upd ? s2 / h->n_ev_upd : 0.0;
+    t->tot_ms = h->last_tot_ms;
+    t->iterations = h->last_iters;
+    t->iter_ms = h->last_iters ? h->last_tot_ms / h->last_iters : 0.0;
+    return PRCG_OK;
+}
+
+int prcg_solve(prcg_t* h, int variant, const double* b, const double* x0, int max_iter, const double* x_true,
+               const double* inv_diag, uint32_t hist_mask, double* hist, double* x_out, prcg_timings* t) {
+    if (!h) return PRCG_EINVAL;
+    int rc = prcg_solve_begin(h, variant, b, x0, max_iter, x_true, inv_diag, hist_mask);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = prcg_iterate(h, max_iter - 1))) return rc;
+    if ((rc = prcg_sync(h))) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    h->last_tot_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    h->last_iters = max_iter - 1;
+    if (hist && hist_mask && (rc = prcg_get_history(h, hist))) return rc;
+    if (x_out && (rc = prcg_get_vector(h, PRCG_VEC_X, x_out))) return rc;
+    if (t) rc = prcg_get_timings(h, t);
+    return rc;
+}
+
+int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class, int cap_nnz, int cap_rows,
+                        int32_t* tiles_out, int64_t capacity, int64_t* n_class0) {
+    if (n < 0 || !indptr || cap_nnz < 1 || cap_rows < 1 || (!tiles_out && capacity > 0)) return -1;
+    std::vector<Tile> t0, t1;
+    plan_tiles(n, indptr, row_class, cap_nnz, cap_rows, t0, t1);
+    const int64_t total = (int64_t)t0.size() + (int64_t)t1.size();
+    if (n_class0) *n_class0 = (int64_t)t0.size();
+    if (total > capacity) return -total;   // tell the caller how much room is needed
+    int64_t o = 0;
+    for (const auto& t : t0) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
+    for (const auto& t : t1) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
+    return total;
+}
+
+void prcg_tile_caps(int* cap_nnz, int* cap_rows) {
+    if (cap_nnz) *cap_nnz = kTileCapNnz;
+    if (cap_rows) *cap_rows = kTileCapRows;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Launch wrappers of the gfx950 kernels (definitions: prcg_kernels.hip).
+// Internal to libprcg.so -- the public boundary is include/prcg.h.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace prcg {
+
+// ---- tile geometry (must agree with the host planner) -----------------------------
+// A tile is a run of consecutive rows handled by ONE wavefront: its nonzeros are
+// streamed with 16-byte loads, the products staged in that wave's LDS slice, and each
+// row reduced sequentially (left to right, as scipy's csr_matvec does) by one lane.
+constexpr int kTileSteps = 2;                       // 256-nnz steps per tile
+constexpr int kTileSlots = 256 * kTileSteps;        // LDS product slots per wave
+constexpr int kTileCapNnz = kTileSlots - 3;         // -3: the stream starts 16-B aligned
+constexpr int kTileCapRows = 256;
+constexpr int kMaxGridBlocks = 2048;                // 8 blocks x 256 CUs
+constexpr int kPartialStride = 8;                   // doubles per block in a partials array
+
+#ifndef PRCG_TILE_DEFINED
+#define PRCG_TILE_DEFINED
+struct Tile { int row_begin, row_end; };
+#endif
+
+// epilogues fused into the single-vector SpMV
+enum SpmvEpilogue {
+    kEpiNone = 0,
+    kEpiDotXY = 1,   // partial[0] += x_i * y_i                       (HS: mu = p.s; e'Ae)
+    kEpiPR = 2,      // st = d*y (or y); partials mu=p.s, dl=r.st, gm=st.s   (pr_pcg)
+};
+
+struct CsrDev {
+    const int* indptr;
+    const int* col;
+    const double* val;
+};
+
+// y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
+// partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.
+// returns the grid size used (needed to reduce the partials), <0 on launch failure.
+int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+                const double* x, double* y, SpmvEpilogue epi,
+                const double* ep_r, const double* ep_d, double* ep_st,
+                double* partials);
+
+// [w u] = A [r s] on interleaved pairs.  write_mask: 1 = first, 2 = second, 3 = both.
+int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+                 const double* rs, double* wu, int write_mask);
+
+// ---- fused vector updates + inner products -----------------------------------------
+struct PipeUpdateArgs {
+    int64_t n;
+    double* x;        // n
+    double* p;        // n
+    double* rs;       // pairs (r,s)  -- when preconditioned: the plain pair, no ghosts
+    double* rst;      // pairs (r~,s~) (preconditioned only; the SpMM input)
+    double* wu;       // pairs (w,u)
+    double* wt;       // w~ (preconditioned 'p' flavours only)
+    const double* d;  // inverse diagonal (preconditioned only)
+    const double* dots_prev;   // kNumScalars doubles: mu, dl, gm, nu of iteration k-1
+    double* coef_out;          // alpha, beta, nu_pred of this iteration
+    double* partials;          // [grid][kPartialStride]
+    int meurant;      // nu prediction flavour
+    int recompute_w;  // 'pr' flavours: w is overwritten by the following SpMM
+};
+int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a);
+// the four (five) inner products of the current pipe state, no update (initialisation)
+int launch_pipe_dots(hipStream_t st, const PipeUpdateArgs& a);
+
+struct HsArgs {
+    int64_t n;
+    double* x; double* r; double* rt; double* p; const double* s; const double* d;
+    const double* dots_prev; const double* dots_cur; double* coef_out; double* partials;
+};
+int launch_hs_update_xr(hipStream_t st, const HsArgs& a);   // x,r,(rt); partial nu (slot 3), rr (slot 4)
+int launch_hs_update_p(hipStream_t st, const HsArgs& a);    // p = z + beta p
+int launch_hs_init_dots(hipStream_t st, const HsArgs& a);   // nu, rr of the initial state
+
+struct PrArgs {   // non-pipelined predict-and-recompute (pr_pcg / m_pcg)
+    int64_t n;
+    double* x; double* r; double* rt; double* p; const double* s; const double* st_;
+    const double* dots_prev; double* coef_out; double* partials; int meurant; int precond;
+};
+int launch_pr_update(hipStream_t st, const PrArgs& a);      // x,r,rt,p; partial nu (3), rr (4)
+int launch_pr_init_dots(hipStream_t st, const PrArgs& a);
+
+// out[dst_first..+count) = fixed-order sum over blocks b of partials[b][src_first..+count)
+void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out,
+                         int src_first, int dst_first, int count);
+
+// ---- small utility kernels (strided so they can address one half of a pair array) ----
+void launch_copy(hipStream_t st, double* dst, int ds, const double* src, int ss, int64_t n);
+void launch_sub(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n);
+void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n);
+// partial[slot] = sum (a_i - b_i)^2
+int launch_diff_sq(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot);
+// buf[j*nc + c] = v[idx[j]*nc + c]
+void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc);
+
+}  // namespace prcg

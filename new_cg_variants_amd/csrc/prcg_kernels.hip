@@ -1,0 +1,610 @@
+// gfx950 (MI355X / CDNA4) kernels of the predict-and-recompute CG hot path.
+//
+// Everything here is HBM-bandwidth-bound fp64 streaming work (0.17-0.25 flop/byte):
+// no MFMA.  What matters is 16-byte coalesced loads of val/col_ind, enough bytes in
+// flight per CU, LDS-staged per-wavefront row reductions and wave64 shuffle reductions.
+//
+// Arithmetic contract (built with -ffp-contract=off): every update is `a + c*b` with
+// the product rounded first and every SpMV row is summed left to right without FMA,
+// exactly as NumPy / scipy._sparsetools.csr_matvec do in the reference
+// (numerical_experiments/cg_variants/pipe_pr_cg.py:61-75, hs_cg.py:54-61), so vectors
+// agree bit for bit with the reference given the same scalars; inner products use a
+// fixed reduction tree (thread-sequential -> wave xor-butterfly -> waves in order ->
+// blocks in order), deterministic run to run.
+#include <hip/hip_runtime.h>
+
+#include "prcg_kernels.h"
+
+namespace prcg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kElemsPerTrip = kBlock * 2;   // update kernels: 2 elements per thread per trip
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a contiguous
+// range of work items so neighbouring tiles (which gather overlapping x entries) meet
+// in the same 4 MiB L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// LDS traffic of ONE wave is processed in issue order; only the compiler has to be
+// kept from moving the row reads above the product writes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NV> struct VecT;
+template <> struct VecT<1> { using type = double; };
+template <> struct VecT<2> { using type = double2; };
+
+__device__ __forceinline__ double vmul(double a, double g) { return a * g; }
+__device__ __forceinline__ double2 vmul(double a, double2 g) { return make_double2(a * g.x, a * g.y); }
+__device__ __forceinline__ void vacc(double& s, double p) { s += p; }
+__device__ __forceinline__ void vacc(double2& s, double2 p) { s.x += p.x; s.y += p.y; }
+__device__ __forceinline__ void vzero(double& s) { s = 0.0; }
+__device__ __forceinline__ void vzero(double2& s) { s.x = 0.0; s.y = 0.0; }
+__device__ __forceinline__ double vwave_sum(double v) { return wave_sum(v); }
+__device__ __forceinline__ double2 vwave_sum(double2 v) { return make_double2(wave_sum(v.x), wave_sum(v.y)); }
+
+// block-level combine of per-lane accumulators -> partials[block][slot0 + q]
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NQ], double* partials, int slot0) {
+    __shared__ double red[kWaves][NQ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + slot0 + threadIdx.x] = v;
+    }
+}
+
+// ======================================================================================
+// CSR-adaptive SpMV / two-vector SpMM.
+// One wavefront per tile, persistent grid: wave `slot` handles tiles slot, slot+W, ...
+// so the chip sweeps the matrix as one front (stencil neighbours are fetched while
+// their lines are still in L2 / Infinity Cache).
+//   stream phase : 16-B loads of 4 column indices and 4 values per lane, gather of
+//                  x[col] (NV=2: one 16-B gather of the interleaved pair), products
+//                  into this wave's LDS slice;
+//   reduce phase : lane i sums row i of the tile sequentially from LDS and stores it.
+// A row longer than a tile is summed by the whole wave (partial sums + butterfly).
+// ======================================================================================
+template <int NV, int EPI, int STEPS>
+__global__ __launch_bounds__(kBlock) void k_spmv_tiles(
+    CsrDev A, const Tile* __restrict__ tiles, int ntiles,
+    const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
+    const double* __restrict__ ep_r, const double* __restrict__ ep_d,
+    double* __restrict__ ep_st, double* __restrict__ partials)
+{
+    using V = typename VecT<NV>::type;
+    constexpr int kSlots = 256 * STEPS;
+    constexpr int kCap = kSlots - 3;
+    __shared__ V prod[kWaves][kSlots];
+
+    const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    V* my = prod[wv];
+
+    double acc[3] = {0.0, 0.0, 0.0};
+
+    const int nblk = gridDim.x;
+    const int W = nblk * kWaves;
+    const int slot = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+
+    for (int t = slot; t < ntiles; t += W) {
+        const int rb = __builtin_amdgcn_readfirstlane(tiles[t].row_begin);
+        const int re = __builtin_amdgcn_readfirstlane(tiles[t].row_end);
+        const int lo = __builtin_amdgcn_readfirstlane(A.indptr[rb]);
+        const int hi = __builtin_amdgcn_readfirstlane(A.indptr[re]);
+
+        if (hi - lo > kCap) {
+            // ---- long row: the planner gives it a tile of its own (re == rb+1) ----
+            V sum; vzero(sum);
+            for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
+            sum = vwave_sum(sum);
+            if (lane == 0) {
+                if constexpr (NV == 1) {
+                    double* Y = reinterpret_cast<double*>(yout_);
+                    Y[rb] = sum;
+                    if constexpr (EPI == kEpiDotXY) acc[0] += X[rb] * sum;
+                    if constexpr (EPI == kEpiPR) {
+                        const double stv = ep_d ? ep_d[rb] * sum : sum;
+                        if (ep_st) ep_st[rb] = stv;
+                        acc[0] += X[rb] * sum; acc[1] += ep_r[rb] * stv; acc[2] += stv * sum;
+                    }
+                } else {
+                    double* Y = reinterpret_cast<double*>(yout_);
+                    if (write_mask & 1) Y[2 * (size_t)rb] = sum.x;
+                    if (write_mask & 2) Y[2 * (size_t)rb + 1] = sum.y;
+                }
+            }
+            continue;
+        }
+
+        // ---- stream phase ---------------------------------------------------------
+        // Branch-free: a lane whose chunk lies past the tile re-reads the tile's first
+        // chunk (one hot line) and parks its products in slots nobody reads, so all the
+        // 16-B loads of all steps are in flight together.
+        const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
+        int4 cc[STEPS];
+        double2 va[STEPS], vb[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int base = alo + st * 256 + lane * 4;
+            const int lb = base < hi ? base : alo;
+            cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+            va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+            vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const V g0 = X[cc[st].x], g1 = X[cc[st].y], g2 = X[cc[st].z], g3 = X[cc[st].w];
+            const int o = st * 256 + lane * 4;
+            my[o + 0] = vmul(va[st].x, g0);
+            my[o + 1] = vmul(va[st].y, g1);
+            my[o + 2] = vmul(vb[st].x, g2);
+            my[o + 3] = vmul(vb[st].y, g3);
+        }
+        wave_lds_sync();
+
+        // ---- reduce phase: one lane per row, left-to-right -------------------------
+        for (int row = rb + lane; row < re; row += 64) {
+            const int s = A.indptr[row] - alo;
+            const int e = A.indptr[row + 1] - alo;
+            V sum; vzero(sum);
+            int q = s;
+            for (; q + 4 <= e; q += 4) {   // 4 LDS reads in flight, adds stay in row order
+                const V p0 = my[q], p1 = my[q + 1], p2 = my[q + 2], p3 = my[q + 3];
+                vacc(sum, p0); vacc(sum, p1); vacc(sum, p2); vacc(sum, p3);
+            }
+            for (; q < e; ++q) vacc(sum, my[q]);
+            if constexpr (NV == 1) {
+                double* Y = reinterpret_cast<double*>(yout_);
+                Y[row] = sum;
+                if constexpr (EPI == kEpiDotXY) acc[0] += X[row] * sum;
+                if constexpr (EPI == kEpiPR) {
+                    const double stv = ep_d ? ep_d[row] * sum : sum;
+                    if (ep_st) ep_st[row] = stv;
+                    acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
+                }
+            } else {
+                if (write_mask == 3) {
+                    reinterpret_cast<double2*>(yout_)[row] = sum;
+                } else {
+                    double* Y = reinterpret_cast<double*>(yout_);
+                    if (write_mask & 1) Y[2 * (size_t)row] = sum.x;
+                    if (write_mask & 2) Y[2 * (size_t)row + 1] = sum.y;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+
+    if constexpr (EPI != kEpiNone) block_reduce_store<3>(acc, partials, 0);
+}
+
+// ======================================================================================
+// Fused vector updates + inner products.  Block b owns `trips` consecutive 512-element
+// trips; thread t handles elements 2t, 2t+1 of each trip with 16-byte accesses.
+// ======================================================================================
+struct Coefs { double al, bt, nup; };
+
+__device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {
+    // a_k1 = nu/mu; nu_k = nu - 2 a dl + a^2 gm (or Meurant's -nu + a^2 gm); b_k = nu_k/nu
+    // (numerical_experiments/cg_variants/pipe_pr_cg.py:64-66,75; Python evaluates
+    //  ((nu - (2a)dl) + (a^2)gm) left to right)
+    const double mu = dp[0], dl = dp[1], gm = dp[2], nu = dp[3];
+    Coefs c;
+    c.al = nu / mu;
+    const double a2 = c.al * c.al;
+    c.nup = meurant ? (-nu + a2 * gm) : ((nu - (2 * c.al) * dl) + a2 * gm);
+    c.bt = c.nup / nu;
+    return c;
+}
+
+template <bool PREC, bool DOTS_ONLY>
+__global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int trips) {
+    Coefs c = {0.0, 0.0, 0.0};
+    if constexpr (!DOTS_ONLY) {
+        c = predict(a.dots_prev, a.meurant);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.coef_out[0] = c.al; a.coef_out[1] = c.bt; a.coef_out[2] = c.nup;
+        }
+    }
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // mu, dl, gm, nu, rr
+    const int64_t n = a.n;
+    double2* __restrict__ RS = reinterpret_cast<double2*>(a.rs);
+    double2* __restrict__ RST = reinterpret_cast<double2*>(a.rst);
+    double2* __restrict__ WU = reinterpret_cast<double2*>(a.wu);
+
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+        if (i >= n) break;
+        const bool two = (i + 1 < n);
+        double xv[2], pv[2];
+        if (two) {
+            const double2 x2 = *reinterpret_cast<const double2*>(a.x + i);
+            const double2 p2 = *reinterpret_cast<const double2*>(a.p + i);
+            xv[0] = x2.x; xv[1] = x2.y; pv[0] = p2.x; pv[1] = p2.y;
+        } else {
+            xv[0] = a.x[i]; pv[0] = a.p[i]; xv[1] = 0.0; pv[1] = 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && !two) break;
+            const int64_t ie = i + e;
+            double2 rs = RS[ie];
+            if constexpr (DOTS_ONLY) {
+                if constexpr (PREC) {
+                    const double2 rst = RST[ie];
+                    acc[0] += pv[e] * rs.y; acc[1] += rs.x * rst.y; acc[2] += rst.y * rs.y;
+                    acc[3] += rst.x * rs.x; acc[4] += rs.x * rs.x;
+                } else {
+                    acc[0] += pv[e] * rs.y; acc[1] += rs.x * rs.y; acc[2] += rs.y * rs.y;
+                    acc[3] += rs.x * rs.x;
+                }
+                continue;
+            }
+            const double2 wu = WU[ie];
+            xv[e] = xv[e] + c.al * pv[e];                       // x += a p
+            const double rn = rs.x - c.al * rs.y;               // r -= a s
+            const double wn = wu.x - c.al * wu.y;               // w -= a u
+            if constexpr (PREC) {
+                double2 rst = RST[ie];
+                const double dv = a.d[ie];
+                const double ut = dv * wu.y;                    // u~ = M^-1 u
+                const double wt = a.recompute_w ? dv * wu.x : a.wt[ie];   // w~
+                const double rtn = rst.x - c.al * rst.y;        // r~ -= a s~
+                const double wtn = wt - c.al * ut;              // w~ -= a u~
+                const double pn = rtn + c.bt * pv[e];           // p = r~ + b p
+                const double sn = wn + c.bt * rs.y;             // s = w + b s
+                const double stn = wtn + c.bt * rst.y;          // s~ = w~ + b s~
+                pv[e] = pn;
+                RS[ie] = make_double2(rn, sn);
+                RST[ie] = make_double2(rtn, stn);
+                if (!a.recompute_w) { a.wu[2 * ie] = wn; a.wt[ie] = wtn; }
+                acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn;
+                acc[3] += rtn * rn; acc[4] += rn * rn;
+            } else {
+                const double pn = rn + c.bt * pv[e];            // p = r + b p
+                const double sn = wn + c.bt * rs.y;             // s = w + b s
+                pv[e] = pn;
+                RS[ie] = make_double2(rn, sn);
+                if (!a.recompute_w) a.wu[2 * ie] = wn;
+                acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+            }
+        }
+        if constexpr (!DOTS_ONLY) {
+            if (two) {
+                *reinterpret_cast<double2*>(a.x + i) = make_double2(xv[0], xv[1]);
+                *reinterpret_cast<double2*>(a.p + i) = make_double2(pv[0], pv[1]);
+            } else {
+                a.x[i] = xv[0]; a.p[i] = pv[0];
+            }
+        }
+    }
+    if constexpr (!PREC) acc[4] = acc[3];
+    block_reduce_store<5>(acc, a.partials, 0);
+}
+
+// ---- Hestenes-Stiefel (hs_cg.py:54-61, hs_pcg :116-124) ------------------------------
+template <bool PREC, bool DOTS_ONLY>
+__global__ __launch_bounds__(kBlock) void k_hs_update_xr(HsArgs a, int trips) {
+    double al = 0.0;
+    if constexpr (!DOTS_ONLY) {
+        al = a.dots_prev[3] / a.dots_prev[0];                   // a_k1 = nu/mu
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.coef_out[0] = al;
+    }
+    double acc[2] = {0.0, 0.0};   // nu, rr
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= a.n) break;
+            double rn = a.r[ie];
+            if constexpr (!DOTS_ONLY) {
+                a.x[ie] = a.x[ie] + al * a.p[ie];
+                rn = rn - al * a.s[ie];
+                a.r[ie] = rn;
+            }
+            if constexpr (PREC) {
+                const double z = a.d[ie] * rn;                  // r~ = M^-1 r
+                a.rt[ie] = z;
+                acc[0] += rn * z; acc[1] += rn * rn;
+            } else {
+                acc[0] += rn * rn;
+            }
+        }
+    }
+    if constexpr (!PREC) acc[1] = acc[0];
+    block_reduce_store<2>(acc, a.partials, 3);
+}
+
+__global__ __launch_bounds__(kBlock) void k_hs_update_p(HsArgs a, int trips) {
+    const double bt = a.dots_cur[3] / a.dots_prev[3];           // b_k = nu_k / nu_k1
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.coef_out[1] = bt;
+    const double* __restrict__ z = a.rt ? a.rt : a.r;
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= a.n) break;
+            a.p[ie] = z[ie] + bt * a.p[ie];                     // p = r~ + b p
+        }
+    }
+}
+
+// ---- non-pipelined predict-and-recompute (pr_cg.py:146-151) ---------------------------
+template <bool PREC, bool DOTS_ONLY>
+__global__ __launch_bounds__(kBlock) void k_pr_update(PrArgs a, int trips) {
+    Coefs c = {0.0, 0.0, 0.0};
+    if constexpr (!DOTS_ONLY) {
+        c = predict(a.dots_prev, a.meurant);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.coef_out[0] = c.al; a.coef_out[1] = c.bt; a.coef_out[2] = c.nup;
+        }
+    }
+    double acc[2] = {0.0, 0.0};   // nu = r~.r, rr
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= a.n) break;
+            double rn = a.r[ie];
+            double rtn = PREC ? a.rt[ie] : rn;
+            if constexpr (!DOTS_ONLY) {
+                a.x[ie] = a.x[ie] + c.al * a.p[ie];
+                rn = rn - c.al * a.s[ie];
+                a.r[ie] = rn;
+                if constexpr (PREC) {
+                    rtn = rtn - c.al * a.st_[ie];
+                    a.rt[ie] = rtn;
+                } else {
+                    rtn = rn;
+                }
+                a.p[ie] = rtn + c.bt * a.p[ie];
+            }
+            acc[0] += rtn * rn; acc[1] += rn * rn;
+        }
+    }
+    block_reduce_store<2>(acc, a.partials, 3);
+}
+
+// ---- fixed-order final reduction of per-block partials --------------------------------
+constexpr int kFinalThreads = 1024;
+__global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
+    const double* __restrict__ partials, int nparts, double* __restrict__ out,
+    int src_first, int dst_first, int count)
+{
+    __shared__ double red[kFinalThreads / 64][kPartialStride];
+    double acc[kPartialStride];
+#pragma unroll
+    for (int q = 0; q < kPartialStride; ++q) acc[q] = 0.0;
+    for (int j = threadIdx.x; j < nparts; j += kFinalThreads) {
+#pragma unroll
+        for (int q = 0; q < kPartialStride; ++q)
+            if (q < count) acc[q] += partials[(size_t)j * kPartialStride + src_first + q];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kPartialStride; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < kFinalThreads / 64; ++w) v += red[w][threadIdx.x];
+        out[dst_first + threadIdx.x] = v;
+    }
+}
+
+// ---- utilities -------------------------------------------------------------------------
+__global__ void k_copy(double* dst, int ds, const double* src, int ss, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i * ds] = src[i * ss];
+}
+__global__ void k_sub(double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i * ds] = a[i * as] - b[i * bs];
+}
+__global__ void k_mul(double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i * ds] = a[i * as] * b[i * bs];
+}
+__global__ __launch_bounds__(kBlock) void k_diff_sq(const double* __restrict__ a, const double* __restrict__ b,
+                                                    int64_t n, double* partials, int slot, int trips) {
+    double acc[1] = {0.0};
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= n) break;
+            const double dlt = a[ie] - b[ie];
+            acc[0] += dlt * dlt;
+        }
+    }
+    block_reduce_store<1>(acc, partials, slot);
+}
+__global__ void k_pack(double* buf, const double* v, const int* idx, int64_t count, int nc) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = idx[j];
+        for (int c = 0; c < nc; ++c) buf[j * nc + c] = v[src * nc + c];
+    }
+}
+
+struct Chunking { int grid; int trips; };
+Chunking chunking(int64_t n) {
+    const int64_t total = (n + kElemsPerTrip - 1) / kElemsPerTrip;
+    int64_t grid = total < kMaxGridBlocks ? total : kMaxGridBlocks;
+    if (grid < 1) grid = 1;
+    const int64_t trips = (total + grid - 1) / grid;
+    grid = trips > 0 ? (total + trips - 1) / trips : 1;
+    if (grid < 1) grid = 1;
+    return {(int)grid, (int)(trips > 0 ? trips : 1)};
+}
+
+int util_grid(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// occupancy-capped persistent grid for the tile kernels
+template <int TAG, typename K>
+int tile_grid(K kernel, int ntiles) {
+    static int cap = 0;   // per TAG (the kernels share one function-pointer type)
+    if (cap == 0) {
+        int dev = 0, cus = 256, occ = 4;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
+        }
+        cap = occ * cus;
+    }
+    int g = (ntiles + kWaves - 1) / kWaves;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return g;
+}
+
+}  // namespace
+
+// ---- launch wrappers -------------------------------------------------------------------
+#define PRCG_LAUNCH_OK() (hipGetLastError() == hipSuccess)
+
+int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+                const double* x, double* y, SpmvEpilogue epi,
+                const double* ep_r, const double* ep_d, double* ep_st, double* partials)
+{
+    if (ntiles <= 0) return 0;
+    int grid = 0;
+    switch (epi) {
+    case kEpiNone: {
+        auto k = k_spmv_tiles<1, kEpiNone, kTileSteps>;
+        grid = tile_grid<0>(k, ntiles);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+        break; }
+    case kEpiDotXY: {
+        auto k = k_spmv_tiles<1, kEpiDotXY, kTileSteps>;
+        grid = tile_grid<1>(k, ntiles);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+        break; }
+    case kEpiPR: {
+        auto k = k_spmv_tiles<1, kEpiPR, kTileSteps>;
+        grid = tile_grid<2>(k, ntiles);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+        break; }
+    }
+    return PRCG_LAUNCH_OK() ? grid : -1;
+}
+
+int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+                 const double* rs, double* wu, int write_mask)
+{
+    if (ntiles <= 0) return 0;
+    auto k = k_spmv_tiles<2, kEpiNone, kTileSteps>;
+    const int grid = tile_grid<3>(k, ntiles);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, rs, wu, write_mask,
+                       (const double*)nullptr, (const double*)nullptr, (double*)nullptr, (double*)nullptr);
+    return PRCG_LAUNCH_OK() ? grid : -1;
+}
+
+int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.d) hipLaunchKernelGGL((k_pipe_update<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else     hipLaunchKernelGGL((k_pipe_update<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_pipe_dots(hipStream_t st, const PipeUpdateArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.d) hipLaunchKernelGGL((k_pipe_update<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else     hipLaunchKernelGGL((k_pipe_update<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+
+int launch_hs_update_xr(hipStream_t st, const HsArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else     hipLaunchKernelGGL((k_hs_update_xr<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_hs_init_dots(hipStream_t st, const HsArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else     hipLaunchKernelGGL((k_hs_update_xr<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_hs_update_p(hipStream_t st, const HsArgs& a) {
+    const Chunking c = chunking(a.n);
+    hipLaunchKernelGGL(k_hs_update_p, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+
+int launch_pr_update(hipStream_t st, const PrArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.precond) hipLaunchKernelGGL((k_pr_update<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else           hipLaunchKernelGGL((k_pr_update<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_pr_init_dots(hipStream_t st, const PrArgs& a) {
+    const Chunking c = chunking(a.n);
+    if (a.precond) hipLaunchKernelGGL((k_pr_update<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else           hipLaunchKernelGGL((k_pr_update<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+
+void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out,
+                         int src_first, int dst_first, int count) {
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kFinalThreads), 0, st, partials, nparts, out, src_first, dst_first, count);
+}
+
+void launch_copy(hipStream_t st, double* dst, int ds, const double* src, int ss, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_copy, dim3(util_grid(n)), dim3(256), 0, st, dst, ds, src, ss, n);
+}
+void launch_sub(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sub, dim3(util_grid(n)), dim3(256), 0, st, dst, ds, a, as, b, bs, n);
+}
+void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_mul, dim3(util_grid(n)), dim3(256), 0, st, dst, ds, a, as, b, bs, n);
+}
+int launch_diff_sq(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot) {
+    const Chunking c = chunking(n);
+    hipLaunchKernelGGL(k_diff_sq, dim3(c.grid), dim3(kBlock), 0, st, a, b, n, partials, slot, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_pack, dim3(util_grid(count)), dim3(256), 0, st, buf, v, idx, count, nc);
+}
+
+}  // namespace prcg

@@ -1,0 +1,17 @@
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace prcg {
+
+#ifndef PRCG_TILE_DEFINED
+#define PRCG_TILE_DEFINED
+struct Tile { int row_begin, row_end; };
+#endif
+
+void plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
+                int cap_nnz, int cap_rows,
+                std::vector<Tile>& class0, std::vector<Tile>& class1);
+
+}  // namespace prcg

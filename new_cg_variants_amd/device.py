@@ -1,0 +1,203 @@
+"""Host-side owner of one libprcg handle: one GPU, one row block, one rank.
+
+This is the thin layer between SciPy CSR arrays and the C-ABI (include/prcg.h); every
+numerical operation happens in the HIP kernels behind it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceCSR:
+    """A CSR row block resident on one MI355X.
+
+    ``A`` is what the reference passes around as ``A``: a ``scipy.sparse`` CSR matrix
+    (numerical_experiments/figure_gen.py:350).  For a multi-rank run ``A`` is the rank's
+    row block with LOCAL column numbering and ``halo`` the plan produced by
+    ``partition.plan_halo`` (columns >= n_rows are ghosts).
+    """
+
+    def __init__(self, A, device=0, comm_init=None, halo=None):
+        self._h = C.c_void_p()
+        self._lib = L.lib()
+        rc = self._lib.prcg_create(C.byref(self._h), int(device))
+        if rc != L.OK:
+            msg = self._lib.prcg_last_error(None)
+            self._h = C.c_void_p()
+            raise L.PrcgError(rc, msg.decode() if msg else '?')
+        self.rank, self.nranks = 0, 1
+        if comm_init is not None:
+            rank, nranks, uid, path = comm_init
+            self._check(self._lib.prcg_comm_init(self._h, path.encode() if path else None, rank, nranks,
+                                                 L.ptr(np.frombuffer(uid, dtype=np.uint8).copy())))
+            self.rank, self.nranks = rank, nranks
+        self._set_matrix(A, halo)
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        L.check(self._h, rc)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.prcg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _set_matrix(self, A, halo):
+        if not hasattr(A, 'indptr'):
+            raise TypeError('A must be a scipy.sparse CSR matrix/array')
+        if A.format != 'csr':
+            A = A.tocsr()
+        if A.dtype != np.float64:
+            raise TypeError(f'fp64 only (got {A.dtype}); the reference works in double precision')
+        n_rows, n_cols = A.shape
+        n_ghost = n_cols - n_rows
+        if n_ghost < 0:
+            raise ValueError('row block must have at least n_rows columns (local numbering)')
+        if n_ghost > 0 and halo is None and self.nranks > 1:
+            raise ValueError('ghost columns need a halo plan')
+        indptr = np.ascontiguousarray(A.indptr)
+        is64 = indptr.dtype == np.int64
+        if not is64:
+            indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        data = np.ascontiguousarray(A.data, dtype=np.float64)
+        self.n, self.n_ghost, self.nnz = int(n_rows), int(n_ghost), int(A.nnz)
+        self._check(self._lib.prcg_set_csr(self._h, self.n, self.n_ghost, self.nnz, L.ptr(indptr), int(is64),
+                                           L.ptr(indices), L.ptr(data)))
+        if halo is not None:
+            peers = np.ascontiguousarray(halo['peers'], dtype=np.int32)
+            send_ptr = np.ascontiguousarray(halo['send_ptr'], dtype=np.int64)
+            send_idx = np.ascontiguousarray(halo['send_idx'], dtype=np.int32)
+            recv_ptr = np.ascontiguousarray(halo['recv_ptr'], dtype=np.int64)
+            self._check(self._lib.prcg_set_halo(self._h, len(peers), L.ptr(peers), L.ptr(send_ptr),
+                                                L.ptr(send_idx), L.ptr(recv_ptr)))
+
+    # -- products (tests / bench) ---------------------------------------------------------
+    def matvec(self, x, reps=1):
+        """y = A x on the device; returns (y, mean ms per launch)."""
+        x = L.f64(x)
+        assert x.shape == (self.n,)
+        y = np.empty(self.n)
+        ms = C.c_double(0.0)
+        self._check(self._lib.prcg_spmv(self._h, L.ptr(x), L.ptr(y), int(reps), C.byref(ms)))
+        return y, ms.value
+
+    def matmat2(self, RS, reps=1):
+        """[w u] = A [r s] for an (n,2) array; returns ((n,2) array, mean ms per launch)."""
+        RS = L.f64(RS)
+        assert RS.shape == (self.n, 2)
+        WU = np.empty((self.n, 2))
+        ms = C.c_double(0.0)
+        self._check(self._lib.prcg_spmm2(self._h, L.ptr(RS), L.ptr(WU), int(reps), C.byref(ms)))
+        return WU, ms.value
+
+    # -- solver session ------------------------------------------------------------------------
+    def begin(self, variant, b, x0, max_iter, x_true=None, inv_diag=None, hist_mask=0):
+        b, x0 = L.f64(b), L.f64(x0)
+        assert b.shape == (self.n,) and x0.shape == (self.n,)
+        xt = None if x_true is None else L.f64(x_true)
+        dv = None if inv_diag is None else L.f64(inv_diag)
+        self._check(self._lib.prcg_solve_begin(self._h, int(variant), L.ptr(b), L.ptr(x0), int(max_iter),
+                                               L.ptr(xt), L.ptr(dv), int(hist_mask)))
+        self.max_iter, self.hist_mask = int(max_iter), int(hist_mask)
+
+    def iterate(self, iters):
+        self._check(self._lib.prcg_iterate(self._h, int(iters)))
+
+    def sync(self):
+        self._check(self._lib.prcg_sync(self._h))
+
+    @property
+    def k(self):
+        return self._lib.prcg_iteration(self._h)
+
+    def set_iteration(self, k):
+        self._check(self._lib.prcg_set_iteration(self._h, int(k)))
+
+    def get_vector(self, name):
+        out = np.empty(self.n)
+        self._check(self._lib.prcg_get_vector(self._h, L.VEC[name], L.ptr(out)))
+        return out
+
+    def set_vector(self, name, v):
+        v = L.f64(v)
+        assert v.shape == (self.n,)
+        self._check(self._lib.prcg_set_vector(self._h, L.VEC[name], L.ptr(v)))
+
+    def get_scalars(self, k):
+        out = np.empty(L.NUM_SCALARS)
+        self._check(self._lib.prcg_get_scalars(self._h, int(k), L.ptr(out)))
+        return out
+
+    def set_scalars(self, k, values):
+        v = L.f64(values)
+        assert v.shape == (L.NUM_SCALARS,)
+        self._check(self._lib.prcg_set_scalars(self._h, int(k), L.ptr(v)))
+
+    def get_coefficients(self, k):
+        out = np.empty(3)
+        self._check(self._lib.prcg_get_coefficients(self._h, int(k), L.ptr(out)))
+        return out
+
+    def history(self):
+        """dict recorder-name -> array(max_iter) for the recorders of this session."""
+        names = [q for q, bit in sorted(L.HIST_BITS.items(), key=lambda kv: kv[1]) if self.hist_mask & bit]
+        if not names:
+            return {}
+        buf = np.zeros((len(names), self.max_iter))
+        self._check(self._lib.prcg_get_history(self._h, L.ptr(buf)))
+        return {q: buf[i].copy() for i, q in enumerate(names)}
+
+    def set_profiling(self, stride):
+        self._check(self._lib.prcg_set_profiling(self._h, int(stride)))
+
+    def timings(self):
+        t = L.Timings()
+        self._check(self._lib.prcg_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def solve(self, variant, b, x0, max_iter, x_true=None, inv_diag=None, hist_mask=0):
+        """One C call: begin + (max_iter-1) iterations + histories + x (prcg_solve)."""
+        b, x0 = L.f64(b), L.f64(x0)
+        xt = None if x_true is None else L.f64(x_true)
+        dv = None if inv_diag is None else L.f64(inv_diag)
+        nh = bin(hist_mask).count('1')
+        hist = np.zeros((max(nh, 1), max_iter))
+        x = np.empty(self.n)
+        t = L.Timings()
+        self._check(self._lib.prcg_solve(self._h, int(variant), L.ptr(b), L.ptr(x0), int(max_iter), L.ptr(xt),
+                                         L.ptr(dv), int(hist_mask), L.ptr(hist) if nh else None, L.ptr(x),
+                                         C.byref(t)))
+        self.max_iter, self.hist_mask = int(max_iter), int(hist_mask)
+        names = [q for q, bit in sorted(L.HIST_BITS.items(), key=lambda kv: kv[1]) if hist_mask & bit]
+        return x, {q: hist[i].copy() for i, q in enumerate(names)}, t.as_dict()
+
+
+def plan_tiles(indptr, row_class=None, cap_nnz=None, cap_rows=None):
+    """Host-only view of the CSR-adaptive tiling (no GPU needed): returns
+    (tiles[(row_begin,row_end)], n_class0)."""
+    lib = L.lib()
+    if cap_nnz is None or cap_rows is None:
+        a, b = C.c_int(0), C.c_int(0)
+        lib.prcg_tile_caps(C.byref(a), C.byref(b))
+        cap_nnz = cap_nnz or a.value
+        cap_rows = cap_rows or b.value
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    n = len(indptr) - 1
+    rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
+    cap = n + 1
+    out = np.zeros((cap, 2), dtype=np.int32)
+    n0 = C.c_int64(0)
+    got = lib.prcg_plan_tiles(n, L.ptr(indptr), L.ptr(rc), int(cap_nnz), int(cap_rows), L.ptr(out), cap,
+                              C.byref(n0))
+    if got < 0:
+        raise RuntimeError('prcg_plan_tiles failed')
+    return out[:got].copy(), int(n0.value)

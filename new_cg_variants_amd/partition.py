@@ -1,0 +1,104 @@
+"""Row-block partition of a CSR operator and the halo plan between the blocks.
+
+Pure host logic (NumPy), no GPU and no communication library: the exchange of the
+"who needs what" lists is delegated to an ``allgather(obj) -> [obj_rank0, ...]``
+callable (torch.distributed.all_gather_object in production, a plain list in tests).
+
+Layout produced for rank ``r`` owning global rows ``[lo, hi)``:
+
+* local columns ``[0, n_local)``          = owned entries (global id - lo)
+* local columns ``[n_local, n_local+g)``  = ghosts, sorted by global id, hence grouped
+  by owning rank in ascending order; ``recv_ptr`` delimits the groups;
+* ``send_idx[send_ptr[q]:send_ptr[q+1]]`` = local rows whose entries peer ``q`` asked
+  for, in the order of that peer's ghost list (= ascending global id).
+
+The order of the nonzeros inside each row is left untouched, so a distributed SpMV sums
+every row in exactly the order the single-GPU (and SciPy) product does.
+
+This replaces the reference's dense column blocks + full-vector Allreduce
+(scaling_experiments_mpi4py/scaling_tests.py:51-54, cg_variants/pipe_pr_cg.py:65-67)
+with the row-block layout PETSc's MPIAIJ uses in its third experiment
+(scaling_experiments_petsc/ex2b.c:67-71).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def even_offsets(n, nranks):
+    """Contiguous row ranges of (almost) equal length: offsets[r]..offsets[r+1]."""
+    base, extra = divmod(int(n), int(nranks))
+    sizes = np.full(nranks, base, dtype=np.int64)
+    sizes[:extra] += 1
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def nnz_balanced_offsets(indptr, nranks):
+    """Split points that balance the nonzeros (prefix sum over the row pointer)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n = len(indptr) - 1
+    targets = indptr[-1] * np.arange(1, nranks) / nranks
+    cuts = np.searchsorted(indptr, targets, side='left')
+    off = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    return np.maximum.accumulate(off)
+
+
+def localize(A_rows, lo, hi):
+    """Renumber the columns of the row block ``A_rows`` (shape n_local x n_global, global
+    column ids) to the local layout.  Returns (A_local, ghost_ids)."""
+    A_rows = A_rows.tocsr()
+    n_local = hi - lo
+    assert A_rows.shape[0] == n_local
+    cols = A_rows.indices.astype(np.int64, copy=False)
+    owned = (cols >= lo) & (cols < hi)
+    ghost_ids = np.unique(cols[~owned])
+    new_cols = np.empty(cols.shape, dtype=np.int32)
+    new_cols[owned] = (cols[owned] - lo).astype(np.int32)
+    if ghost_ids.size:
+        new_cols[~owned] = (n_local + np.searchsorted(ghost_ids, cols[~owned])).astype(np.int32)
+    A_local = sp.csr_matrix((A_rows.data, new_cols, A_rows.indptr), shape=(n_local, n_local + ghost_ids.size))
+    return A_local, ghost_ids
+
+
+def plan_halo(ghost_ids, offsets, rank, allgather):
+    """Build the halo plan of ``rank`` (dict with peers, send_ptr, send_idx, recv_ptr)."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    nranks = len(offsets) - 1
+    lo = offsets[rank]
+    owner = np.searchsorted(offsets, ghost_ids, side='right') - 1 if ghost_ids.size else np.zeros(0, dtype=np.int64)
+    assert not np.any(owner == rank)
+    wants = {int(q): ghost_ids[owner == q] for q in np.unique(owner)}        # what I need, per owner
+    everyone = allgather(wants)                                              # list over ranks
+    gives = {q: np.asarray(everyone[q][rank], dtype=np.int64)
+             for q in range(nranks) if q != rank and rank in everyone[q] and len(everyone[q][rank])}
+    peers = sorted(set(wants) | set(gives))
+    send_ptr, recv_ptr, send_idx = [0], [0], []
+    for q in peers:
+        s = gives.get(q, np.zeros(0, dtype=np.int64))
+        send_idx.append((s - lo).astype(np.int32))
+        send_ptr.append(send_ptr[-1] + len(s))
+        recv_ptr.append(recv_ptr[-1] + len(wants.get(q, ())))
+    send_idx = np.concatenate(send_idx) if send_idx else np.zeros(0, dtype=np.int32)
+    n_local = offsets[rank + 1] - lo
+    assert send_idx.size == 0 or (send_idx.min() >= 0 and send_idx.max() < n_local)
+    assert recv_ptr[-1] == ghost_ids.size
+    return {'peers': np.asarray(peers, dtype=np.int32), 'send_ptr': np.asarray(send_ptr, dtype=np.int64),
+            'send_idx': send_idx, 'recv_ptr': np.asarray(recv_ptr, dtype=np.int64)}
+
+
+def split_serial(A, nranks, offsets=None):
+    """Partition a whole matrix in one process (tests, single-process drivers): returns
+    (offsets, [(A_local, ghost_ids, halo)] per rank)."""
+    A = A.tocsr()
+    n = A.shape[0]
+    offsets = even_offsets(n, nranks) if offsets is None else np.asarray(offsets, dtype=np.int64)
+    local = [localize(A[offsets[r]:offsets[r + 1]], offsets[r], offsets[r + 1]) for r in range(nranks)]
+    wants_all = []
+    for r in range(nranks):
+        g = local[r][1]
+        owner = np.searchsorted(offsets, g, side='right') - 1 if g.size else np.zeros(0, dtype=np.int64)
+        wants_all.append({int(q): g[owner == q] for q in np.unique(owner)})
+    out = []
+    for r in range(nranks):
+        halo = plan_halo(local[r][1], offsets, r, lambda _w: wants_all)
+        out.append((local[r][0], local[r][1], halo))
+    return offsets, out

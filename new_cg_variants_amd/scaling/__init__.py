@@ -1,0 +1,151 @@
+"""Distributed CG variants with the call shape of the reference's mpi4py experiment:
+
+    sol, times = variant(comm, A, b, max_iter)
+    (scaling_experiments_mpi4py/scaling_tests.py:71; cg_variants/pipe_pr_cg.py:7, hs_cg.py:7)
+
+one process per GPU.  ``comm`` is a communicator-like object (``TorchComm`` wraps
+torch.distributed; anything with Get_rank/Get_size/Barrier/allgather_obj/bcast_obj
+works); ``A`` is the rank's CSR row block with GLOBAL column ids (shape n_local x n) --
+or a ``RowBlockOperator`` already resident on the GPU; ``b`` the rank's slice of the
+right-hand side.  As in the reference x0 = 0, r0 = p0 = b, the loop body runs
+``max_iter`` times, the return value is the local slice of x and ``{'tot': seconds}`` on
+rank 0 (``None`` elsewhere), and the clock starts/stops between barriers
+(pipe_pr_cg.py:54-56,85-87).
+
+What differs by design (BASELINE.json north_star): the operator is a sparse row block,
+not a dense column block, so the per-iteration traffic is a neighbour halo exchange of
+the SpMV input plus ONE 5-double RCCL all-reduce, issued on a side stream and overlapped
+with the interior rows of the matrix product (HS-CG: two dependent all-reduces, nothing
+to overlap them with -- that contrast is the experiment).
+"""
+import os
+import time
+
+import numpy as np
+
+from .. import _lib as L
+from .. import partition
+from ..device import DeviceCSR
+
+
+class TorchComm:
+    """torch.distributed as a communicator-like object (control plane only: the
+    per-iteration data path is RCCL inside libprcg.so)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+
+    def Get_rank(self):
+        return self._dist.get_rank(self._group)
+
+    def Get_size(self):
+        return self._dist.get_world_size(self._group)
+
+    def Barrier(self):
+        self._dist.barrier(self._group)
+
+    def allgather_obj(self, obj):
+        out = [None] * self.Get_size()
+        self._dist.all_gather_object(out, obj, group=self._group)
+        return out
+
+    def bcast_obj(self, obj, root=0):
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=root, group=self._group)
+        return box[0]
+
+
+class SelfComm:
+    """The one-rank communicator (no torch needed)."""
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return 1
+
+    def Barrier(self):
+        pass
+
+    def allgather_obj(self, obj):
+        return [obj]
+
+    def bcast_obj(self, obj, root=0):
+        return obj
+
+
+class RowBlockOperator:
+    """The rank's row block on its GPU, halo plan and RCCL communicator included."""
+
+    def __init__(self, comm, A_rows, device=None, rccl_path=None):
+        self.comm = comm
+        rank, size = comm.Get_rank(), comm.Get_size()
+        n_local, n = A_rows.shape
+        sizes = comm.allgather_obj(int(n_local))
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        if self.offsets[-1] != n:
+            raise ValueError(f'row blocks cover {self.offsets[-1]} rows of an n={n} operator')
+        lo, hi = int(self.offsets[rank]), int(self.offsets[rank + 1])
+        self.n_local, self.n = n_local, n
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        comm_init = None
+        halo = None
+        if size > 1:
+            A_local, self.ghost_ids = partition.localize(A_rows, lo, hi)
+            halo = partition.plan_halo(self.ghost_ids, self.offsets, rank, comm.allgather_obj)
+            path = rccl_path or L.default_rccl_path()
+            lib = L.lib()
+            uid = None
+            if rank == 0:
+                buf = np.zeros(128, dtype=np.uint8)
+                L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf)))
+                uid = buf.tobytes()
+            uid = comm.bcast_obj(uid, root=0)
+            comm_init = (rank, size, uid, path)
+        else:
+            A_local = A_rows.tocsr()
+            self.ghost_ids = np.zeros(0, dtype=np.int64)
+        self.dev = DeviceCSR(A_local, device=device, comm_init=comm_init, halo=halo)
+
+
+def _as_operator(comm, A):
+    return A if isinstance(A, RowBlockOperator) else RowBlockOperator(comm, A)
+
+
+def _timed(comm, op, variant, b, max_iter):
+    dev = op.dev
+    b = L.f64(b)
+    rank = comm.Get_rank()
+    times = {'tot': 0., 'c_ip': 0., 'c_mv': 0., 'w_mv': 0., 'w_ip': 0., 'w_vec': 0.} if rank == 0 else None
+    # x0 = 0, r0 = p0 = b; one extra history slot because the reference's loop body runs
+    # max_iter times (pipe_pr_cg.py:58), not max_iter - 1
+    dev.begin(variant, b, np.zeros_like(b), max_iter + 1)
+    comm.Barrier()
+    t0 = time.perf_counter()
+    dev.iterate(max_iter)
+    dev.sync()
+    comm.Barrier()
+    if rank == 0:
+        times['tot'] = time.perf_counter() - t0
+    return dev.get_vector('x'), times
+
+
+def pipe_pr_cg(comm, A, b, max_iter):
+    """Pipelined predict-and-recompute CG (scaling_experiments_mpi4py/cg_variants/pipe_pr_cg.py:7)."""
+    return _timed(comm, _as_operator(comm, A), L.PIPE_PR, b, max_iter)
+
+
+def hs_cg(comm, A, b, max_iter):
+    """Hestenes-Stiefel CG, the two-reduction baseline (cg_variants/hs_cg.py:7)."""
+    return _timed(comm, _as_operator(comm, A), L.HS, b, max_iter)
+
+
+def pr_cg(comm, A, b, max_iter):
+    """Predict-and-recompute CG, one (blocking) reduction per iteration (cg_variants/pr_cg.py)."""
+    return _timed(comm, _as_operator(comm, A), L.PR, b, max_iter)
+
+
+__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'hs_cg', 'pr_cg']

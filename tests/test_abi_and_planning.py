@@ -1,0 +1,123 @@
+"""CPU: the C-ABI library loads, exports every symbol include/prcg.h declares, refuses
+to work without a GPU (no CPU fallback), and its host-only planning is sound."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from new_cg_variants_amd import _lib as L
+from new_cg_variants_amd import problems
+from new_cg_variants_amd.device import plan_tiles
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'prcg.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(prcg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in include/prcg.h but not exported'
+    # and the binding covers exactly the header
+    assert sorted(L._SIGNATURES) == names
+    assert lib.prcg_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a GPU creating a handle must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    h = C.c_void_p()
+    rc = L.lib().prcg_create(C.byref(h), 0)
+    assert rc == L.EHIP and not h.value
+    assert b'no CPU fallback' in L.lib().prcg_last_error(None)
+    from new_cg_variants_amd.cg_variants import hs_cg
+    A = problems.laplace_2d(8, 8)
+    with pytest.raises(L.PrcgError):
+        hs_cg(A, np.ones(64), np.zeros(64), 5)
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure; nothing in the package may reference it."""
+    pkg = os.path.join(ROOT, 'new_cg_variants_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'ne_oracle' not in src and 'mp_oracle' not in src, f
+
+
+def check_tiles(indptr, tiles, n0, cap_nnz, cap_rows, row_class=None):
+    n = len(indptr) - 1
+    covered = np.zeros(n, dtype=np.int32)
+    for t, (rb, re_) in enumerate(tiles):
+        assert 0 <= rb < re_ <= n
+        covered[rb:re_] += 1
+        nn = indptr[re_] - indptr[rb]
+        assert (re_ - rb) <= cap_rows
+        assert nn <= cap_nnz or re_ == rb + 1          # only a single long row may exceed the cap
+        if row_class is not None:
+            cls = row_class[rb:re_]
+            assert np.all(cls == cls[0])
+            assert (cls[0] != 0) == (t >= n0)           # class-0 tiles come first
+    assert np.all(covered == 1), 'every row in exactly one tile'
+
+
+def test_tile_caps_match_kernel_constants():
+    a, b = C.c_int(0), C.c_int(0)
+    L.lib().prcg_tile_caps(C.byref(a), C.byref(b))
+    assert a.value % 256 == 253 and b.value >= 64       # 256*steps - 3
+
+
+@pytest.mark.parametrize('name', ['s1_small', 's3_small'])
+def test_tiling_regular_matrices(name):
+    A = problems.WORKLOADS[name]['make']()
+    tiles, n0 = plan_tiles(A.indptr)
+    assert n0 == len(tiles)
+    check_tiles(A.indptr, tiles, n0, 509, 256)
+    # packing is tight: no tile could have taken the next row
+    for rb, re_ in tiles[:-1]:
+        nn = A.indptr[re_] - A.indptr[rb]
+        nxt = A.indptr[re_ + 1] - A.indptr[re_]
+        assert nn + nxt > 509 or (re_ - rb) == 256
+
+
+def test_tiling_ragged_empty_and_long_rows():
+    rng = np.random.default_rng(7)
+    lens = rng.integers(0, 40, size=5000)
+    lens[100] = 3000        # longer than a tile
+    lens[101] = 509         # exactly a tile
+    lens[102] = 510         # one more than a tile
+    lens[200:700] = 0       # a long run of empty rows (row cap must cut it)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cls = (rng.random(5000) < 0.1).astype(np.uint8)
+    tiles, n0 = plan_tiles(indptr, cls)
+    check_tiles(indptr, tiles, n0, 509, 256, cls)
+    tiles2, n02 = plan_tiles(indptr, None, cap_nnz=64, cap_rows=8)
+    check_tiles(indptr, tiles2, n02, 64, 8)
+    # empty matrix
+    t0, _ = plan_tiles(np.zeros(1, dtype=np.int32))
+    assert len(t0) == 0
+
+
+def test_generators_match_their_stated_sizes():
+    A = problems.laplace_2d(1000, 1000, rows=(0, 3000))
+    assert A.shape == (3000, 1_000_000)
+    full_nnz_s1 = 5 * 1_000_000 - 4 * 1000
+    assert full_nnz_s1 == 4_996_000
+    assert 7 * 216**3 - 6 * 216**2 == 70_263_936
+    assert 15 * 10_000_000 - 2 * sum(range(1, 8)) == 149_999_944
+    B = problems.banded_ex2b(5000, 7)
+    assert B.nnz == 15 * 5000 - 56 and abs(B - B.T).max() == 0
+    # ex2b.c:93: diag = 1 + (i/(n-1)) (kappa-1) rho^(n-1-i); last row has the full kappa
+    assert B[4999, 4999] == 1.0 + (1e6 - 1.0)
+    assert B[0, 0] == 1.0 and B[10, 11] == 1e-4

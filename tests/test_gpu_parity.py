@@ -1,0 +1,318 @@
+"""GPU (MI355X): the HIP path through the C-ABI against the oracle and the golden
+fixtures.  Run with ``pytest -m gpu``.
+
+Bars (stated here, used below):
+  * SpMV / SpMM with short rows: BIT-EXACT vs SciPy's csr_matvec (same left-to-right
+    order, no FMA);
+  * teacher-forced single iteration from every stored reference state: vectors and
+    scalars <= 1e-12 relative (north_star's tolerance);
+  * free-running histories: <= 1e-12 on the prefix k<=8 (bcsstk03) / k<=15 (nos7);
+    beyond that any change of summation order diverges on these ill-conditioned
+    problems, so the rest is held to convergence-level agreement;
+  * against the oracle run with the device's own reduction order (tests/device_order.py):
+    the whole free-running trajectory, <= 1e-13 on every recorded norm (normally
+    bit-exact).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_state, load_run
+from device_order import device_dot
+from oracle import ne_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FOUR = ['error_A_norm', 'residual_2_norm', 'error_2_norm', 'updated_residual_2_norm']
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import new_cg_variants_amd.cg_variants as cgv
+    import new_cg_variants_amd.callbacks as cbs
+    from new_cg_variants_amd import _lib, device, problems
+    return dict(cgv=cgv, cbs=cbs, L=_lib, device=device, problems=problems)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    s = np.linalg.norm(b)
+    d = np.linalg.norm(a - b)
+    return d / s if s > 0 else d
+
+
+def srel(a, b):
+    return abs(a - b) / abs(b) if b != 0 else abs(a)
+
+
+# ---------------------------------------------------------------------------------------
+# SpMV / SpMM
+# ---------------------------------------------------------------------------------------
+def test_spmv_bitexact_on_golden_matrices(amd, matrices):
+    for name, (A, z) in matrices.items():
+        op = amd['device'].DeviceCSR(A)
+        for i in range(z['spmv_x'].shape[0]):
+            y, _ = op.matvec(z['spmv_x'][i])
+            assert np.array_equal(y, z['spmv_y'][i]), name
+        RS = np.stack([z['spmv_x'][0], z['spmv_x'][1]], axis=1)
+        WU, _ = op.matmat2(RS)
+        assert np.array_equal(WU[:, 0], z['spmv_y'][0]) and np.array_equal(WU[:, 1], z['spmv_y'][1])
+        op.close()
+
+
+@pytest.mark.parametrize('name', ['s1_small', 's3_small'])
+def test_spmv_bitexact_on_synthetic(amd, name):
+    A = amd['problems'].WORKLOADS[name]['make']()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(A.shape[0])
+    op = amd['device'].DeviceCSR(A)
+    y, _ = op.matvec(x, reps=3)
+    assert np.array_equal(y, A @ x)
+    op.close()
+
+
+def test_spmv_ragged_empty_and_long_rows(amd):
+    """Edge cases: empty rows, rows of exactly/over a tile, one very long row, unsorted
+    indices, an all-empty matrix, a 1x1 matrix."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    lens = rng.integers(0, 30, size=n)
+    lens[10] = 509
+    lens[11] = 510
+    lens[12] = 4000
+    lens[300:900] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(indptr[-1])
+    indices = rng.integers(0, n, size=nnz).astype(np.int32)      # unsorted, with duplicates
+    data = rng.standard_normal(nnz)
+    A = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+    x = rng.standard_normal(n)
+    ref = A @ x                                                  # scipy: sequential per row
+    op = amd['device'].DeviceCSR(A)
+    y, _ = op.matvec(x)
+    short = lens <= 509
+    assert np.array_equal(y[short], ref[short])                  # tile path: bit-exact
+    scale = abs(A) @ np.abs(x)
+    assert np.all(np.abs(y[~short] - ref[~short]) <= 1e-14 * scale[~short])   # wave-reduced rows
+    RS = np.stack([x, -2.0 * x], axis=1)
+    WU, _ = op.matmat2(RS)
+    assert np.array_equal(WU[short, 0], ref[short]) and np.array_equal(WU[short, 1], -2.0 * ref[short])
+    op.close()
+    for tiny in (sp.csr_matrix((4, 4)), sp.csr_matrix(np.array([[2.5]]))):
+        op = amd['device'].DeviceCSR(tiny.astype(np.float64))
+        v = np.arange(1.0, tiny.shape[0] + 1)
+        y, _ = op.matvec(v)
+        assert np.array_equal(y, tiny @ v)
+        op.close()
+
+
+def test_spmv_full_size_properties(amd):
+    """S1 at full size (n=1e6): bit-exact vs SciPy, plus size-independent properties:
+    A*1 = row sums, symmetry x'(Ay) = y'(Ax), linearity."""
+    A = amd['problems'].laplace_2d(1000, 1000)
+    n = A.shape[0]
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    op = amd['device'].DeviceCSR(A)
+    Ax, _ = op.matvec(x)
+    Ay, _ = op.matvec(y)
+    assert np.array_equal(Ax, A @ x)
+    ones, _ = op.matvec(np.ones(n))
+    assert np.array_equal(ones, np.asarray(A.sum(axis=1)).ravel())
+    assert abs(x @ Ay - y @ Ax) <= 1e-11 * np.linalg.norm(x) * np.linalg.norm(Ay)
+    Axy, _ = op.matvec(2.0 * x + y)
+    assert rel(Axy, 2.0 * Ax + Ay) <= 1e-15
+    op.close()
+
+
+# ---------------------------------------------------------------------------------------
+# teacher-forced single steps from the reference's stored iterates
+# ---------------------------------------------------------------------------------------
+VARIANT_OF = {'hs_cg': 'HS', 'hs_pcg': 'HS', 'pipe_pr_cg': 'PIPE_PR', 'pipe_pr_pcg': 'PIPE_PR',
+              'pipe_p_cg': 'PIPE_P', 'pipe_p_pcg': 'PIPE_P', 'pipe_pr_m_cg': 'PIPE_PR_M',
+              'pipe_p_m_cg': 'PIPE_P_M', 'pr_pcg': 'PR', 'm_pcg': 'M'}
+FORCED = [('bcsstk03', 'hs_cg', 'None'), ('bcsstk03', 'pipe_pr_cg', 'None'), ('nos7', 'hs_cg', 'None'),
+          ('nos7', 'pipe_pr_cg', 'None'), ('bcsstk03', 'pr_pcg', 'None'), ('bcsstk03', 'm_pcg', 'None'),
+          ('bcsstk03', 'pipe_p_cg', 'None'), ('bcsstk03', 'pipe_pr_m_cg', 'None'),
+          ('bcsstk03', 'pipe_p_m_cg', 'None'), ('nos7', 'pr_pcg', 'None'), ('nos7', 'pipe_p_cg', 'None'),
+          ('bcsstk03', 'hs_pcg', 'jacobi'), ('bcsstk03', 'pr_pcg', 'jacobi'),
+          ('bcsstk03', 'pipe_pr_pcg', 'jacobi'), ('bcsstk03', 'pipe_p_pcg', 'jacobi'),
+          ('nos7', 'hs_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi')]
+
+
+@pytest.mark.parametrize('matrix,method,prec', FORCED)
+def test_teacher_forced_single_step(amd, matrices, matrix, method, prec):
+    L = amd['L']
+    A, z = matrices[matrix]
+    run = load_run(matrix, method, prec)
+    ks = set(int(k) for k in run['state_ks'])
+    variant = getattr(L, VARIANT_OF[method])
+    inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
+    op = amd['device'].DeviceCSR(A)
+    n = A.shape[0]
+    max_iter = int(run['max_iter'])
+    op.begin(variant, z['b'], np.zeros(n), max_iter, inv_diag=inv_diag)
+    checked, worst = 0, 0.0
+    for k in sorted(ks):
+        if k + 1 not in ks:
+            continue
+        g0, g1 = golden_state(run, k), golden_state(run, k + 1)
+        for f, v in g0.items():
+            if np.ndim(v) == 1:
+                try:
+                    op.set_vector(f, v)
+                except L.PrcgError:
+                    pass            # vector not part of this variant's device state
+        sc = np.zeros(L.NUM_SCALARS)
+        sc[L.S_MU], sc[L.S_NU] = float(g0['mu']), float(g0['nu'])
+        sc[L.S_DELTA], sc[L.S_GAMMA] = float(g0.get('dl', 0.0)), float(g0.get('gm', 0.0))
+        op.set_scalars(k, sc)
+        op.set_iteration(k)
+        op.iterate(1)
+        op.sync()
+        got_sc = op.get_scalars(k + 1)
+        for f, v in g1.items():
+            if np.ndim(v) == 1:
+                try:
+                    got = op.get_vector(f)
+                except L.PrcgError:
+                    continue
+                err = rel(got, v)
+            elif f in ('mu', 'nu', 'dl', 'gm'):
+                slot = {'mu': L.S_MU, 'nu': L.S_NU, 'dl': L.S_DELTA, 'gm': L.S_GAMMA}[f]
+                if f in ('dl', 'gm') and VARIANT_OF[method] == 'HS':
+                    continue
+                err = srel(got_sc[slot], float(v))
+            elif f == 'beta':
+                err = srel(op.get_coefficients(k + 1)[1], float(v))
+            elif f == 'alpha':
+                err = srel(got_sc[L.S_NU] / got_sc[L.S_MU], float(v))
+            else:
+                continue
+            worst = max(worst, err)
+            assert err <= 1e-12, (matrix, method, prec, k, f, err)
+        checked += 1
+    op.close()
+    assert checked >= 3
+    print(f'{matrix}/{method}/{prec}: {checked} forced steps, worst rel. deviation {worst:.2e}')
+
+
+# ---------------------------------------------------------------------------------------
+# free-running: prefix vs the reference, whole trajectory vs the device-ordered oracle,
+# convergence statistics vs the reference
+# ---------------------------------------------------------------------------------------
+FREE = [('bcsstk03', 'hs_cg', 'None'), ('bcsstk03', 'pipe_pr_cg', 'None'), ('nos7', 'hs_cg', 'None'),
+        ('nos7', 'pipe_pr_cg', 'None'), ('bcsstk03', 'pr_pcg', 'None'), ('bcsstk03', 'pipe_p_cg', 'None'),
+        ('bcsstk03', 'pipe_pr_m_cg', 'None'), ('bcsstk03', 'hs_pcg', 'jacobi'),
+        ('bcsstk03', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'hs_pcg', 'jacobi')]
+
+
+@pytest.mark.parametrize('matrix,method,prec', FREE)
+def test_free_running_against_reference(amd, matrices, matrix, method, prec):
+    A, z = matrices[matrix]
+    run = load_run(matrix, method, prec)
+    max_iter = int(run['max_iter'])
+    cbs = [getattr(amd['cbs'], q) for q in FOUR]
+    kw = {}
+    if method.endswith('pcg'):
+        kw['preconditioner'] = (lambda v: (1 / A.diagonal()) * v) if prec == 'jacobi' else (lambda v: v)
+    out = getattr(amd['cgv'], method)(A, z['b'], np.zeros(A.shape[0]), max_iter, callbacks=cbs,
+                                      x_true=z['x_true'], **kw)
+    assert out['name'] == str(run['name']) and out['max_iter'] == max_iter
+    prefix = 9 if matrix == 'bcsstk03' else 16
+    for q in FOUR:
+        assert out[q].shape == (max_iter,)
+        np.testing.assert_allclose(out[q][:prefix], run['hist_' + q][:prefix], rtol=1e-12, atol=0,
+                                   err_msg=f'{matrix}/{method}/{prec}/{q}')
+    its, acc = orc.convergence_summary(out['error_A_norm'])
+    ref_its, ref_acc = int(run['iters_to_1e-5']), float(run['log10_min_rel_error_A'])
+    assert abs(its - ref_its) <= max(2, 0.05 * ref_its), (its, ref_its)
+    assert abs(acc - ref_acc) < 2.5, (acc, ref_acc)
+    print(f'{matrix}/{method}/{prec}: its {its} (ref {ref_its}), log10 min err {acc:.2f} (ref {ref_acc:.2f})')
+
+
+@pytest.mark.parametrize('matrix,flavour,method,max_iter', [
+    ('bcsstk03', 'pr', 'pipe_pr_cg', 1250), ('nos7', 'pr', 'pipe_pr_cg', 3000),
+    ('bcsstk03', 'p', 'pipe_p_cg', 600), ('bcsstk03', 'pr_m', 'pipe_pr_m_cg', 600)])
+def test_whole_trajectory_against_device_ordered_oracle(amd, matrices, matrix, flavour, method, max_iter):
+    """Same algorithm, same reduction tree on both sides: the entire free-running history
+    must agree (this is what catches races and indexing slips far from the prefix)."""
+    A, z = matrices[matrix]
+    n = A.shape[0]
+    want = getattr(orc, method)(A, z['b'], np.zeros(n), max_iter, callbacks=FOUR, x_true=z['x_true'],
+                                dot=device_dot)
+    cbs = [getattr(amd['cbs'], q) for q in FOUR]
+    got = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), max_iter, callbacks=cbs, x_true=z['x_true'])
+    bitexact = np.array_equal(got['updated_residual_2_norm'], want['updated_residual_2_norm'])
+    for q in FOUR:
+        ok = np.isfinite(want[q])
+        np.testing.assert_allclose(got[q][ok], want[q][ok], rtol=1e-9, atol=0, err_msg=f'{matrix}/{method}/{q}')
+    print(f'{matrix}/{method}: recurrence-residual history bit-exact vs device-ordered oracle: {bitexact}')
+
+
+def test_device_results_are_reproducible(amd, matrices):
+    A, z = matrices['nos7']
+    cbs = [amd['cbs'].updated_residual_2_norm]
+    a = amd['cgv'].pipe_pr_cg(A, z['b'], np.zeros(729), 2000, callbacks=cbs)
+    b = amd['cgv'].pipe_pr_cg(A, z['b'], np.zeros(729), 2000, callbacks=cbs)
+    assert np.array_equal(a['updated_residual_2_norm'], b['updated_residual_2_norm'])
+
+
+def test_foreign_callback_sees_reference_locals(amd, matrices):
+    """Any callable in callbacks= is honoured with the reference's local names."""
+    A, z = matrices['bcsstk03']
+    seen = []
+
+    def spy(**kw):
+        seen.append((kw['k'], float(np.linalg.norm(kw['r_k'])), kw['output']['name'], 'x_true' in kw['kwargs']))
+    out = amd['cgv'].pipe_pr_cg(A, z['b'], np.zeros(112), 30, callbacks=[spy, amd['cbs'].updated_residual_2_norm],
+                                x_true=z['x_true'])
+    assert [s[0] for s in seen] == list(range(30))
+    np.testing.assert_allclose([s[1] for s in seen], out['updated_residual_2_norm'], rtol=1e-14)
+    assert seen[0][2] == 'pipe_pr_cg' and seen[0][3]
+
+
+def test_breakdown_propagates_nan_not_exception(amd):
+    """Zero right-hand side: 0/0 at the first step; histories fill with nan, no error
+    (the reference behaves the same way; figure_gen.py:89 uses nanmin)."""
+    A = amd['problems'].laplace_2d(16, 16)
+    out = amd['cgv'].pipe_pr_cg(A, np.zeros(256), np.zeros(256), 6, callbacks=[amd['cbs'].updated_residual_2_norm])
+    h = out['updated_residual_2_norm']
+    assert h[0] == 0.0 and np.all(np.isnan(h[1:]))
+
+
+# ---------------------------------------------------------------------------------------
+# full-size workloads: size-independent properties + oracle agreement on a short run
+# ---------------------------------------------------------------------------------------
+def test_s1_full_size_short_run_against_device_ordered_oracle(amd):
+    A = amd['problems'].laplace_2d(1000, 1000)
+    n = A.shape[0]
+    b, x0, x_true = amd['problems'].reference_rhs(A, n)
+    iters = 12
+    want = orc.pipe_pr_cg(A, b, x0, iters, callbacks=['updated_residual_2_norm', 'error_2_norm'],
+                          x_true=x_true, dot=device_dot)
+    got = amd['cgv'].pipe_pr_cg(A, b, x0, iters, callbacks=[amd['cbs'].updated_residual_2_norm,
+                                                            amd['cbs'].error_2_norm], x_true=x_true)
+    np.testing.assert_allclose(got['updated_residual_2_norm'], want['updated_residual_2_norm'], rtol=1e-13)
+    np.testing.assert_allclose(got['error_2_norm'], want['error_2_norm'], rtol=1e-12)
+    # and against the reference-order oracle (BLAS dot) within the stated tolerance on this prefix
+    ref = orc.pipe_pr_cg(A, b, x0, iters, callbacks=['updated_residual_2_norm'], x_true=x_true)
+    np.testing.assert_allclose(got['updated_residual_2_norm'], ref['updated_residual_2_norm'], rtol=1e-12)
+
+
+def test_s3_banded_cg_monotone_error_and_residual_identity(amd):
+    """ex2b-style banded matrix (n=2e5): A-norm error decreases monotonically for HS-CG,
+    and the true residual equals the recurrence residual to rounding for both variants."""
+    P = amd['problems']
+    n = 200_000
+    A = P.banded_ex2b(n, 7)
+    b, x0, x_true = P.reference_rhs(A, n)
+    cbs = [amd['cbs'].error_A_norm, amd['cbs'].residual_2_norm, amd['cbs'].updated_residual_2_norm]
+    for fn in (amd['cgv'].hs_cg, amd['cgv'].pipe_pr_cg):
+        out = fn(A, b, x0, 40, callbacks=cbs, x_true=x_true)
+        e = out['error_A_norm']
+        assert np.all(np.diff(e[:25]) < 0), fn.__name__
+        assert e[25] < 0.2 * e[0]
+        want = getattr(orc, fn.__name__)(A, b, x0, 40, callbacks=['error_A_norm'], x_true=x_true)
+        np.testing.assert_allclose(e, want['error_A_norm'], rtol=1e-8)
+        np.testing.assert_allclose(out['residual_2_norm'][:20], out['updated_residual_2_norm'][:20], rtol=1e-6)

@@ -1,0 +1,158 @@
+"""CPU: the oracle against the golden fixtures generated from the reference
+(tests/golden/make_golden.py).  Three-part parity protocol:
+
+  1. teacher-forced single step from every stored reference state: <= 1e-12 relative
+     (here: the oracle uses the same BLAS as the fixture generator in the build
+     container, so it is normally bit-exact; on other hosts the dot order may differ);
+  2. free-running prefix <= 1e-12 for k <= 8 (bcsstk03) / k <= 15 (nos7);
+  3. convergence-level agreement with the paper's own statistic.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_state, load_matrix, load_run
+from oracle import mp_oracle, ne_oracle as orc
+
+FOUR = ['error_A_norm', 'residual_2_norm', 'error_2_norm', 'updated_residual_2_norm']
+RUNS = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, 'run_*.npz')))
+
+# method -> (family, flavour)
+METHODS = {
+    'hs_cg': ('hs', None), 'hs_pcg': ('hs', None), 'pr_pcg': ('pr', 'pr'), 'm_pcg': ('pr', 'm'),
+    'pipe_p_cg': ('pipe', 'p'), 'pipe_pr_cg': ('pipe', 'pr'), 'pipe_p_m_cg': ('pipe', 'p_m'),
+    'pipe_pr_m_cg': ('pipe', 'pr_m'), 'pipe_p_pcg': ('pipe', 'p'), 'pipe_pr_pcg': ('pipe', 'pr'),
+    'cg_cg': ('cg_cg', None), 'gv_cg': ('gv', None),
+}
+
+
+def split_tag(tag):
+    matrix, rest = tag.split('_', 1)
+    method, prec = rest.rsplit('_', 1)
+    return matrix, method, prec
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    d = np.linalg.norm(a - b)
+    s = np.linalg.norm(b)
+    return d / s if s > 0 else d
+
+
+def test_spmv_known_answers(matrices):
+    for name, (A, z) in matrices.items():
+        for i in range(z['spmv_x'].shape[0]):
+            assert np.array_equal(A @ z['spmv_x'][i], z['spmv_y'][i]), name
+        # problem setup of figure_gen.py:31-34
+        n = A.shape[0]
+        assert np.array_equal(z['x_true'], np.ones(n) / np.sqrt(n))
+        assert np.array_equal(A @ z['x_true'], z['b'])
+
+
+@pytest.mark.parametrize('tag', RUNS)
+def test_free_running_prefix_and_convergence(tag, matrices):
+    matrix, method, prec_name = split_tag(tag)
+    A, z = matrices[matrix]
+    run = load_run(matrix, method, prec_name)
+    max_iter = int(run['max_iter'])
+    prec = orc.jacobi(A) if prec_name == 'jacobi' else None
+    kw = {'preconditioner': prec} if method.endswith('pcg') else {}
+    out = getattr(orc, method)(A, z['b'], np.zeros(A.shape[0]), max_iter, callbacks=FOUR,
+                               x_true=z['x_true'], **kw)
+    assert out['name'] == str(run['name'])
+    prefix = 9 if matrix == 'bcsstk03' else 16
+    for q in FOUR:
+        ref = run['hist_' + q]
+        assert out[q].shape == ref.shape == (max_iter,)
+        np.testing.assert_allclose(out[q][:prefix], ref[:prefix], rtol=1e-12, atol=0)
+    its, acc = orc.convergence_summary(out['error_A_norm'])
+    ref_its = int(run['iters_to_1e-5'])
+    if ref_its > 0:
+        assert abs(its - ref_its) <= max(2, 0.05 * ref_its)
+        # attained accuracy: within the spread the reference shows against its own table
+        assert abs(acc - float(run['log10_min_rel_error_A'])) < 2.5
+    else:
+        assert its == 0
+
+
+@pytest.mark.parametrize('tag', [t for t in RUNS if len(np.load(os.path.join(GOLDEN, f'run_{t}.npz'))['state_ks'])])
+def test_teacher_forced_single_step(tag, matrices):
+    matrix, method, prec_name = split_tag(tag)
+    family, flavour = METHODS[method]
+    A, z = matrices[matrix]
+    run = load_run(matrix, method, prec_name)
+    ks = set(int(k) for k in run['state_ks'])
+    prec = orc.jacobi(A) if prec_name == 'jacobi' else None
+    _, advance, has_flavour = orc.FAMILIES[family]
+    worst = 0.0
+    checked = 0
+    for k in sorted(ks):
+        if k + 1 not in ks:
+            continue
+        g0, g1 = golden_state(run, k), golden_state(run, k + 1)
+        st = orc.State(k=k)
+        for f, v in g0.items():
+            setattr(st, f, float(v) if np.ndim(v) == 0 else np.array(v, copy=True))
+        with np.errstate(all='ignore'):
+            if has_flavour:
+                advance(A, st, flavour, prec=prec)
+            else:
+                advance(A, st, prec=prec)
+        for f, v in g1.items():
+            if f == 'beta' and k + 1 == 0:
+                continue
+            got = getattr(st, f)
+            if got is None:
+                continue
+            if np.ndim(v) == 0:
+                err = abs(float(got) - float(v)) / abs(float(v)) if float(v) != 0 else abs(float(got))
+            else:
+                err = rel(got, v)
+            worst = max(worst, err)
+            assert err <= 1e-12, (tag, k, f, err)
+        checked += 1
+    assert checked > 0
+
+
+def test_published_convergence_table_is_reproduced_within_its_own_spread():
+    """The reference's committed table (figures/convergence_table_data.tex:5,26,38,52;
+    BASELINE.md section 1): iterations to 1e-5 for hs / pipe_pr."""
+    published = {('bcsstk03', 'None'): (364, 411), ('nos7', 'None'): (2869, 2899),
+                 ('bcsstk03', 'jacobi'): (118, 121), ('nos7', 'jacobi'): (67, 67)}
+    for (matrix, prec), (hs_pub, ppr_pub) in published.items():
+        hs = load_run(matrix, 'hs_cg' if prec == 'None' else 'hs_pcg', prec)
+        ppr = load_run(matrix, 'pipe_pr_cg' if prec == 'None' else 'pipe_pr_pcg', prec)
+        assert abs(int(hs['iters_to_1e-5']) - hs_pub) <= 0.05 * hs_pub
+        assert abs(int(ppr['iters_to_1e-5']) - ppr_pub) <= 0.05 * ppr_pub
+
+
+def test_mp_oracle_against_reference_fixture():
+    z = np.load(os.path.join(GOLDEN, 'mp_model_problem.npz'))
+    n = 1024
+    lam = mp_oracle.model_problem_eigs(n)
+    b = lam / np.sqrt(n)
+    comm = mp_oracle.SingleRankComm()
+    A = mp_oracle.DenseColumnBlock(comm, np.diag(lam))
+    for name in ('pipe_pr_cg', 'hs_cg'):
+        x, t = getattr(mp_oracle, name)(comm, A, b.copy(), 40)
+        assert set(t) == {'tot'} and t['tot'] >= 0
+        assert rel(x, z[f'{name}_n1024_it40_x']) <= 1e-12
+        x, _ = getattr(mp_oracle, name)(comm, A, b.copy(), 400)
+        err = np.linalg.norm(np.ones(n) / np.sqrt(n) - x)
+        assert abs(np.log10(err) - np.log10(float(z[f'{name}_n1024_it400_error']))) < 0.5
+    # published final errors of the n=12288 / 1500-iteration experiment:
+    # hs 1.1e-7, pipe_pr 4.2e-7 -- the fixture holds the reference re-run here
+    assert abs(np.log10(float(z['pipe_pr_cg_n12288_it1500_error'])) - np.log10(4.2e-7)) < 0.3
+    assert abs(np.log10(float(z['hs_cg_n12288_it1500_error'])) - np.log10(1.1e-7)) < 0.3
+
+
+def test_device_order_dot_is_a_valid_summation():
+    from device_order import device_dot
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 63, 64, 511, 512, 513, 729, 4097, 1_200_000):
+        a, b = rng.standard_normal(n), rng.standard_normal(n)
+        exact = float(np.dot(a.astype(np.longdouble), b.astype(np.longdouble)))
+        scale = float(np.dot(np.abs(a), np.abs(b)))
+        assert abs(device_dot(a, b) - exact) <= 1e-13 * scale
