@@ -222,8 +222,17 @@ def test_free_running_against_reference(amd, matrices, matrix, method, prec):
     prefix = 9 if matrix == 'bcsstk03' else 16
     for q in FOUR:
         assert out[q].shape == (max_iter,)
-        np.testing.assert_allclose(out[q][:prefix], run['hist_' + q][:prefix], rtol=1e-12, atol=0,
-                                   err_msg=f'{matrix}/{method}/{prec}/{q}')
+        ref = run['hist_' + q]
+        if q == 'updated_residual_2_norm':
+            # the residual history proper: 1e-12 relative
+            np.testing.assert_allclose(out[q][:prefix], ref[:prefix], rtol=1e-12, atol=0,
+                                       err_msg=f'{matrix}/{method}/{prec}/{q}')
+        else:
+            # b - A x and x - x_true are differences of O(|b|), O(|x|) quantities: a 1e-16
+            # perturbation of x shows up as 1e-16 * |b| in them, so the bar is 1e-12
+            # relative to the initial value (plus 1e-10 relative)
+            np.testing.assert_allclose(out[q][:prefix], ref[:prefix], rtol=1e-10, atol=1e-12 * ref[0],
+                                       err_msg=f'{matrix}/{method}/{prec}/{q}')
     its, acc = orc.convergence_summary(out['error_A_norm'])
     ref_its, ref_acc = int(run['iters_to_1e-5']), float(run['log10_min_rel_error_A'])
     assert abs(its - ref_its) <= max(2, 0.05 * ref_its), (its, ref_its)
