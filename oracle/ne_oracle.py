@@ -120,10 +120,18 @@ def hs_advance(A, st, prec=None, dot=np.dot):
 # (the unpreconditioned pr_cg/m_cg of the reference raise NameError, pr_cg.py:24,54;
 #  the preconditioned ones with the identity are their oracle -- SURVEY.md 8c)
 # ---------------------------------------------------------------------------
-def _predict_nu(flavour_m, nu, a, dl, gm):
+def _pow2(a):
+    return a**2
+
+
+def _predict_nu(flavour_m, nu, a, dl, gm, square=_pow2):
+    """`a_k1**2` on a NumPy/Python float scalar goes through libm pow(a, 2.0), which is
+    NOT always the correctly rounded square (about 1 case in 1000 is one ulp off).  The
+    default reproduces the reference; tests that emulate the device (which multiplies)
+    pass ``square=lambda a: a*a``."""
     if flavour_m:
-        return -nu + a**2 * gm                                 # pipe_pr_cg.py:64
-    return nu - 2 * a * dl + a**2 * gm                         # pipe_pr_cg.py:65
+        return -nu + square(a) * gm                            # pipe_pr_cg.py:64
+    return nu - 2 * a * dl + square(a) * gm                    # pipe_pr_cg.py:65
 
 
 def pr_start(A, b, x0, prec=None, dot=np.dot):
@@ -143,14 +151,14 @@ def pr_start(A, b, x0, prec=None, dot=np.dot):
     return st
 
 
-def pr_advance(A, st, flavour='pr', prec=None, dot=np.dot):
+def pr_advance(A, st, flavour='pr', prec=None, dot=np.dot, square=_pow2):
     M = prec or _ident
     a = st.alpha
     nu_old = st.nu
     st.x = st.x + a * st.p                                     # :146
     st.r = st.r - a * st.s                                     # :147
     st.rt = st.rt - a * st.st                                  # :148
-    st.nu_pred = _predict_nu(flavour == 'm', nu_old, a, st.dl, st.gm)   # :149
+    st.nu_pred = _predict_nu(flavour == 'm', nu_old, a, st.dl, st.gm, square)   # :149
     st.beta = st.nu_pred / nu_old                              # :150
     st.p = st.rt + st.beta * st.p                              # :151
     st.s = A @ st.p                                            # :152
@@ -201,7 +209,7 @@ def pipe_start(A, b, x0, prec=None, dot=np.dot):
     return st
 
 
-def pipe_advance(A, st, flavour='pr', prec=None, dot=np.dot):
+def pipe_advance(A, st, flavour='pr', prec=None, dot=np.dot, square=_pow2):
     recompute = flavour.startswith('pr')
     a = st.alpha
     nu_old = st.nu
@@ -209,7 +217,7 @@ def pipe_advance(A, st, flavour='pr', prec=None, dot=np.dot):
     st.r = st.r - a * st.s                                     # :62 / :170
     if prec is None:
         st.w = st.w - a * st.u                                 # :63
-        st.nu_pred = _predict_nu(flavour.endswith('m'), nu_old, a, st.dl, st.gm)
+        st.nu_pred = _predict_nu(flavour.endswith('m'), nu_old, a, st.dl, st.gm, square)
         st.beta = st.nu_pred / nu_old                          # :66
         st.p = st.r + st.beta * st.p                           # :67
         st.s = st.w + st.beta * st.s                           # :68
@@ -224,7 +232,7 @@ def pipe_advance(A, st, flavour='pr', prec=None, dot=np.dot):
         st.rt = st.rt - a * st.st                              # :171
         st.w = st.w - a * st.u                                 # :172
         st.wt = st.wt - a * st.ut                              # :173
-        st.nu_pred = _predict_nu(flavour.endswith('m'), nu_old, a, st.dl, st.gm)   # :174
+        st.nu_pred = _predict_nu(flavour.endswith('m'), nu_old, a, st.dl, st.gm, square)   # :174
         st.beta = st.nu_pred / nu_old                          # :175
         st.p = st.rt + st.beta * st.p                          # :176
         st.s = st.w + st.beta * st.s                           # :177
@@ -356,7 +364,7 @@ FAMILIES = {
 
 
 def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
-        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None):
+        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None, square=_pow2):
     """Free-running solve with the reference's loop shape: recorders fire on the
     initial state (index 0) and after each of the ``max_iter - 1`` iterations
     (NE/cg_variants/hs_cg.py:33-36,39,64-65).  ``tap(state)`` sees every state."""
@@ -376,7 +384,7 @@ def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
     with np.errstate(all='ignore'):
         for _ in range(1, max_iter):
             if has_flavour:
-                advance(A, st, flavour, prec=prec, dot=dot)
+                advance(A, st, flavour, prec=prec, dot=dot, square=square)
             else:
                 advance(A, st, prec=prec, dot=dot)
             record()
@@ -390,7 +398,8 @@ def _public(family, flavour, ref_name, preconditioned):
         prec = preconditioner if preconditioned else None
         out = run(family, A, b, x0, max_iter, flavour=flavour, prec=prec,
                   recorders=tuple(callbacks), x_true=kwargs.get('x_true'),
-                  dot=kwargs.get('dot', np.dot), tap=kwargs.get('tap'), name=ref_name)
+                  dot=kwargs.get('dot', np.dot), tap=kwargs.get('tap'), name=ref_name,
+                  square=kwargs.get('square', _pow2))
         return out
     f.__name__ = ref_name
     return f
