@@ -82,6 +82,7 @@ struct prcg_handle {
     int64_t n = 0, g = 0, nnz = 0;
     DevBuf indptr, col, val, tiles;
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
+    int steps = kDefaultTileSteps;       // tile size the table was planned for
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
     DevBuf t1;                           // 2*n doubles: SpMV output scratch
     DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues
@@ -152,6 +153,16 @@ int fail(prcg_t* h, int code, const char* fmt, ...) {
 #define CHECK(h, cond, ...)                                                                   \
     do { if (!(cond)) return fail(h, PRCG_EINVAL, __VA_ARGS__); } while (0)
 
+// experiment knob: PRCG_TILE_STEPS = 1 | 2 | 4 (256-nnz steps per wave tile)
+int env_tile_steps() {
+    const char* e = getenv("PRCG_TILE_STEPS");
+    if (e) {
+        const int s = atoi(e);
+        if (s == 1 || s == 2 || s == 4) return s;
+    }
+    return kDefaultTileSteps;
+}
+
 bool is_pipe(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_P || v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M; }
 bool is_pr(int v) { return v == PRCG_PR || v == PRCG_M; }
 bool pipe_recompute(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_PR_M; }
@@ -191,7 +202,7 @@ int dist_spmv(prcg_t* h, double* x_ext, double* y, SpmvEpilogue epi, const doubl
     int rc = exchange(h, x_ext, 1, h->sc);
     if (rc) return rc;
     const int nt = h->nt_int + h->nt_bnd;
-    const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, x_ext, y, epi, ep_r, ep_d, ep_st,
+    const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                  h->partB.d());
     LAUNCHCHK(h, grid);
     if (grid_out) *grid_out = grid;
@@ -256,7 +267,7 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     if (!h->multi()) {
         launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, in_ext, h->wu.d(), mask));
+        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         return PRCG_OK;
     }
@@ -270,10 +281,10 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
 
     if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int, in_ext, h->wu.d(), mask));
+    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
     if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, in_ext, h->wu.d(), mask));
+    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
     return PRCG_OK;
 }
@@ -285,7 +296,7 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
     bool on = false;
     if (!h->multi()) {
         prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-        const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, x_ext, y, epi, ep_r,
+        const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, x_ext, y, epi, ep_r,
                                      ep_d, ep_st, h->partB.d());
         LAUNCHCHK(h, grid);
         prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
@@ -298,12 +309,12 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, x_ext, y, epi, ep_r, ep_d, ep_st,
+    const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d());
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-    const int g2 = launch_spmv(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, x_ext, y, epi, ep_r, ep_d, ep_st,
+    const int g2 = launch_spmv(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d() + (size_t)g1 * kPartialStride);
     LAUNCHCHK(h, g2);
     *nparts = g1 + g2;
@@ -561,7 +572,8 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         cls[i] = c;
     }
     std::vector<Tile> t0, t1;
-    plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, kTileCapNnz, kTileCapRows, t0, t1);
+    h->steps = env_tile_steps();
+    plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, tile_cap_nnz(h->steps), kTileCapRows, t0, t1);
     std::vector<Tile> all(t0);
     all.insert(all.end(), t1.begin(), t1.end());
 
@@ -639,10 +651,10 @@ static int timed_product(prcg_t* h, int nc, const double* in, double* out, int r
     for (int i = 0; i < reps; ++i) {
         HIPCHK(h, hipEventRecord(a, h->sc));
         if (nc == 1)
-            LAUNCHCHK(h, launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr,
+            LAUNCHCHK(h, launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr,
                                      nullptr, nullptr, nullptr));
         else
-            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), nt, h->tmp_ext.d(), h->t1.d(), 3));
+            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, h->tmp_ext.d(), h->t1.d(), 3));
         HIPCHK(h, hipEventRecord(b, h->sc));
         HIPCHK(h, hipEventSynchronize(b));
         float ms = 0.f;
@@ -970,7 +982,7 @@ int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_cla
 }
 
 void prcg_tile_caps(int* cap_nnz, int* cap_rows) {
-    if (cap_nnz) *cap_nnz = kTileCapNnz;
+    if (cap_nnz) *cap_nnz = tile_cap_nnz(env_tile_steps());
     if (cap_rows) *cap_rows = kTileCapRows;
 }
 

@@ -10,16 +10,15 @@ namespace prcg {
 // A tile is a run of consecutive rows handled by ONE wavefront: its nonzeros are
 // streamed with 16-byte loads, the products staged in that wave's LDS slice, and each
 // row reduced sequentially (left to right, as scipy's csr_matvec does) by one lane.
-constexpr int kTileSteps = 2;                       // 256-nnz steps per tile
-constexpr int kTileSlots = 256 * kTileSteps;        // LDS product slots per wave
-constexpr int kTileCapNnz = kTileSlots - 3;         // -3: the stream starts 16-B aligned
+constexpr int kDefaultTileSteps = 2;                // 256-nnz steps per tile (1, 2 or 4)
+inline int tile_cap_nnz(int steps) { return 256 * steps - 3; }   // -3: the stream starts 16-B aligned
 constexpr int kTileCapRows = 256;
 constexpr int kMaxGridBlocks = 2048;                // 8 blocks x 256 CUs
 constexpr int kPartialStride = 8;                   // doubles per block in a partials array
 
 #ifndef PRCG_TILE_DEFINED
 #define PRCG_TILE_DEFINED
-struct Tile { int row_begin, row_end; };
+struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 #endif
 
 // epilogues fused into the single-vector SpMV
@@ -38,13 +37,13 @@ struct CsrDev {
 // y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
 // partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.
 // returns the grid size used (needed to reduce the partials), <0 on launch failure.
-int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
                 const double* ep_r, const double* ep_d, double* ep_st,
                 double* partials);
 
 // [w u] = A [r s] on interleaved pairs.  write_mask: 1 = first, 2 = second, 3 = both.
-int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                  const double* rs, double* wu, int write_mask);
 
 // ---- fused vector updates + inner products -----------------------------------------

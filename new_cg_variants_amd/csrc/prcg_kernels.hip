@@ -89,6 +89,50 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NQ], double* pa
 //   reduce phase : lane i sums row i of the tile sequentially from LDS and stores it.
 // A row longer than a tile is summed by the whole wave (partial sums + butterfly).
 // ======================================================================================
+// per-row epilogue: store y (and the fused extras)
+template <int NV, int EPI>
+__device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
+                                           int write_mask, const typename VecT<NV>::type* __restrict__ X,
+                                           const double* __restrict__ ep_r, const double* __restrict__ ep_d,
+                                           double* __restrict__ ep_st, double (&acc)[3])
+{
+    if constexpr (NV == 1) {
+        double* Y = reinterpret_cast<double*>(yout_);
+        Y[row] = sum;
+        if constexpr (EPI == kEpiDotXY) acc[0] += X[row] * sum;
+        if constexpr (EPI == kEpiPR) {
+            const double stv = ep_d ? ep_d[row] * sum : sum;
+            if (ep_st) ep_st[row] = stv;
+            acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
+        }
+    } else {
+        if (write_mask == 3) {
+            reinterpret_cast<double2*>(yout_)[row] = sum;
+        } else {
+            double* Y = reinterpret_cast<double*>(yout_);
+            if (write_mask & 1) Y[2 * (size_t)row] = sum.x;
+            if (write_mask & 2) Y[2 * (size_t)row + 1] = sum.y;
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename VecT<NV>::type* my, int s, int e) {
+    using V = typename VecT<NV>::type;
+    V sum; vzero(sum);
+    int q = s;
+    for (; q + 4 <= e; q += 4) {   // 4 LDS reads in flight, adds stay in row order
+        const V p0 = my[q], p1 = my[q + 1], p2 = my[q + 2], p3 = my[q + 3];
+        vacc(sum, p0); vacc(sum, p1); vacc(sum, p2); vacc(sum, p3);
+    }
+    for (; q < e; ++q) vacc(sum, my[q]);
+    return sum;
+}
+
+// Software-pipelined: while a wave reduces tile t out of LDS, the descriptor and the
+// val/col stream of its next tile (t + W) are already in flight, so the dependent chain
+// per tile is just  gather -> LDS -> row sums  instead of
+// descriptor -> row pointers -> val/col -> gather -> LDS -> row sums.
 template <int NV, int EPI, int STEPS>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
@@ -102,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     __shared__ V prod[kWaves][kSlots];
 
     const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
+    const int4* __restrict__ T4 = reinterpret_cast<const int4*>(tiles);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     V* my = prod[wv];
@@ -110,95 +155,94 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
 
     const int nblk = gridDim.x;
     const int W = nblk * kWaves;
-    const int slot = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+    int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
 
-    for (int t = slot; t < ntiles; t += W) {
-        const int rb = __builtin_amdgcn_readfirstlane(tiles[t].row_begin);
-        const int re = __builtin_amdgcn_readfirstlane(tiles[t].row_end);
-        const int lo = __builtin_amdgcn_readfirstlane(A.indptr[rb]);
-        const int hi = __builtin_amdgcn_readfirstlane(A.indptr[re]);
+    int4 cc[STEPS];
+    double2 va[STEPS], vb[STEPS];
 
-        if (hi - lo > kCap) {
-            // ---- long row: the planner gives it a tile of its own (re == rb+1) ----
+    // descriptor of the current tile (scalar registers)
+    int rb = 0, re = 0, lo = 0, hi = 0;
+    if (t < ntiles) {
+        const int4 d = T4[t];
+        rb = __builtin_amdgcn_readfirstlane(d.x); re = __builtin_amdgcn_readfirstlane(d.y);
+        lo = __builtin_amdgcn_readfirstlane(d.z); hi = __builtin_amdgcn_readfirstlane(d.w);
+        if (hi - lo <= kCap) {
+            const int alo = lo & ~3;
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int base = alo + st * 256 + lane * 4;
+                const int lb = base < hi ? base : alo;
+                cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+                va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+                vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+            }
+        }
+    }
+
+    while (t < ntiles) {
+        const int tn = t + W;
+        const bool has_next = tn < ntiles;
+        // next descriptor: one scalar 16-byte load, in flight during the gathers
+        const int4 dn = T4[has_next ? tn : t];
+        const bool is_long = (hi - lo > kCap);
+        const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
+
+        // row pointers of the first two row batches of this tile
+        // (branch-free, clamped: the loads are issued now and waited for only in the
+        //  reduce phase)
+        const int row0 = rb + lane, row1 = rb + 64 + lane;
+        const int* ip0 = A.indptr + (row0 < re ? row0 : rb);
+        const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
+        const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
+        if (!is_long) {
+            // ---- gather + products into LDS (branch-free: lanes past the tile re-read the
+            //      tile's first chunk and park their products in slots nobody reads) ----
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const V g0 = X[cc[st].x], g1 = X[cc[st].y], g2 = X[cc[st].z], g3 = X[cc[st].w];
+                const int o = st * 256 + lane * 4;
+                my[o + 0] = vmul(va[st].x, g0);
+                my[o + 1] = vmul(va[st].y, g1);
+                my[o + 2] = vmul(vb[st].x, g2);
+                my[o + 3] = vmul(vb[st].y, g3);
+            }
+            wave_lds_sync();
+        }
+
+        // ---- issue the next tile's val/col stream now; it flies during the row sums ----
+        const int rbn = __builtin_amdgcn_readfirstlane(dn.x), ren = __builtin_amdgcn_readfirstlane(dn.y);
+        const int lon = __builtin_amdgcn_readfirstlane(dn.z), hin = __builtin_amdgcn_readfirstlane(dn.w);
+        if (has_next && (hin - lon <= kCap)) {
+            const int alon = lon & ~3;
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const int base = alon + st * 256 + lane * 4;
+                const int lb = base < hin ? base : alon;
+                cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+                va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+                vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+            }
+        }
+
+        if (!is_long) {
+            // ---- reduce phase: one lane per row, left-to-right -------------------------
+            if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+            if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+            for (int row = rb + 128 + lane; row < re; row += 64) {
+                const int s = A.indptr[row] - alo;
+                const int e = A.indptr[row + 1] - alo;
+                finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+            }
+            wave_lds_sync();
+        } else {
+            // ---- long row: the planner gives it a tile of its own (re == rb+1) ----------
             V sum; vzero(sum);
             for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
             sum = vwave_sum(sum);
-            if (lane == 0) {
-                if constexpr (NV == 1) {
-                    double* Y = reinterpret_cast<double*>(yout_);
-                    Y[rb] = sum;
-                    if constexpr (EPI == kEpiDotXY) acc[0] += X[rb] * sum;
-                    if constexpr (EPI == kEpiPR) {
-                        const double stv = ep_d ? ep_d[rb] * sum : sum;
-                        if (ep_st) ep_st[rb] = stv;
-                        acc[0] += X[rb] * sum; acc[1] += ep_r[rb] * stv; acc[2] += stv * sum;
-                    }
-                } else {
-                    double* Y = reinterpret_cast<double*>(yout_);
-                    if (write_mask & 1) Y[2 * (size_t)rb] = sum.x;
-                    if (write_mask & 2) Y[2 * (size_t)rb + 1] = sum.y;
-                }
-            }
-            continue;
+            if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
         }
 
-        // ---- stream phase ---------------------------------------------------------
-        // Branch-free: a lane whose chunk lies past the tile re-reads the tile's first
-        // chunk (one hot line) and parks its products in slots nobody reads, so all the
-        // 16-B loads of all steps are in flight together.
-        const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
-        int4 cc[STEPS];
-        double2 va[STEPS], vb[STEPS];
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int base = alo + st * 256 + lane * 4;
-            const int lb = base < hi ? base : alo;
-            cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
-            va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-            vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
-        }
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const V g0 = X[cc[st].x], g1 = X[cc[st].y], g2 = X[cc[st].z], g3 = X[cc[st].w];
-            const int o = st * 256 + lane * 4;
-            my[o + 0] = vmul(va[st].x, g0);
-            my[o + 1] = vmul(va[st].y, g1);
-            my[o + 2] = vmul(vb[st].x, g2);
-            my[o + 3] = vmul(vb[st].y, g3);
-        }
-        wave_lds_sync();
-
-        // ---- reduce phase: one lane per row, left-to-right -------------------------
-        for (int row = rb + lane; row < re; row += 64) {
-            const int s = A.indptr[row] - alo;
-            const int e = A.indptr[row + 1] - alo;
-            V sum; vzero(sum);
-            int q = s;
-            for (; q + 4 <= e; q += 4) {   // 4 LDS reads in flight, adds stay in row order
-                const V p0 = my[q], p1 = my[q + 1], p2 = my[q + 2], p3 = my[q + 3];
-                vacc(sum, p0); vacc(sum, p1); vacc(sum, p2); vacc(sum, p3);
-            }
-            for (; q < e; ++q) vacc(sum, my[q]);
-            if constexpr (NV == 1) {
-                double* Y = reinterpret_cast<double*>(yout_);
-                Y[row] = sum;
-                if constexpr (EPI == kEpiDotXY) acc[0] += X[row] * sum;
-                if constexpr (EPI == kEpiPR) {
-                    const double stv = ep_d ? ep_d[row] * sum : sum;
-                    if (ep_st) ep_st[row] = stv;
-                    acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
-                }
-            } else {
-                if (write_mask == 3) {
-                    reinterpret_cast<double2*>(yout_)[row] = sum;
-                } else {
-                    double* Y = reinterpret_cast<double*>(yout_);
-                    if (write_mask & 1) Y[2 * (size_t)row] = sum.x;
-                    if (write_mask & 2) Y[2 * (size_t)row + 1] = sum.y;
-                }
-            }
-        }
-        wave_lds_sync();
+        t = tn; rb = rbn; re = ren; lo = lon; hi = hin;
     }
 
     if constexpr (EPI != kEpiNone) block_reduce_store<3>(acc, partials, 0);
@@ -483,7 +527,7 @@ int tile_grid(K kernel, int ntiles) {
     if (cap == 0) {
         int dev = 0, cus = 256, occ = 4;
         if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
         }
         cap = occ * cus;
@@ -499,41 +543,49 @@ int tile_grid(K kernel, int ntiles) {
 // ---- launch wrappers -------------------------------------------------------------------
 #define PRCG_LAUNCH_OK() (hipGetLastError() == hipSuccess)
 
-int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+template <int NV, int EPI, int STEPS>
+int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
+                 int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials)
+{
+    auto k = k_spmv_tiles<NV, EPI, STEPS>;
+    const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
+                       partials);
+    return PRCG_LAUNCH_OK() ? grid : -1;
+}
+
+template <int NV, int EPI>
+int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
+                       void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
+                       double* partials)
+{
+    switch (steps) {
+    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
+    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
+    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
+    default: return -1;
+    }
+}
+
+int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
                 const double* ep_r, const double* ep_d, double* ep_st, double* partials)
 {
     if (ntiles <= 0) return 0;
-    int grid = 0;
     switch (epi) {
-    case kEpiNone: {
-        auto k = k_spmv_tiles<1, kEpiNone, kTileSteps>;
-        grid = tile_grid<0>(k, ntiles);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-        break; }
-    case kEpiDotXY: {
-        auto k = k_spmv_tiles<1, kEpiDotXY, kTileSteps>;
-        grid = tile_grid<1>(k, ntiles);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-        break; }
-    case kEpiPR: {
-        auto k = k_spmv_tiles<1, kEpiPR, kTileSteps>;
-        grid = tile_grid<2>(k, ntiles);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-        break; }
+    case kEpiNone: return launch_tiles_steps<1, kEpiNone>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+    case kEpiDotXY: return launch_tiles_steps<1, kEpiDotXY>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+    case kEpiPR: return launch_tiles_steps<1, kEpiPR>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
     }
-    return PRCG_LAUNCH_OK() ? grid : -1;
+    return -1;
 }
 
-int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
+int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                  const double* rs, double* wu, int write_mask)
 {
     if (ntiles <= 0) return 0;
-    auto k = k_spmv_tiles<2, kEpiNone, kTileSteps>;
-    const int grid = tile_grid<3>(k, ntiles);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, rs, wu, write_mask,
-                       (const double*)nullptr, (const double*)nullptr, (double*)nullptr, (double*)nullptr);
-    return PRCG_LAUNCH_OK() ? grid : -1;
+    return launch_tiles_steps<2, kEpiNone>(steps, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr,
+                                           nullptr);
 }
 
 int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {

@@ -37,7 +37,7 @@ void plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
                 ++e;
             }
             if (e == r) e = r + 1;   // a single long row
-            out.push_back(Tile{(int)r, (int)e});
+            out.push_back(Tile{(int)r, (int)e, (int)indptr[r], (int)indptr[e]});
             r = e;
         }
     }
