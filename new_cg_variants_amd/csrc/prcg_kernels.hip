@@ -13,6 +13,8 @@
 // blocks in order), deterministic run to run.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "prcg_kernels.h"
 
 namespace prcg {
@@ -129,10 +131,90 @@ __device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename Ve
     return sum;
 }
 
-// Software-pipelined: while a wave reduces tile t out of LDS, the descriptor and the
-// val/col stream of its next tile (t + W) are already in flight, so the dependent chain
-// per tile is just  gather -> LDS -> row sums  instead of
-// descriptor -> row pointers -> val/col -> gather -> LDS -> row sums.
+// ---- register image of one tile's val/col stream ------------------------------------
+template <int STEPS>
+struct MatRegs {
+    int4 cc[STEPS];
+    double2 va[STEPS], vb[STEPS];
+};
+
+struct TileDesc { int rb, re, lo, hi; };
+
+__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, int t) {
+    const int4 d = T4[t];
+    TileDesc o;
+    o.rb = __builtin_amdgcn_readfirstlane(d.x); o.re = __builtin_amdgcn_readfirstlane(d.y);
+    o.lo = __builtin_amdgcn_readfirstlane(d.z); o.hi = __builtin_amdgcn_readfirstlane(d.w);
+    return o;
+}
+
+// Branch-free 16-byte loads of the tile's column indices and values: a lane whose chunk
+// lies past the tile re-reads the tile's first chunk (one hot line); its products land in
+// LDS slots nobody reads.
+template <int STEPS>
+__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS>& m) {
+    const int alo = d.lo & ~3;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int base = alo + st * 256 + lane * 4;
+        const int lb = base < d.hi ? base : alo;
+        m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+        m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+        m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+    }
+}
+
+// One tile: gather x[col], products -> this wave's LDS slice, then one lane per row sums
+// its row left to right.  `cur` holds the tile's val/col stream (loaded one tile ago).
+template <int NV, int EPI, int STEPS>
+__device__ __forceinline__ void process_tile(
+    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS>& cur,
+    typename VecT<NV>::type* my, const typename VecT<NV>::type* __restrict__ X,
+    void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
+    const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[3])
+{
+    using V = typename VecT<NV>::type;
+    constexpr int kCap = 256 * STEPS - 3;
+    const int rb = d.rb, re = d.re, lo = d.lo, hi = d.hi;
+    if (hi - lo > kCap) {
+        // ---- long row: the planner gives it a tile of its own (re == rb+1) ----------
+        V sum; vzero(sum);
+        for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
+        sum = vwave_sum(sum);
+        if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+        return;
+    }
+    const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
+    // row pointers of the first two row batches (branch-free, clamped: issued now, waited
+    // for only in the reduce phase)
+    const int row0 = rb + lane, row1 = rb + 64 + lane;
+    const int* ip0 = A.indptr + (row0 < re ? row0 : rb);
+    const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
+    const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
+        const int o = st * 256 + lane * 4;
+        my[o + 0] = vmul(cur.va[st].x, g0);
+        my[o + 1] = vmul(cur.va[st].y, g1);
+        my[o + 2] = vmul(cur.vb[st].x, g2);
+        my[o + 3] = vmul(cur.vb[st].y, g3);
+    }
+    wave_lds_sync();
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+    for (int row = rb + 128 + lane; row < re; row += 64) {
+        const int s = A.indptr[row] - alo;
+        const int e = A.indptr[row + 1] - alo;
+        finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+    }
+    wave_lds_sync();
+}
+
+// Software pipeline, two tiles deep: while a wave gathers / reduces tile t, the val/col
+// stream of tile t+W is already in flight (second register image) and the descriptor of
+// tile t+2W is being fetched.  The dependent chain per tile is then just
+// gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
 template <int NV, int EPI, int STEPS>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
@@ -157,92 +239,36 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     const int W = nblk * kWaves;
     int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
 
-    int4 cc[STEPS];
-    double2 va[STEPS], vb[STEPS];
-
-    // descriptor of the current tile (scalar registers)
-    int rb = 0, re = 0, lo = 0, hi = 0;
+    MatRegs<STEPS> m0, m1;
+    TileDesc d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
     if (t < ntiles) {
-        const int4 d = T4[t];
-        rb = __builtin_amdgcn_readfirstlane(d.x); re = __builtin_amdgcn_readfirstlane(d.y);
-        lo = __builtin_amdgcn_readfirstlane(d.z); hi = __builtin_amdgcn_readfirstlane(d.w);
-        if (hi - lo <= kCap) {
-            const int alo = lo & ~3;
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const int base = alo + st * 256 + lane * 4;
-                const int lb = base < hi ? base : alo;
-                cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
-                va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-                vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
-            }
-        }
+        d0 = read_desc(T4, t);
+        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS>(A, d0, lane, m0);
+        if (t + W < ntiles) d1 = read_desc(T4, t + W);
     }
 
     while (t < ntiles) {
-        const int tn = t + W;
-        const bool has_next = tn < ntiles;
-        // next descriptor: one scalar 16-byte load, in flight during the gathers
-        const int4 dn = T4[has_next ? tn : t];
-        const bool is_long = (hi - lo > kCap);
-        const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
-
-        // row pointers of the first two row batches of this tile
-        // (branch-free, clamped: the loads are issued now and waited for only in the
-        //  reduce phase)
-        const int row0 = rb + lane, row1 = rb + 64 + lane;
-        const int* ip0 = A.indptr + (row0 < re ? row0 : rb);
-        const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
-        const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
-        if (!is_long) {
-            // ---- gather + products into LDS (branch-free: lanes past the tile re-read the
-            //      tile's first chunk and park their products in slots nobody reads) ----
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const V g0 = X[cc[st].x], g1 = X[cc[st].y], g2 = X[cc[st].z], g3 = X[cc[st].w];
-                const int o = st * 256 + lane * 4;
-                my[o + 0] = vmul(va[st].x, g0);
-                my[o + 1] = vmul(va[st].y, g1);
-                my[o + 2] = vmul(vb[st].x, g2);
-                my[o + 3] = vmul(vb[st].y, g3);
-            }
-            wave_lds_sync();
+        // ---- even phase: tile t lives in m0 / d0 ----
+        {
+            const bool has_next = t + W < ntiles;
+            const int t2 = t + 2 * W;
+            const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
+            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS>(A, d1, lane, m1);
+            process_tile<NV, EPI, STEPS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            d0 = d2;
+            t += W;
         }
-
-        // ---- issue the next tile's val/col stream now; it flies during the row sums ----
-        const int rbn = __builtin_amdgcn_readfirstlane(dn.x), ren = __builtin_amdgcn_readfirstlane(dn.y);
-        const int lon = __builtin_amdgcn_readfirstlane(dn.z), hin = __builtin_amdgcn_readfirstlane(dn.w);
-        if (has_next && (hin - lon <= kCap)) {
-            const int alon = lon & ~3;
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const int base = alon + st * 256 + lane * 4;
-                const int lb = base < hin ? base : alon;
-                cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
-                va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-                vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
-            }
+        if (t >= ntiles) break;
+        // ---- odd phase: tile t lives in m1 / d1 ----
+        {
+            const bool has_next = t + W < ntiles;
+            const int t2 = t + 2 * W;
+            const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
+            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS>(A, d0, lane, m0);
+            process_tile<NV, EPI, STEPS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            d1 = d2;
+            t += W;
         }
-
-        if (!is_long) {
-            // ---- reduce phase: one lane per row, left-to-right -------------------------
-            if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
-            if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
-            for (int row = rb + 128 + lane; row < re; row += 64) {
-                const int s = A.indptr[row] - alo;
-                const int e = A.indptr[row + 1] - alo;
-                finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
-            }
-            wave_lds_sync();
-        } else {
-            // ---- long row: the planner gives it a tile of its own (re == rb+1) ----------
-            V sum; vzero(sum);
-            for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
-            sum = vwave_sum(sum);
-            if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
-        }
-
-        t = tn; rb = rbn; re = ren; lo = lon; hi = hin;
     }
 
     if constexpr (EPI != kEpiNone) block_reduce_store<3>(acc, partials, 0);
@@ -520,7 +546,12 @@ int util_grid(int64_t n) {
     return (int)g;
 }
 
-// occupancy-capped persistent grid for the tile kernels
+// Persistent grid for the tile kernels = blocks that are truly co-resident.  The strided
+// tile assignment assumes every block runs from the start; a block that has to queue
+// behind the others turns into a serial tail (measured: 32 KiB blocks at the occupancy
+// API's 5 per CU run 17 % slower than at 4 per CU -- only 4 are resident).  The LDS of a
+// CU is handed out per half (80 KiB each), so residency = 2 * floor(80 KiB / block LDS),
+// further capped by the API and by 8 blocks (32 waves) per CU.
 template <int TAG, typename K>
 int tile_grid(K kernel, int ntiles) {
     static int cap = 0;   // per TAG (the kernels share one function-pointer type)
@@ -529,7 +560,15 @@ int tile_grid(K kernel, int ntiles) {
         if (hipGetDevice(&dev) == hipSuccess) {
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 4;
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0) {
+                const int by_lds = 2 * (int)((80 * 1024) / fa.sharedSizeBytes);
+                if (by_lds >= 1 && by_lds < occ) occ = by_lds;
+            }
+            if (occ > 8) occ = 8;
         }
+        // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
+        if (const char* e = getenv("PRCG_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) occ = v; }
         cap = occ * cus;
     }
     int g = (ntiles + kWaves - 1) / kWaves;
