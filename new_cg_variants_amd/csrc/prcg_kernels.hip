@@ -566,6 +566,12 @@ int tile_grid(K kernel, int ntiles) {
                 if (by_lds >= 1 && by_lds < occ) occ = by_lds;
             }
             if (occ > 8) occ = 8;
+            // Measured on MI355X (profiles/r01_sweeps.md): beyond ~12 resident waves per CU
+            // of this two-deep pipeline the extra outstanding streams cost more HBM
+            // efficiency than the latency hiding they add (S3: 3 blocks/CU 5.2 TB/s,
+            // 4 blocks/CU 4.6 TB/s at 512-slot tiles; 4 blocks/CU best at 256-slot tiles).
+            const int tuned = (TAG % 10 == 1) ? 4 : (TAG % 10 == 2) ? 3 : 2;
+            if (occ > tuned) occ = tuned;
         }
         // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
         if (const char* e = getenv("PRCG_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) occ = v; }
