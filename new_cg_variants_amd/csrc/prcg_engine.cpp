@@ -114,7 +114,8 @@ struct prcg_handle {
 
     CsrDev csr() const { return CsrDev{indptr.i(), col.i(), val.d()}; }
     const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
-    bool multi() const { return nranks > 1; }
+    // any communicator -- even a 1-rank one -- selects the two-stream schedule
+    bool multi() const { return comm != nullptr; }
 };
 
 namespace {
@@ -170,7 +171,7 @@ bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == P
 
 // ---- halo exchange of an nc-component extended vector, all on `st` ----------------------
 int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
-    if (!h->multi() || h->g == 0) return PRCG_OK;
+    if (!h->multi() || h->g == 0 || h->nranks == 1) return PRCG_OK;
     CHECK(h, h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
     const int64_t nsend = h->send_ptr[h->n_peers];
     launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);

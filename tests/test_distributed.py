@@ -1,0 +1,117 @@
+"""The N>1 path.
+
+CPU (gloo, world_size 2 and 3): partition + halo-plan exchange + the exchange contract of
+prcg_set_halo, driven by the oracle's distributed loop (tests/dist_worker.py, mode 'cpu').
+
+GPU: the same worker in mode 'gpu' goes through libprcg (RCCL halo + all-reduce).  A
+one-GPU box can only host it if RCCL accepts two ranks on one device; when it refuses
+("Duplicate GPU") the test reports that and falls back to the single-rank communicator
+test, which still drives the complete two-stream schedule (events, side-stream reduction,
+ncclAllReduce) through a 1-rank RCCL communicator.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(mode, world, workload, iters, tmp_path, extra_env=None, timeout=300):
+    env = dict(os.environ)
+    env['MASTER_ADDR'] = '127.0.0.1'
+    env['OMP_NUM_THREADS'] = '1'
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    if extra_env:
+        env.update(extra_env)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), mode, workload, str(iters), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    return p
+
+
+@pytest.mark.parametrize('world,workload', [(2, 's1_small'), (3, 's3_small')])
+def test_row_block_halo_plan_over_gloo(tmp_path, world, workload):
+    p = launch('cpu', world, workload, 10, tmp_path)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    for r in range(world):
+        res = np.load(tmp_path / f'result_cpu_{r}.npy', allow_pickle=True).item()
+        assert res['pipe_pr_cg'] <= 1e-11 and res['hs_cg'] <= 1e-11, res
+
+
+def test_halo_plan_is_consistent_between_ranks():
+    """send lists of rank a towards b == ghost list of b owned by a, for an irregular matrix."""
+    from new_cg_variants_amd import partition, problems
+    A = problems.irregular_standin(6000, mean_len=12, max_len=80, reach=900, seed=3)
+    offsets, parts = partition.split_serial(A, 4, partition.nnz_balanced_offsets(A.indptr, 4))
+    x = np.random.default_rng(0).standard_normal(A.shape[0])
+    y = A @ x
+    for r, (A_local, ghosts, halo) in enumerate(parts):
+        lo, hi = offsets[r], offsets[r + 1]
+        ext = np.concatenate([x[lo:hi], x[ghosts]])
+        assert np.array_equal(A_local @ ext, y[lo:hi])
+        for q, peer in enumerate(halo['peers']):
+            # what I send to `peer` must be exactly what `peer` expects from me, in order
+            mine = halo['send_idx'][halo['send_ptr'][q]:halo['send_ptr'][q + 1]] + lo
+            ph = parts[peer][2]
+            qq = list(ph['peers']).index(r)
+            theirs = parts[peer][1][ph['recv_ptr'][qq]:ph['recv_ptr'][qq + 1]]
+            assert np.array_equal(mine, theirs)
+    # balanced: no rank has more than 1.25x the mean nnz
+    nnz = [p[0].nnz for p in parts]
+    assert max(nnz) <= 1.25 * np.mean(nnz)
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
+    """A 1-rank RCCL communicator switches the engine to its multi-rank schedule (compute
+    + communication stream, events, side-stream reduction, ncclAllReduce).  Results must be
+    bit-identical to the plain single-GPU path."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd.device import DeviceCSR
+    A, z = matrices['nos7']
+    n = A.shape[0]
+    path = L.default_rccl_path()
+    uid = np.zeros(128, dtype=np.uint8)
+    L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+    plain = DeviceCSR(A)
+    comm = DeviceCSR(A, comm_init=(0, 1, uid.tobytes(), path))
+    for variant in (L.PIPE_PR, L.HS, L.PR):
+        outs = []
+        for op in (plain, comm):
+            op.begin(variant, z['b'], np.zeros(n), 400, x_true=z['x_true'], hist_mask=15)
+            op.iterate(399)
+            op.sync()
+            outs.append((op.history(), op.get_vector('x')))
+        for q in outs[0][0]:
+            assert np.array_equal(outs[0][0][q], outs[1][0][q], equal_nan=True), (variant, q)
+        assert np.array_equal(outs[0][1], outs[1][1])
+    plain.close()
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_rccl_when_the_box_allows_it(tmp_path):
+    import torch
+    ngpu = torch.cuda.device_count()
+    share = ngpu < 2
+    p = launch('gpu', 2, 's1_small', 10, tmp_path, {'PRCG_TEST_SHARE_GPU': '1' if share else '0'}, timeout=600)
+    if p.returncode != 0 and share:
+        tail = (p.stdout + p.stderr)[-3000:]
+        pytest.skip('RCCL refused two ranks on one GPU on this box (expected on a 1-GPU box): ' + tail[-400:])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    for r in range(2):
+        res = np.load(tmp_path / f'result_gpu_{r}.npy', allow_pickle=True).item()
+        assert res['pipe_pr_cg'] <= 1e-11 and res['hs_cg'] <= 1e-11, res
