@@ -171,7 +171,7 @@ bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == P
 
 // ---- halo exchange of an nc-component extended vector, all on `st` ----------------------
 int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
-    if (!h->multi() || h->g == 0 || h->nranks == 1) return PRCG_OK;
+    if (!h->multi() || h->g == 0) return PRCG_OK;
     CHECK(h, h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
     const int64_t nsend = h->send_ptr[h->n_peers];
     launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);
@@ -618,8 +618,10 @@ int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank, const int64_
     }
     CHECK(h, h->send_ptr[0] == 0 && h->recv_ptr[0] == 0, "prcg_set_halo: pointers must start at 0");
     for (int q = 0; q < n_peers; ++q) {
-        CHECK(h, h->peer_rank[q] >= 0 && h->peer_rank[q] < h->nranks && h->peer_rank[q] != h->rank,
-              "prcg_set_halo: bad peer rank %d", h->peer_rank[q]);
+        // peer == own rank is allowed: RCCL does self send/recv inside a group, which is how
+        // the one-GPU tests drive the whole halo path (loopback ghosts)
+        CHECK(h, h->peer_rank[q] >= 0 && h->peer_rank[q] < h->nranks, "prcg_set_halo: bad peer rank %d",
+              h->peer_rank[q]);
         CHECK(h, h->send_ptr[q + 1] >= h->send_ptr[q] && h->recv_ptr[q + 1] >= h->recv_ptr[q],
               "prcg_set_halo: pointers not monotone");
     }
@@ -639,7 +641,7 @@ int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank, const int64_
 static int timed_product(prcg_t* h, int nc, const double* in, double* out, int reps, double* ms_avg) {
     CHECK(h, h->have_csr, "no matrix: call prcg_set_csr first");
     CHECK(h, in && out && reps >= 1, "bad argument");
-    CHECK(h, h->g == 0 || !h->multi() || h->have_halo, "ghost columns without a halo plan");
+    CHECK(h, h->g == 0 || (h->multi() && h->have_halo), "ghost columns need a communicator and a halo plan");
     HIPCHK(h, hipSetDevice(h->dev));
     int rc = h2d(h, h->tmp_ext.d(), in, h->n * nc);
     if (rc) return rc;
@@ -688,7 +690,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     CHECK(h, (hist_mask & ~PRCG_HIST_ALL) == 0, "prcg_solve_begin: unknown history bits");
     CHECK(h, !(hist_mask & (PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) || x_true,
           "prcg_solve_begin: error histories need x_true");
-    CHECK(h, h->g == 0 || !h->multi() || h->have_halo, "ghost columns without a halo plan");
+    CHECK(h, h->g == 0 || (h->multi() && h->have_halo), "ghost columns need a communicator and a halo plan");
     HIPCHK(h, hipSetDevice(h->dev));
     const int64_t n = h->n, ne = h->n + h->g;
     const size_t D = sizeof(double);

@@ -61,8 +61,8 @@ class DeviceCSR:
         n_ghost = n_cols - n_rows
         if n_ghost < 0:
             raise ValueError('row block must have at least n_rows columns (local numbering)')
-        if n_ghost > 0 and halo is None and self.nranks > 1:
-            raise ValueError('ghost columns need a halo plan')
+        if n_ghost > 0 and halo is None:
+            raise ValueError('ghost columns need a halo plan (and a communicator)')
         indptr = np.ascontiguousarray(A.indptr)
         is64 = indptr.dtype == np.int64
         if not is64:

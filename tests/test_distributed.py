@@ -102,6 +102,67 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
     comm.close()
 
 
+def loopback_problem(A, k):
+    """Rewrite A as if it were cut at row n/2 into two row blocks whose halo is exchanged
+    with ... itself: columns in [n/2-k, n/2) seen from rows >= n/2 and columns in
+    [n/2, n/2+k) seen from rows < n/2 are reached through ghost slots fed by a self
+    send/recv.  A_loop @ [x ; x[ghost_ids]] == A @ x with the nonzeros of every row in
+    unchanged order."""
+    import scipy.sparse as sp
+    A = A.tocsr()
+    n = A.shape[0]
+    h = n // 2
+    ghost_ids = np.arange(h - k, h + k)
+    slot = -np.ones(n, dtype=np.int64)
+    slot[ghost_ids] = n + np.arange(ghost_ids.size)
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    cols = A.indices.astype(np.int64).copy()
+    via_ghost = ((cols >= h - k) & (cols < h) & (rows >= h)) | ((cols >= h) & (cols < h + k) & (rows < h))
+    cols[via_ghost] = slot[cols[via_ghost]]
+    A_loop = sp.csr_matrix((A.data, cols.astype(np.int32), A.indptr), shape=(n, n + ghost_ids.size))
+    halo = {'peers': np.array([0], dtype=np.int32), 'send_ptr': np.array([0, ghost_ids.size], dtype=np.int64),
+            'send_idx': ghost_ids.astype(np.int32), 'recv_ptr': np.array([0, ghost_ids.size], dtype=np.int64)}
+    return A_loop, halo, int(via_ghost.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,k', [('s1_small', 70), ('s3_small', 9)])
+def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k):
+    """pack kernel -> ncclSend/ncclRecv (to self) -> ghost slots -> interior/boundary tile
+    split -> event choreography, all on one GPU.  Must be bit-identical to the plain path."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    A_loop, halo, moved = loopback_problem(A, k)
+    assert moved > 0
+    b, x0, x_true = problems.reference_rhs(A, n)
+    path = L.default_rccl_path()
+    uid = np.zeros(128, dtype=np.uint8)
+    L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+    plain = DeviceCSR(A)
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid.tobytes(), path), halo=halo)
+    x = np.random.default_rng(2).standard_normal(n)
+    y0, _ = plain.matvec(x)
+    y1, _ = loop.matvec(x)
+    assert np.array_equal(y0, A @ x) and np.array_equal(y1, y0)
+    RS = np.stack([x, x[::-1]], axis=1)
+    assert np.array_equal(loop.matmat2(RS)[0], plain.matmat2(RS)[0])
+    for variant in (L.PIPE_PR, L.HS, L.PR, L.PIPE_P):
+        outs = []
+        for op in (plain, loop):
+            op.begin(variant, b, x0, 120, x_true=x_true, hist_mask=15)
+            op.iterate(119)
+            op.sync()
+            outs.append((op.history(), op.get_vector('x')))
+        for q in outs[0][0]:
+            assert np.array_equal(outs[0][0][q], outs[1][0][q], equal_nan=True), (variant, q)
+        assert np.array_equal(outs[0][1], outs[1][1]), variant
+    plain.close()
+    loop.close()
+
+
 @pytest.mark.gpu
 def test_two_ranks_through_rccl_when_the_box_allows_it(tmp_path):
     import torch
