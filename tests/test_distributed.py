@@ -156,9 +156,20 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k):
             op.iterate(119)
             op.sync()
             outs.append((op.history(), op.get_vector('x')))
+        pipelined = variant in (L.PIPE_PR, L.PIPE_P)
         for q in outs[0][0]:
-            assert np.array_equal(outs[0][0][q], outs[1][0][q], equal_nan=True), (variant, q)
-        assert np.array_equal(outs[0][1], outs[1][1]), variant
+            if pipelined and q != 'error_A_norm':
+                # every inner product comes from the fused update kernel, whose reduction
+                # tree does not depend on the tiling: bit-identical
+                assert np.array_equal(outs[0][0][q], outs[1][0][q], equal_nan=True), (variant, q)
+            else:
+                # inner products fused into the SpMV are summed per tile; the loopback
+                # operator has a different (interior / boundary) tile order
+                np.testing.assert_allclose(outs[1][0][q], outs[0][0][q], rtol=1e-7 if not pipelined else 1e-11)
+        if pipelined:
+            assert np.array_equal(outs[0][1], outs[1][1]), variant
+        else:
+            np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-7)
     plain.close()
     loop.close()
 
