@@ -83,6 +83,7 @@ struct prcg_handle {
     DevBuf indptr, col, val, tiles;
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
+    bool side_stream = true;             // reduce partials beside the SpMM (PRCG_SIDE_STREAM=0 turns it off)
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
     DevBuf t1;                           // 2*n doubles: SpMV output scratch
     DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues
@@ -102,7 +103,7 @@ struct prcg_handle {
     int k = 0;
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
-    DevBuf x, p, rs, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf x, xp, p, rs, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
     DevBuf dots, coef;
 
     // ---- profiling ----
@@ -210,6 +211,10 @@ int dist_spmv(prcg_t* h, double* x_ext, double* y, SpmvEpilogue epi, const doubl
     return PRCG_OK;
 }
 
+// the iterate x: second-class citizen of the pair array XP in the pipelined variants
+const double* x_ptr(prcg_t* h) { return is_pipe(h->variant) ? h->xp.d() : h->x.d(); }
+int x_stride(prcg_t* h) { return is_pipe(h->variant) ? 2 : 1; }
+
 double* dots_at(prcg_t* h, int k) { return h->dots.d() + (size_t)k * kNS; }
 double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride; }
 
@@ -221,21 +226,21 @@ int record(prcg_t* h, int k) {
     int rc;
     if (m & PRCG_HIST_RESIDUAL_2_NORM) {
         // |b - A x|   callbacks/residual_2_norm.py:41
-        launch_copy(h->sc, h->tmp_ext.d(), 1, h->x.d(), 1, n);
+        launch_copy(h->sc, h->tmp_ext.d(), 1, x_ptr(h), x_stride(h), n);
         if ((rc = dist_spmv(h, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
-        const int grid = launch_diff_sq(h->sc, h->b.d(), h->t1.d(), n, h->partA.d(), PRCG_S_RES2);
+        const int grid = launch_diff_sq(h->sc, h->b.d(), 1, h->t1.d(), n, h->partA.d(), PRCG_S_RES2);
         LAUNCHCHK(h, grid);
         launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), PRCG_S_RES2, PRCG_S_RES2, 1);
     }
     if (m & PRCG_HIST_ERROR_2_NORM) {
         // |x - x_true|   callbacks/error_2_norm.py:47-48
-        const int grid = launch_diff_sq(h->sc, h->x.d(), h->xt.d(), n, h->partA.d(), PRCG_S_ERR2);
+        const int grid = launch_diff_sq(h->sc, x_ptr(h), x_stride(h), h->xt.d(), n, h->partA.d(), PRCG_S_ERR2);
         LAUNCHCHK(h, grid);
         launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), PRCG_S_ERR2, PRCG_S_ERR2, 1);
     }
     if (m & PRCG_HIST_ERROR_A_NORM) {
         // e = x - x_true; e'(A e)   callbacks/error_A_norm.py:47-48
-        launch_sub(h->sc, h->e_ext.d(), 1, h->x.d(), 1, h->xt.d(), 1, n);
+        launch_sub(h->sc, h->e_ext.d(), 1, x_ptr(h), x_stride(h), h->xt.d(), 1, n);
         int grid = 0;
         if ((rc = dist_spmv(h, h->e_ext.d(), h->t1.d(), kEpiDotXY, nullptr, nullptr, nullptr, &grid))) return rc;
         launch_reduce_final(h->sc, h->partB.d(), grid, dots_at(h, k), 0, PRCG_S_ERRA2, 1);
@@ -259,24 +264,30 @@ void prof_end(prcg_t* h, std::vector<EventPair>& evs, int& count, bool on) {
     ++count;
 }
 
-// SpMM of the pipelined loop, overlapped with halo + reduction when multi-rank.
+// SpMM of the pipelined loop.  The fixed-order reduction of the update kernel's block
+// partials (and, with a communicator, the halo exchange and the one all-reduce) run on
+// the communication stream, hidden behind the matrix product on the compute stream.
 // `grid_upd` = number of partial blocks the update kernel just wrote to partA.
 int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     double* in_ext = h->prec ? h->rst.d() : h->rs.d();
     const int mask = pipe_recompute(h->variant) ? 3 : 2;
     bool on = false;
-    if (!h->multi()) {
+    int rc;
+    if (!h->side_stream && !h->multi()) {
+        // everything in order on one stream (PRCG_SIDE_STREAM=0; A/B knob)
         launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
         LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         return PRCG_OK;
     }
+    const bool halo = h->multi() && h->g > 0;
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
     HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
-    int rc = exchange(h, in_ext, 2, h->sm);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+    if (halo) {
+        if ((rc = exchange(h, in_ext, 2, h->sm))) return rc;
+        HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+    }
     launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
     if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
@@ -284,8 +295,10 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
     if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
-    HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+    if (halo) {
+        HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
+        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+    }
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
     return PRCG_OK;
 }
@@ -325,7 +338,7 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
 PipeUpdateArgs pipe_args(prcg_t* h, int k) {
     PipeUpdateArgs a{};
     a.n = h->n;
-    a.x = h->x.d(); a.p = h->p.d();
+    a.xp = h->xp.d();
     a.rs = h->rs.d(); a.rst = h->prec ? h->rst.d() : nullptr;
     a.wu = h->wu.d(); a.wt = h->wt.d();
     a.d = h->prec ? h->dinv.d() : nullptr;
@@ -428,10 +441,10 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
     *stride = 1;
     *base = nullptr;
     const int v = h->variant;
-    if (which == PRCG_VEC_X) { *base = h->x.d(); return true; }
-    if (which == PRCG_VEC_P) { *base = h->p.d(); return true; }
     if (is_pipe(v)) {
         switch (which) {
+        case PRCG_VEC_X: *base = h->xp.d(); *stride = 2; return true;
+        case PRCG_VEC_P: *base = h->xp.d() + 1; *stride = 2; return true;
         case PRCG_VEC_R: *base = h->rs.d(); *stride = 2; return true;
         case PRCG_VEC_S: *base = h->rs.d() + 1; *stride = 2; return true;
         case PRCG_VEC_W: *base = h->wu.d(); *stride = 2; return true;
@@ -443,6 +456,8 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         }
     }
     switch (which) {
+    case PRCG_VEC_X: *base = h->x.d(); return true;
+    case PRCG_VEC_P: *base = h->p.d(); return true;
     case PRCG_VEC_R: *base = h->r.d(); return true;
     case PRCG_VEC_S: *base = h->s.d(); return true;
     case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
@@ -480,6 +495,7 @@ int prcg_create(prcg_t** out, int device_id) {
     prcg_t* h = new (std::nothrow) prcg_handle();
     if (!h) return fail(nullptr, PRCG_ENOMEM, "out of host memory");
     h->dev = device_id;
+    if (const char* e = getenv("PRCG_SIDE_STREAM")) h->side_stream = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -724,16 +740,18 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
 
     if (is_pipe(variant)) {
-        HIPCHK(h, h->p.alloc((size_t)n * D));
+        HIPCHK(h, h->xp.alloc((size_t)2 * n * D));
         HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
         HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
         HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
         HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
         double* RS = h->rs.d();
         double* WU = h->wu.d();
+        double* XP = h->xp.d();
+        launch_copy(sc, XP, 2, h->x.d(), 1, n);                             // x = x0         :22
         launch_sub(sc, RS, 2, h->b.d(), 1, t1, 1, n);                       // r = b - A x
         if (!h->prec) {
-            launch_copy(sc, h->p.d(), 1, RS, 2, n);                         // p = r          :24
+            launch_copy(sc, XP + 1, 2, RS, 2, n);                           // p = r          :24
             launch_copy(sc, tmp, 1, RS, 2, n);
             if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
             launch_copy(sc, RS + 1, 2, t1, 1, n);                           // s = A p        :26
@@ -744,7 +762,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         } else {
             double* RST = h->rst.d();
             launch_mul(sc, RST, 2, h->dinv.d(), 1, RS, 2, n);               // r~ = M^-1 r    :124
-            launch_copy(sc, h->p.d(), 1, RST, 2, n);                        // p = r~         :125
+            launch_copy(sc, XP + 1, 2, RST, 2, n);                          // p = r~         :125
             launch_copy(sc, tmp, 1, RST, 2, n);
             if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
             launch_copy(sc, RS + 1, 2, t1, 1, n);                           // s = A p        :127

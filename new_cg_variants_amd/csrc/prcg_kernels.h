@@ -49,8 +49,7 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {
     int64_t n;
-    double* x;        // n
-    double* p;        // n
+    double* xp;       // pairs (x,p)
     double* rs;       // pairs (r,s)  -- when preconditioned: the plain pair, no ghosts
     double* rst;      // pairs (r~,s~) (preconditioned only; the SpMM input)
     double* wu;       // pairs (w,u)
@@ -91,8 +90,8 @@ void launch_reduce_final(hipStream_t st, const double* partials, int nparts, dou
 void launch_copy(hipStream_t st, double* dst, int ds, const double* src, int ss, int64_t n);
 void launch_sub(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n);
 void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n);
-// partial[slot] = sum (a_i - b_i)^2
-int launch_diff_sq(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot);
+// partial[slot] = sum (a[i*as] - b[i])^2
+int launch_diff_sq(hipStream_t st, const double* a, int as, const double* b, int64_t n, double* partials, int slot);
 // buf[j*nc + c] = v[idx[j]*nc + c]
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc);
 

@@ -293,6 +293,11 @@ __device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meur
     return c;
 }
 
+// All state of the pipelined variants is stored as 16-byte pairs -- XP = (x,p), RS = (r,s),
+// WU = (w,u), RSt = (r~,s~) -- so that every global access of this kernel is one fully
+// coalesced 16-byte-per-lane instruction.  Thread t of block b handles elements
+// base + t and base + 256 + t of each 512-element trip (two independent elements in
+// flight).
 template <bool PREC, bool DOTS_ONLY>
 __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int trips) {
     Coefs c = {0.0, 0.0, 0.0};
@@ -304,73 +309,77 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
     }
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // mu, dl, gm, nu, rr
     const int64_t n = a.n;
+    double2* __restrict__ XP = reinterpret_cast<double2*>(a.xp);
     double2* __restrict__ RS = reinterpret_cast<double2*>(a.rs);
     double2* __restrict__ RST = reinterpret_cast<double2*>(a.rst);
     double2* __restrict__ WU = reinterpret_cast<double2*>(a.wu);
+    double* __restrict__ WT = a.wt;
+    const double* __restrict__ D = a.d;
+    const bool recompute_w = a.recompute_w != 0;
 
-    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
-    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
-        if (i >= n) break;
-        const bool two = (i + 1 < n);
-        double xv[2], pv[2];
-        if (two) {
-            const double2 x2 = *reinterpret_cast<const double2*>(a.x + i);
-            const double2 p2 = *reinterpret_cast<const double2*>(a.p + i);
-            xv[0] = x2.x; xv[1] = x2.y; pv[0] = p2.x; pv[1] = p2.y;
-        } else {
-            xv[0] = a.x[i]; pv[0] = a.p[i]; xv[1] = 0.0; pv[1] = 0.0;
-        }
+    int64_t base = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x;
+    for (int j = 0; j < trips; ++j, base += kElemsPerTrip) {
+        if (base >= n) break;
+        // ---- loads of both elements first ----
+        double2 xp[2], rs[2], wu[2], rst[2];
+        double dv[2], wt[2];
+        bool ok[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (e == 1 && !two) break;
-            const int64_t ie = i + e;
-            double2 rs = RS[ie];
-            if constexpr (DOTS_ONLY) {
-                if constexpr (PREC) {
-                    const double2 rst = RST[ie];
-                    acc[0] += pv[e] * rs.y; acc[1] += rs.x * rst.y; acc[2] += rst.y * rs.y;
-                    acc[3] += rst.x * rs.x; acc[4] += rs.x * rs.x;
-                } else {
-                    acc[0] += pv[e] * rs.y; acc[1] += rs.x * rs.y; acc[2] += rs.y * rs.y;
-                    acc[3] += rs.x * rs.x;
-                }
-                continue;
-            }
-            const double2 wu = WU[ie];
-            xv[e] = xv[e] + c.al * pv[e];                       // x += a p
-            const double rn = rs.x - c.al * rs.y;               // r -= a s
-            const double wn = wu.x - c.al * wu.y;               // w -= a u
+            const int64_t ie = base + e * kBlock;
+            ok[e] = ie < n;
+            const int64_t il = ok[e] ? ie : base;      // clamped: branch-free loads
+            xp[e] = XP[il];
+            rs[e] = RS[il];
+            if constexpr (!DOTS_ONLY) wu[e] = WU[il];
             if constexpr (PREC) {
-                double2 rst = RST[ie];
-                const double dv = a.d[ie];
-                const double ut = dv * wu.y;                    // u~ = M^-1 u
-                const double wt = a.recompute_w ? dv * wu.x : a.wt[ie];   // w~
-                const double rtn = rst.x - c.al * rst.y;        // r~ -= a s~
-                const double wtn = wt - c.al * ut;              // w~ -= a u~
-                const double pn = rtn + c.bt * pv[e];           // p = r~ + b p
-                const double sn = wn + c.bt * rs.y;             // s = w + b s
-                const double stn = wtn + c.bt * rst.y;          // s~ = w~ + b s~
-                pv[e] = pn;
-                RS[ie] = make_double2(rn, sn);
-                RST[ie] = make_double2(rtn, stn);
-                if (!a.recompute_w) { a.wu[2 * ie] = wn; a.wt[ie] = wtn; }
-                acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn;
-                acc[3] += rtn * rn; acc[4] += rn * rn;
-            } else {
-                const double pn = rn + c.bt * pv[e];            // p = r + b p
-                const double sn = wn + c.bt * rs.y;             // s = w + b s
-                pv[e] = pn;
-                RS[ie] = make_double2(rn, sn);
-                if (!a.recompute_w) a.wu[2 * ie] = wn;
-                acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+                rst[e] = RST[il];
+                if constexpr (!DOTS_ONLY) {
+                    dv[e] = D[il];
+                    wt[e] = recompute_w ? 0.0 : WT[il];
+                }
             }
         }
-        if constexpr (!DOTS_ONLY) {
-            if (two) {
-                *reinterpret_cast<double2*>(a.x + i) = make_double2(xv[0], xv[1]);
-                *reinterpret_cast<double2*>(a.p + i) = make_double2(pv[0], pv[1]);
+        // ---- arithmetic + stores, element 0 then element 1 (this order is part of the
+        //      reduction tree the tests emulate) ----
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!ok[e]) continue;
+            const int64_t ie = base + e * kBlock;
+            if constexpr (DOTS_ONLY) {
+                if constexpr (PREC) {
+                    acc[0] += xp[e].y * rs[e].y; acc[1] += rs[e].x * rst[e].y; acc[2] += rst[e].y * rs[e].y;
+                    acc[3] += rst[e].x * rs[e].x; acc[4] += rs[e].x * rs[e].x;
+                } else {
+                    acc[0] += xp[e].y * rs[e].y; acc[1] += rs[e].x * rs[e].y; acc[2] += rs[e].y * rs[e].y;
+                    acc[3] += rs[e].x * rs[e].x;
+                }
             } else {
-                a.x[i] = xv[0]; a.p[i] = pv[0];
+                const double xn = xp[e].x + c.al * xp[e].y;             // x += a p
+                const double rn = rs[e].x - c.al * rs[e].y;             // r -= a s
+                const double wn = wu[e].x - c.al * wu[e].y;             // w -= a u
+                if constexpr (PREC) {
+                    const double ut = dv[e] * wu[e].y;                  // u~ = M^-1 u
+                    const double wtv = recompute_w ? dv[e] * wu[e].x : wt[e];   // w~
+                    const double rtn = rst[e].x - c.al * rst[e].y;      // r~ -= a s~
+                    const double wtn = wtv - c.al * ut;                 // w~ -= a u~
+                    const double pn = rtn + c.bt * xp[e].y;             // p = r~ + b p
+                    const double sn = wn + c.bt * rs[e].y;              // s = w + b s
+                    const double stn = wtn + c.bt * rst[e].y;           // s~ = w~ + b s~
+                    XP[ie] = make_double2(xn, pn);
+                    RS[ie] = make_double2(rn, sn);
+                    RST[ie] = make_double2(rtn, stn);
+                    if (!recompute_w) { a.wu[2 * ie] = wn; WT[ie] = wtn; }
+                    acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn;
+                    acc[3] += rtn * rn; acc[4] += rn * rn;
+                } else {
+                    const double pn = rn + c.bt * xp[e].y;              // p = r + b p
+                    const double sn = wn + c.bt * rs[e].y;              // s = w + b s
+                    XP[ie] = make_double2(xn, pn);
+                    RS[ie] = make_double2(rn, sn);
+                    if (!recompute_w) a.wu[2 * ie] = wn;
+                    acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+                }
             }
         }
     }
@@ -506,7 +515,7 @@ __global__ void k_mul(double* dst, int ds, const double* a, int as, const double
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i * ds] = a[i * as] * b[i * bs];
 }
-__global__ __launch_bounds__(kBlock) void k_diff_sq(const double* __restrict__ a, const double* __restrict__ b,
+__global__ __launch_bounds__(kBlock) void k_diff_sq(const double* __restrict__ a, int as, const double* __restrict__ b,
                                                     int64_t n, double* partials, int slot, int trips) {
     double acc[1] = {0.0};
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_diff_sq(const double* __restrict__ a
         for (int e = 0; e < 2; ++e) {
             const int64_t ie = i + e;
             if (ie >= n) break;
-            const double dlt = a[ie] - b[ie];
+            const double dlt = a[ie * as] - b[ie];
             acc[0] += dlt * dlt;
         }
     }
@@ -694,9 +703,9 @@ void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, co
     if (n <= 0) return;
     hipLaunchKernelGGL(k_mul, dim3(util_grid(n)), dim3(256), 0, st, dst, ds, a, as, b, bs, n);
 }
-int launch_diff_sq(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot) {
+int launch_diff_sq(hipStream_t st, const double* a, int as, const double* b, int64_t n, double* partials, int slot) {
     const Chunking c = chunking(n);
-    hipLaunchKernelGGL(k_diff_sq, dim3(c.grid), dim3(kBlock), 0, st, a, b, n, partials, slot, c.trips);
+    hipLaunchKernelGGL(k_diff_sq, dim3(c.grid), dim3(kBlock), 0, st, a, as, b, n, partials, slot, c.trips);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc) {

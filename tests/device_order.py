@@ -3,7 +3,7 @@
 The fused update kernels (new_cg_variants_amd/csrc/prcg_kernels.hip: k_pipe_update,
 block_reduce_store, k_reduce_final) sum a product array in a fixed order:
 
-  thread (block b, lane t): elements (b*trips + j)*512 + 2t, +1  for j = 0..trips-1, in order
+  thread (block b, lane t): elements (b*trips + j)*512 + t, then + 256 + t, for j = 0..trips-1
   wave   : xor butterfly 32,16,8,4,2,1          block : waves 0..3 in order
   final  : 1024 threads, thread t sums partials t, t+1024, ...; butterfly; 16 waves in order
 
@@ -40,12 +40,12 @@ def device_sum(prod):
     grid, trips = chunking(n)
     padded = np.zeros(grid * trips * ELEMS_PER_TRIP)
     padded[:n] = prod
-    a = padded.reshape(grid, trips, 256, 2)
+    a = padded.reshape(grid, trips, 2, 256)
     acc = np.zeros((grid, 256))
     # elements past n are never added on the device; adding +0.0 here is the same value
     for j in range(trips):
         for e in range(2):
-            acc = acc + a[:, j, :, e]
+            acc = acc + a[:, j, e, :]
     waves = _butterfly(acc.reshape(grid, 4, 64))              # (grid, 4)
     partial = waves[:, 0]
     for w in range(1, 4):
