@@ -71,9 +71,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--workload', default='s3', choices=['s1', 's2', 's3', 's1_small', 's3_small'])
+    ap.add_argument('--workload', default='s3', choices=['s1', 's2', 's3', 's3_8th', 's1_small', 's3_small'])
     ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-comm', action='store_true',
+                    help='N=1 only: create a 1-rank RCCL communicator so the multi-rank schedule runs')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     args = ap.parse_args()
 
@@ -107,8 +109,15 @@ def main():
     nnz_local = int(A_rows.nnz)
     nnz_total = sum(comm.allgather_obj(nnz_local))
 
-    op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
-    dev = op.dev
+    if world == 1 and args.force_comm:
+        from new_cg_variants_amd.device import DeviceCSR
+        uid = np.zeros(128, dtype=np.uint8)
+        path = L.default_rccl_path()
+        L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+        dev = DeviceCSR(A_rows.tocsr(), device=local_rank, comm_init=(0, 1, uid.tobytes(), path))
+    else:
+        op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
+        dev = op.dev
     variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR}[args.variant]
 
     # ---- standalone SpMV rate (north_star: effective SpMV HBM GB/s vs roofline) -----------

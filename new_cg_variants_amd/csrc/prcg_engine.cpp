@@ -83,7 +83,8 @@ struct prcg_handle {
     DevBuf indptr, col, val, tiles;
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
-    bool side_stream = true;             // reduce partials beside the SpMM (PRCG_SIDE_STREAM=0 turns it off)
+    bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
+                                         // measured slower than in-order (cross-stream event waits ~15 us/iter)
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
     DevBuf t1;                           // 2*n doubles: SpMV output scratch
     DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues

@@ -120,6 +120,8 @@ WORKLOADS = {
                make=lambda rows=None: laplace_3d(216, 216, 216, rows)),
     's3': dict(desc='S3 ex2b banded n=1e7, 15 diagonals (nnz=149,999,944), kappa=1e6 rho=0.95 off=1e-4',
                n=10_000_000, make=lambda rows=None: banded_ex2b(10_000_000, 7, rows=rows)),
+    's3_8th': dict(desc='one eighth of S3: ex2b banded n=1.25e6, 15 diagonals', n=1_250_000,
+                   make=lambda rows=None: banded_ex2b(1_250_000, 7, rows=rows)),
     # reduced sizes for tests / smoke
     's1_small': dict(desc='5-pt Laplacian 64x48', n=64 * 48, make=lambda rows=None: laplace_2d(64, 48, rows)),
     's3_small': dict(desc='ex2b banded n=20000 k=7', n=20000,

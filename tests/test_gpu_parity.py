@@ -239,7 +239,11 @@ def test_free_running_against_reference(amd, matrices, matrix, method, prec):
                                        err_msg=f'{matrix}/{method}/{prec}/{q}')
     its, acc = orc.convergence_summary(out['error_A_norm'])
     ref_its, ref_acc = int(run['iters_to_1e-5']), float(run['log10_min_rel_error_A'])
-    assert abs(its - ref_its) <= max(2, 0.05 * ref_its), (its, ref_its)
+    # Spread of this statistic under a mere permutation of the summation order inside the
+    # reference's own loop (measured with oracle/, 8 orders): bcsstk03 pipe_pr 398..422
+    # (the fixture's 398 is the low end; the paper publishes 411), hs 363..373; nos7 pipe_pr
+    # 2867..2930, hs 2864..2896.  Hence +-8 %.
+    assert abs(its - ref_its) <= max(2, 0.08 * ref_its), (its, ref_its)
     assert abs(acc - ref_acc) < 2.5, (acc, ref_acc)
     print(f'{matrix}/{method}/{prec}: its {its} (ref {ref_its}), log10 min err {acc:.2f} (ref {ref_acc:.2f})')
 
