@@ -3,11 +3,29 @@
 This is the thin layer between SciPy CSR arrays and the C-ABI (include/prcg.h); every
 numerical operation happens in the HIP kernels behind it.
 """
+import contextlib
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 
 from . import _lib as L
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on fd 1 when a communicator is created; a program
+    whose stdout is a protocol (bench.py prints exactly one JSON line) must not see it."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class DeviceCSR:
@@ -30,8 +48,9 @@ class DeviceCSR:
         self.rank, self.nranks = 0, 1
         if comm_init is not None:
             rank, nranks, uid, path = comm_init
-            self._check(self._lib.prcg_comm_init(self._h, path.encode() if path else None, rank, nranks,
-                                                 L.ptr(np.frombuffer(uid, dtype=np.uint8).copy())))
+            with _stdout_to_stderr():
+                self._check(self._lib.prcg_comm_init(self._h, path.encode() if path else None, rank, nranks,
+                                                     L.ptr(np.frombuffer(uid, dtype=np.uint8).copy())))
             self.rank, self.nranks = rank, nranks
         self._set_matrix(A, halo)
 

@@ -101,7 +101,9 @@ class RowBlockOperator:
             uid = None
             if rank == 0:
                 buf = np.zeros(128, dtype=np.uint8)
-                L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf)))
+                from ..device import _stdout_to_stderr
+                with _stdout_to_stderr():
+                    L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf)))
                 uid = buf.tobytes()
             uid = comm.bcast_obj(uid, root=0)
             comm_init = (rank, size, uid, path)
