@@ -79,6 +79,13 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout is a protocol here (exactly one JSON line on rank 0): libraries that chat on
+    # fd 1 (Gloo's "Rank 0 is connected ...", RCCL's version banner) are sent to stderr
+    # for the whole run; the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -193,7 +200,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
 
     dev.close()
     if world > 1:
