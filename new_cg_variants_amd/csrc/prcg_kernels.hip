@@ -132,7 +132,13 @@ __device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename Ve
 }
 
 // ---- register image of one tile's val/col stream ------------------------------------
-template <int STEPS>
+// LS = false: each lane holds 4 CONSECUTIVE nonzeros per step (one 16-byte load of 4
+//              column indices, two of the values);
+// LS = true : lane l holds nonzeros l, l+64, l+128, l+192 of the step (4-byte / 8-byte
+//              loads, each wave-instruction one contiguous 256 / 512 bytes).  Neighbouring
+//              lanes then gather NEIGHBOURING columns, so one gather instruction touches
+//              ~4x fewer cache lines, and the product stores into LDS are conflict-free.
+template <int STEPS, bool LS>
 struct MatRegs {
     int4 cc[STEPS];
     double2 va[STEPS], vb[STEPS];
@@ -151,24 +157,33 @@ __device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, int t
 // Branch-free 16-byte loads of the tile's column indices and values: a lane whose chunk
 // lies past the tile re-reads the tile's first chunk (one hot line); its products land in
 // LDS slots nobody reads.
-template <int STEPS>
-__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS>& m) {
+template <int STEPS, bool LS>
+__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS>& m) {
     const int alo = d.lo & ~3;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        const int base = alo + st * 256 + lane * 4;
-        const int lb = base < d.hi ? base : alo;
-        m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
-        m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-        m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+        if constexpr (LS) {
+            const int b0 = alo + st * 256 + lane;
+            const int i0 = b0 < d.hi ? b0 : alo, i1 = b0 + 64 < d.hi ? b0 + 64 : alo;
+            const int i2 = b0 + 128 < d.hi ? b0 + 128 : alo, i3 = b0 + 192 < d.hi ? b0 + 192 : alo;
+            m.cc[st] = make_int4(A.col[i0], A.col[i1], A.col[i2], A.col[i3]);
+            m.va[st] = make_double2(A.val[i0], A.val[i1]);
+            m.vb[st] = make_double2(A.val[i2], A.val[i3]);
+        } else {
+            const int base = alo + st * 256 + lane * 4;
+            const int lb = base < d.hi ? base : alo;
+            m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+            m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+            m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+        }
     }
 }
 
 // One tile: gather x[col], products -> this wave's LDS slice, then one lane per row sums
 // its row left to right.  `cur` holds the tile's val/col stream (loaded one tile ago).
-template <int NV, int EPI, int STEPS>
+template <int NV, int EPI, int STEPS, bool LS>
 __device__ __forceinline__ void process_tile(
-    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS>& cur,
+    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS>& cur,
     typename VecT<NV>::type* my, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
     const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[3])
@@ -194,11 +209,19 @@ __device__ __forceinline__ void process_tile(
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
-        const int o = st * 256 + lane * 4;
-        my[o + 0] = vmul(cur.va[st].x, g0);
-        my[o + 1] = vmul(cur.va[st].y, g1);
-        my[o + 2] = vmul(cur.vb[st].x, g2);
-        my[o + 3] = vmul(cur.vb[st].y, g3);
+        if constexpr (LS) {
+            const int o = st * 256 + lane;
+            my[o] = vmul(cur.va[st].x, g0);
+            my[o + 64] = vmul(cur.va[st].y, g1);
+            my[o + 128] = vmul(cur.vb[st].x, g2);
+            my[o + 192] = vmul(cur.vb[st].y, g3);
+        } else {
+            const int o = st * 256 + lane * 4;
+            my[o + 0] = vmul(cur.va[st].x, g0);
+            my[o + 1] = vmul(cur.va[st].y, g1);
+            my[o + 2] = vmul(cur.vb[st].x, g2);
+            my[o + 3] = vmul(cur.vb[st].y, g3);
+        }
     }
     wave_lds_sync();
     if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
@@ -215,7 +238,7 @@ __device__ __forceinline__ void process_tile(
 // stream of tile t+W is already in flight (second register image) and the descriptor of
 // tile t+2W is being fetched.  The dependent chain per tile is then just
 // gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
-template <int NV, int EPI, int STEPS>
+template <int NV, int EPI, int STEPS, bool LS>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -239,11 +262,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     const int W = nblk * kWaves;
     int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
 
-    MatRegs<STEPS> m0, m1;
+    MatRegs<STEPS, LS> m0, m1;
     TileDesc d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
     if (t < ntiles) {
         d0 = read_desc(T4, t);
-        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS>(A, d0, lane, m0);
+        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
         if (t + W < ntiles) d1 = read_desc(T4, t + W);
     }
 
@@ -253,8 +276,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const bool has_next = t + W < ntiles;
             const int t2 = t + 2 * W;
             const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
-            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS>(A, d1, lane, m1);
-            process_tile<NV, EPI, STEPS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d1, lane, m1);
+            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
             d0 = d2;
             t += W;
         }
@@ -264,8 +287,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const bool has_next = t + W < ntiles;
             const int t2 = t + 2 * W;
             const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
-            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS>(A, d0, lane, m0);
-            process_tile<NV, EPI, STEPS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
+            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
             d1 = d2;
             t += W;
         }
@@ -597,11 +620,18 @@ int tile_grid(K kernel, int ntiles) {
 // ---- launch wrappers -------------------------------------------------------------------
 #define PRCG_LAUNCH_OK() (hipGetLastError() == hipSuccess)
 
+// experiment knob: PRCG_LANE_STRIDED=0 selects the 4-consecutive-nonzeros-per-lane layout
+bool lane_strided() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PRCG_LANE_STRIDED"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials)
 {
-    auto k = k_spmv_tiles<NV, EPI, STEPS>;
+    auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
                        partials);
