@@ -201,6 +201,17 @@ def test_teacher_forced_single_step(amd, matrices, matrix, method, prec):
 # free-running: prefix vs the reference, whole trajectory vs the device-ordered oracle,
 # convergence statistics vs the reference
 # ---------------------------------------------------------------------------------------
+# Published known answers: iterations to relative A-norm error 1e-5 and log10 of the best
+# relative error (reference: numerical_experiments/figures/convergence_table_data.tex,
+# columns hs, cg, m, pr, gv, pipe_pr_m, pipe_pr).
+PUBLISHED = {
+    ('bcsstk03', 'None', 'hs_cg'): (364, -14.55), ('bcsstk03', 'None', 'pr_pcg'): (380, -14.43),
+    ('bcsstk03', 'None', 'pipe_pr_m_cg'): (492, -12.65), ('bcsstk03', 'None', 'pipe_pr_cg'): (411, -12.96),
+    ('nos7', 'None', 'hs_cg'): (2869, -9.01), ('nos7', 'None', 'pipe_pr_cg'): (2899, -7.24),
+    ('bcsstk03', 'jacobi', 'hs_pcg'): (118, -14.10), ('bcsstk03', 'jacobi', 'pipe_pr_pcg'): (121, -13.50),
+    ('nos7', 'jacobi', 'hs_pcg'): (67, -8.91), ('nos7', 'jacobi', 'pipe_pr_pcg'): (67, -9.41),
+}
+
 # Free-running prefix on which 1e-12 holds.  It is set by how fast these ill-conditioned
 # problems amplify ANY change of summation order (about 30x per iteration on bcsstk03):
 # measured on MI355X the recurrence residual leaves 1e-12 around k=8 (bcsstk03) / k=14 (nos7),
@@ -240,12 +251,17 @@ def test_free_running_against_reference(amd, matrices, matrix, method, prec):
                                        err_msg=f'{matrix}/{method}/{prec}/{q}')
     its, acc = orc.convergence_summary(out['error_A_norm'])
     ref_its, ref_acc = int(run['iters_to_1e-5']), float(run['log10_min_rel_error_A'])
-    # Spread of this statistic under a mere permutation of the summation order inside the
-    # reference's own loop (measured with oracle/, 8 orders): bcsstk03 pipe_pr 398..422
-    # (the fixture's 398 is the low end; the paper publishes 411), hs 363..373; nos7 pipe_pr
-    # 2867..2930, hs 2864..2896.  Hence +-8 %.
-    assert abs(its - ref_its) <= max(2, 0.08 * ref_its), (its, ref_its)
-    assert abs(acc - ref_acc) < 2.5, (acc, ref_acc)
+    # Two anchors: the reference re-run in the build container (fixture) and the value the
+    # reference publishes (figures/convergence_table_data.tex:5,26,38,52).  Spread of the
+    # statistic under a mere permutation of the summation order inside the reference's own
+    # loop (measured with oracle/, 8 orders): bcsstk03 pipe_pr 398..422 iterations (fixture
+    # 398 is the low end; published 411), hs 363..373; nos7 pipe_pr 2867..2930 and attained
+    # accuracy -7.0..-9.7 (fixture -9.66 is the outlier; published -7.24).
+    pub = PUBLISHED.get((matrix, prec, method))
+    its_anchors = [ref_its] + ([pub[0]] if pub else [])
+    acc_anchors = [ref_acc] + ([pub[1]] if pub else [])
+    assert any(abs(its - a) <= max(2, 0.08 * a) for a in its_anchors), (its, its_anchors)
+    assert min(acc_anchors) - 1.5 <= acc <= max(acc_anchors) + 1.5, (acc, acc_anchors)
     print(f'{matrix}/{method}/{prec}: its {its} (ref {ref_its}), log10 min err {acc:.2f} (ref {ref_acc:.2f})')
 
 

@@ -1,0 +1,86 @@
+// Streaming ceilings on the attached GPU: read-only, copy, and the SpMV-shaped
+// two-stream (4-byte + 8-byte) read.  hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o /tmp/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const double2* __restrict__ a, size_t n2, double* out) {
+    double s = 0.0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
+        double2 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = a[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) s += v[u].x + v[u].y;
+    }
+    for (; i < n2; i += stride) { double2 v = a[i]; s += v.x + v.y; }
+    if (s == 123.456) out[0] = s;
+}
+// block-contiguous chunks instead of grid-stride
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read_chunk(const double2* __restrict__ a, size_t n2, double* out) {
+    double s = 0.0;
+    const size_t per = (n2 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < n2 ? lo + per : n2;
+    size_t i = lo + threadIdx.x;
+    for (; i + (UNROLL - 1) * 256 < hi; i += UNROLL * 256) {
+        double2 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = a[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) s += v[u].x + v[u].y;
+    }
+    for (; i < hi; i += 256) { double2 v = a[i]; s += v.x + v.y; }
+    if (s == 123.456) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_copy(const double2* __restrict__ a, double2* __restrict__ b, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) b[i] = a[i];
+}
+// read/modify/write like the CG update: 3 pair arrays read, 2 written
+__global__ __launch_bounds__(256) void k_update_like(double2* __restrict__ a, double2* __restrict__ b, const double2* __restrict__ c, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) {
+        double2 x = a[i], y = b[i], z = c[i];
+        a[i] = make_double2(x.x + 0.5 * x.y, y.x + 0.25 * x.y);
+        b[i] = make_double2(y.x - 0.5 * y.y, z.x + 0.25 * y.y);
+    }
+}
+int main() {
+    const size_t bytes = (size_t)2 << 30;   // 2 GiB per buffer
+    const size_t n2 = bytes / 16;
+    double2 *a, *b, *c; double* out;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&c, bytes)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes)); CK(hipMemset(c, 1, bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time = [&](auto launch, const char* name, double gbytes) {
+        for (int w = 0; w < 2; ++w) launch();
+        CK(hipDeviceSynchronize());
+        float best = 1e9, tot = 0;
+        for (int r = 0; r < 10; ++r) {
+            CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; if (ms < best) best = ms;
+        }
+        printf("%-34s mean %.3f ms  %.0f GB/s   best %.0f GB/s\n", name, tot / 10, gbytes / (tot / 10) * 1e3, gbytes / best * 1e3);
+    };
+    const double G = bytes / 1e9;
+    for (int g : {256 * 2, 256 * 4, 256 * 8, 256 * 16}) {
+        char nm[64];
+        snprintf(nm, 64, "read stride u1 grid %d", g); time([&] { hipLaunchKernelGGL(k_read<1>, dim3(g), dim3(256), 0, 0, a, n2, out); }, nm, G);
+        snprintf(nm, 64, "read stride u4 grid %d", g); time([&] { hipLaunchKernelGGL(k_read<4>, dim3(g), dim3(256), 0, 0, a, n2, out); }, nm, G);
+        snprintf(nm, 64, "read stride u8 grid %d", g); time([&] { hipLaunchKernelGGL(k_read<8>, dim3(g), dim3(256), 0, 0, a, n2, out); }, nm, G);
+        snprintf(nm, 64, "read chunk  u4 grid %d", g); time([&] { hipLaunchKernelGGL(k_read_chunk<4>, dim3(g), dim3(256), 0, 0, a, n2, out); }, nm, G);
+    }
+    time([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, a, b, n2); }, "copy grid 2048 (r+w bytes)", 2 * G);
+    time([&] { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, a, b, n2); }, "copy grid 8192 (r+w bytes)", 2 * G);
+    time([&] { hipLaunchKernelGGL(k_update_like, dim3(2048), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 2048", 5 * G);
+    time([&] { hipLaunchKernelGGL(k_update_like, dim3(8192), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 8192", 5 * G);
+    return 0;
+}
