@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-    double* __restrict__ ep_st, double* __restrict__ partials)
+    double* __restrict__ ep_st, double* __restrict__ partials, int chunked)
 {
     using V = typename VecT<NV>::type;
     constexpr int kSlots = 256 * STEPS;
@@ -258,39 +258,52 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
 
     double acc[3] = {0.0, 0.0, 0.0};
 
+    // Tile order.  chunked (default): wave `slot` owns the contiguous tile range
+    // [slot*T, (slot+1)*T) -- every wave streams val/col sequentially through its own DRAM
+    // pages (the access pattern that keeps 6 TB/s at any queue depth in tools/membench).
+    // strided: wave `slot` takes tiles slot, slot+W, ... (the whole chip sweeps one front).
     const int nblk = gridDim.x;
     const int W = nblk * kWaves;
-    int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+    const int slot = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+    int t, tend, step;
+    if (chunked) {
+        const int T = (ntiles + W - 1) / W;
+        t = slot * T;
+        tend = t + T < ntiles ? t + T : ntiles;
+        step = 1;
+    } else {
+        t = slot; tend = ntiles; step = W;
+    }
 
     MatRegs<STEPS, LS> m0, m1;
     TileDesc d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-    if (t < ntiles) {
+    if (t < tend) {
         d0 = read_desc(T4, t);
         if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
-        if (t + W < ntiles) d1 = read_desc(T4, t + W);
+        if (t + step < tend) d1 = read_desc(T4, t + step);
     }
 
-    while (t < ntiles) {
+    while (t < tend) {
         // ---- even phase: tile t lives in m0 / d0 ----
         {
-            const bool has_next = t + W < ntiles;
-            const int t2 = t + 2 * W;
-            const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
+            const bool has_next = t + step < tend;
+            const int t2 = t + 2 * step;
+            const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
             if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d1, lane, m1);
             process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
             d0 = d2;
-            t += W;
+            t += step;
         }
-        if (t >= ntiles) break;
+        if (t >= tend) break;
         // ---- odd phase: tile t lives in m1 / d1 ----
         {
-            const bool has_next = t + W < ntiles;
-            const int t2 = t + 2 * W;
-            const TileDesc d2 = read_desc(T4, t2 < ntiles ? t2 : t);
+            const bool has_next = t + step < tend;
+            const int t2 = t + 2 * step;
+            const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
             if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
             process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
             d1 = d2;
-            t += W;
+            t += step;
         }
     }
 
@@ -633,8 +646,10 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 {
     auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
+    static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=stride
+    if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 's') ? 0 : 1; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
-                       partials);
+                       partials, chunked);
     return PRCG_LAUNCH_OK() ? grid : -1;
 }
 
