@@ -258,10 +258,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
 
     double acc[3] = {0.0, 0.0, 0.0};
 
-    // Tile order.  chunked (default): wave `slot` owns the contiguous tile range
-    // [slot*T, (slot+1)*T) -- every wave streams val/col sequentially through its own DRAM
-    // pages (the access pattern that keeps 6 TB/s at any queue depth in tools/membench).
-    // strided: wave `slot` takes tiles slot, slot+W, ... (the whole chip sweeps one front).
+    // Tile order.  strided (default): wave `slot` takes tiles slot, slot+W, ... so the whole
+    // chip sweeps the matrix as one front (stencil neighbours are fetched while their
+    // lines are still in L2 / Infinity Cache).  chunked: wave `slot` owns the contiguous
+    // tile range [slot*T, (slot+1)*T) -- measured slower on S3 (profiles/r01_sweeps.md).
     const int nblk = gridDim.x;
     const int W = nblk * kWaves;
     const int slot = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
@@ -633,10 +633,11 @@ int tile_grid(K kernel, int ntiles) {
 // ---- launch wrappers -------------------------------------------------------------------
 #define PRCG_LAUNCH_OK() (hipGetLastError() == hipSuccess)
 
-// experiment knob: PRCG_LANE_STRIDED=0 selects the 4-consecutive-nonzeros-per-lane layout
+// experiment knob: PRCG_LANE_STRIDED=1 selects the lane-strided layout (measured equal or
+// slightly slower than 4 consecutive nonzeros per lane with 16-byte loads)
 bool lane_strided() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("PRCG_LANE_STRIDED"); v = e ? (atoi(e) != 0) : 1; }
+    if (v < 0) { const char* e = getenv("PRCG_LANE_STRIDED"); v = e ? (atoi(e) != 0) : 0; }
     return v != 0;
 }
 
@@ -646,8 +647,8 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 {
     auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
-    static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=stride
-    if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 's') ? 0 : 1; }
+    static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
+    if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
                        partials, chunked);
     return PRCG_LAUNCH_OK() ? grid : -1;
