@@ -88,6 +88,8 @@ struct prcg_handle {
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
     DevBuf t1;                           // 2*n doubles: SpMV output scratch
     DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues
+    DevBuf ticket;                       // arrival counter of the fused final reduction
+    bool fused_final = true;             // PRCG_FUSED_FINAL=0: separate k_reduce_final launch
 
     // ---- halo plan ----
     int n_peers = 0;
@@ -275,8 +277,8 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     bool on = false;
     int rc;
     if (!h->side_stream && !h->multi()) {
-        // everything in order on one stream (PRCG_SIDE_STREAM=0; A/B knob)
-        launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
+        // everything in order on one stream
+        if (!h->fused_final) launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
         LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
@@ -289,7 +291,7 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
         if ((rc = exchange(h, in_ext, 2, h->sm))) return rc;
         HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
     }
-    launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
+    if (!h->fused_final) launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
     if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
 
@@ -346,6 +348,8 @@ PipeUpdateArgs pipe_args(prcg_t* h, int k) {
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.coef_out = coef_at(h, k);
     a.partials = h->partA.d();
+    a.final_out = h->fused_final ? dots_at(h, k) : nullptr;
+    a.ticket = static_cast<unsigned*>(h->ticket.p);
     a.meurant = meurant(h->variant);
     a.recompute_w = pipe_recompute(h->variant);
     return a;
@@ -497,6 +501,7 @@ int prcg_create(prcg_t** out, int device_id) {
     if (!h) return fail(nullptr, PRCG_ENOMEM, "out of host memory");
     h->dev = device_id;
     if (const char* e = getenv("PRCG_SIDE_STREAM")) h->side_stream = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_FUSED_FINAL")) h->fused_final = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -614,6 +619,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     HIPCHK(h, h->t1.alloc((size_t)2 * n_rows * sizeof(double)));
     HIPCHK(h, h->partA.alloc((size_t)8192 * kPartialStride * sizeof(double)));
     HIPCHK(h, h->partB.alloc((size_t)8192 * kPartialStride * sizeof(double)));
+    HIPCHK(h, h->ticket.alloc(64));
     h->have_csr = true;
     h->have_halo = false;
     return PRCG_OK;
@@ -777,7 +783,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         PipeUpdateArgs a = pipe_args(h, 0);
         const int grid = launch_pipe_dots(sc, a);                           // nu, mu, delta, gamma
         LAUNCHCHK(h, grid);
-        launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
+        if (!h->fused_final) launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
         if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
     } else {
         // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)

@@ -58,6 +58,8 @@ struct PipeUpdateArgs {
     const double* dots_prev;   // kNumScalars doubles: mu, dl, gm, nu of iteration k-1
     double* coef_out;          // alpha, beta, nu_pred of this iteration
     double* partials;          // [grid][kPartialStride]
+    double* final_out;         // non-null: the last block reduces the partials into final_out[0..5)
+    unsigned* ticket;          // arrival counter of that hand-off (zero between launches)
     int meurant;      // nu prediction flavour
     int recompute_w;  // 'pr' flavours: w is overwritten by the following SpMM
 };

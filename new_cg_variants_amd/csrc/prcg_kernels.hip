@@ -80,6 +80,71 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NQ], double* pa
     }
 }
 
+// Same, plus: the block that finishes LAST sums all block partials in a fixed order and
+// writes the final values -- no separate reduction launch.  Which block is last varies
+// from run to run, the order of the summation does not, so the result is reproducible.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, counter form): every block
+// publishes its partials with plain stores -> s_waitcnt vmcnt(0) -> barrier -> one lane:
+// agent-scope release fence, wait, relaxed agent-scope ticket; the block that draws the
+// last ticket: agent-scope acquire fence, wait, barrier, plain loads.  Nobody spins.
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], double* partials, unsigned* ticket,
+                                                         double* __restrict__ final_out) {
+    __shared__ double red[kWaves][NQ];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (tk == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last block: thread t sums partials t, t+256, ...; butterfly; waves in order ----
+    double tot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+    const int nparts = gridDim.x;
+    for (int j = threadIdx.x; j < nparts; j += kBlock) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tot[q] += partials[(size_t)j * kPartialStride + q];
+    }
+    __syncthreads();   // red[] is reused
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(tot[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        final_out[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch (kernel boundary orders it)
+}
+
 // ======================================================================================
 // CSR-adaptive SpMV / two-vector SpMM.
 // One wavefront per tile, persistent grid: wave `slot` handles tiles slot, slot+W, ...
@@ -420,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
         }
     }
     if constexpr (!PREC) acc[4] = acc[3];
-    block_reduce_store<5>(acc, a.partials, 0);
+    if (a.final_out) block_reduce_store_final<5>(acc, a.partials, a.ticket, a.final_out);
+    else block_reduce_store<5>(acc, a.partials, 0);
 }
 
 // ---- Hestenes-Stiefel (hs_cg.py:54-61, hs_pcg :116-124) ------------------------------
@@ -510,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_pr_update(PrArgs a, int trips) {
 }
 
 // ---- fixed-order final reduction of per-block partials --------------------------------
-constexpr int kFinalThreads = 1024;
+constexpr int kFinalThreads = 256;   // same tree as the fused last-block reduction
 __global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
     const double* __restrict__ partials, int nparts, double* __restrict__ out,
     int src_first, int dst_first, int count)

@@ -5,7 +5,8 @@ block_reduce_store, k_reduce_final) sum a product array in a fixed order:
 
   thread (block b, lane t): elements (b*trips + j)*512 + t, then + 256 + t, for j = 0..trips-1
   wave   : xor butterfly 32,16,8,4,2,1          block : waves 0..3 in order
-  final  : 1024 threads, thread t sums partials t, t+1024, ...; butterfly; 16 waves in order
+  final  : the last block (256 threads): thread t sums partials t, t+256, ...; butterfly;
+           4 waves in order   (block_reduce_store_final)
 
 Plugging ``device_dot`` into the oracle (``dot=``) makes the oracle's free-running
 trajectory comparable with the device's bit for bit.
@@ -14,7 +15,7 @@ import numpy as np
 
 ELEMS_PER_TRIP = 512
 MAX_GRID = 2048
-FINAL_THREADS = 1024
+FINAL_THREADS = 256
 
 
 def chunking(n):
@@ -58,10 +59,11 @@ def device_sum(prod):
     t = np.zeros(FINAL_THREADS)
     for j in range(rounds):
         t = t + pp[j]
-    w16 = _butterfly(t.reshape(16, 64))
-    out = w16[0]
-    for w in range(1, 16):
-        out = out + w16[w]
+    nw = FINAL_THREADS // 64
+    wf = _butterfly(t.reshape(nw, 64))
+    out = wf[0]
+    for w in range(1, nw):
+        out = out + wf[w]
     return float(out)
 
 
