@@ -118,11 +118,10 @@ def main():
 
     if world == 1 and args.force_comm:
         from new_cg_variants_amd.device import DeviceCSR
-        uid = np.zeros(128, dtype=np.uint8)
+        uid = np.zeros((2, 128), dtype=np.uint8)
         path = L.default_rccl_path()
-        from new_cg_variants_amd.device import _stdout_to_stderr
-        with _stdout_to_stderr():
-            L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+        for i in range(2):
+            L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid[i])))
         dev = DeviceCSR(A_rows.tocsr(), device=local_rank, comm_init=(0, 1, uid.tobytes(), path))
     else:
         op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)

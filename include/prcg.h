@@ -103,10 +103,13 @@ int  prcg_version(void);
 /* ---- multi-GPU: one RCCL communicator per handle --------------------------------
  * replaces comm = MPI.COMM_WORLD (scaling_tests.py:21) for the data path.
  * rccl_path: path of the librccl.so to dlopen (NULL -> "librccl.so.1").  Rank 0
- * calls prcg_comm_unique_id and ships the 128 bytes to the other ranks by any
- * means (torch.distributed in bench.py); then every rank calls prcg_comm_init. */
+ * calls prcg_comm_unique_id (once per id) and ships the 128-byte ids to the other
+ * ranks by any means (torch.distributed in bench.py); then every rank calls
+ * prcg_comm_init with n_ids = 1 or 2 consecutive ids.  With 2 ids the halo exchange
+ * gets a communicator and a stream of its own, so the neighbour exchange and the
+ * all-reduce of one iteration run side by side instead of one after the other. */
 int prcg_comm_unique_id(const char* rccl_path, void* id128);
-int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* id128);
+int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* ids, int n_ids);
 
 /* ---- operator -------------------------------------------------------------------
  * The rank's row block in CSR (what `A` is in figure_gen.py:350 / scaling_tests.py:51),

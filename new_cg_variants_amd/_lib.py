@@ -50,7 +50,7 @@ _SIGNATURES = {
     'prcg_destroy': (None, [_P]),
     'prcg_last_error': (C.c_char_p, [_P]),
     'prcg_comm_unique_id': (C.c_int, [C.c_char_p, _P]),
-    'prcg_comm_init': (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, _P]),
+    'prcg_comm_init': (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, _P, C.c_int]),
     'prcg_set_csr': (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     'prcg_set_halo': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     'prcg_spmv': (C.c_int, [_P, _P, _P, C.c_int, _dp]),

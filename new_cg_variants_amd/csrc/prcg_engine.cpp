@@ -69,12 +69,14 @@ struct prcg_handle {
     int dev = 0;
     std::string err;
     hipStream_t sc = nullptr;   // compute
-    hipStream_t sm = nullptr;   // communication / reductions
+    hipStream_t sm = nullptr;   // reductions + all-reduce
+    hipStream_t sh = nullptr;   // halo exchange (own stream + own communicator: runs beside the all-reduce)
     hipEvent_t e_upd = nullptr, e_halo = nullptr, e_red = nullptr;
 
     // ---- communicator ----
     Rccl* rccl = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;    // all-reduce (and, if comm_halo is null, the halo too)
+    ncclComm_t comm_halo = nullptr;
     int rank = 0, nranks = 1;
 
     // ---- operator ----
@@ -89,7 +91,9 @@ struct prcg_handle {
     DevBuf t1;                           // 2*n doubles: SpMV output scratch
     DevBuf partA, partB;                 // block partials: update kernels / SpMV epilogues
     DevBuf ticket;                       // arrival counter of the fused final reduction
-    bool fused_final = true;             // PRCG_FUSED_FINAL=0: separate k_reduce_final launch
+    bool fused_final = false;            // PRCG_FUSED_FINAL=1: last block of the update kernel reduces the
+                                         // partials (correct, but its per-block release fence writes back every
+                                         // XCD L2: update 140 -> 250 us at S3; kept as an experiment)
 
     // ---- halo plan ----
     int n_peers = 0;
@@ -177,6 +181,9 @@ bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == P
 int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
     if (!h->multi() || h->g == 0) return PRCG_OK;
     CHECK(h, h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
+    // the halo communicator may only be used on its own stream (operations of one
+    // communicator must be enqueued in one order)
+    ncclComm_t cm = (h->comm_halo && st == h->sh) ? h->comm_halo : h->comm;
     const int64_t nsend = h->send_ptr[h->n_peers];
     launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);
     NCCLCHK(h, h->rccl->GroupStart());
@@ -185,10 +192,10 @@ int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
         const int64_t nr = h->recv_ptr[q + 1] - h->recv_ptr[q];
         if (ns > 0)
             NCCLCHK(h, h->rccl->Send(h->send_buf.d() + h->send_ptr[q] * nc, (size_t)(ns * nc), ncclDouble,
-                                     h->peer_rank[q], h->comm, st));
+                                     h->peer_rank[q], cm, st));
         if (nr > 0)
             NCCLCHK(h, h->rccl->Recv(vec_ext + (h->n + h->recv_ptr[q]) * nc, (size_t)(nr * nc), ncclDouble,
-                                     h->peer_rank[q], h->comm, st));
+                                     h->peer_rank[q], cm, st));
     }
     NCCLCHK(h, h->rccl->GroupEnd());
     return PRCG_OK;
@@ -286,11 +293,14 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     }
     const bool halo = h->multi() && h->g > 0;
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
-    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
     if (halo) {
-        if ((rc = exchange(h, in_ext, 2, h->sm))) return rc;
-        HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+        // chain 1 (halo stream, halo communicator): pack -> grouped send/recv
+        HIPCHK(h, hipStreamWaitEvent(h->sh, h->e_upd, 0));
+        if ((rc = exchange(h, in_ext, 2, h->sh))) return rc;
+        HIPCHK(h, hipEventRecord(h->e_halo, h->sh));
     }
+    // chain 2 (reduction stream): block partials -> 5 doubles -> the one all-reduce
+    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
     if (!h->fused_final) launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
     if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
@@ -321,10 +331,10 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
         return PRCG_OK;
     }
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
-    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
-    int rc = exchange(h, x_ext, 1, h->sm);
+    HIPCHK(h, hipStreamWaitEvent(h->sh, h->e_upd, 0));
+    int rc = exchange(h, x_ext, 1, h->sh);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->e_halo, h->sm));
+    HIPCHK(h, hipEventRecord(h->e_halo, h->sh));
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d());
@@ -508,6 +518,7 @@ int prcg_create(prcg_t** out, int device_id) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&h->sc, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&h->sm, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->sh, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_red, hipEventDisableTiming) != hipSuccess) {
@@ -522,6 +533,7 @@ void prcg_destroy(prcg_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     (void)hipDeviceSynchronize();
+    if (h->comm_halo && h->rccl) (void)h->rccl->CommDestroy(h->comm_halo);
     if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
     destroy_events(h->ev_spmv);
     destroy_events(h->ev_upd);
@@ -530,6 +542,7 @@ void prcg_destroy(prcg_t* h) {
     if (h->e_red) (void)hipEventDestroy(h->e_red);
     if (h->sc) (void)hipStreamDestroy(h->sc);
     if (h->sm) (void)hipStreamDestroy(h->sm);
+    if (h->sh) (void)hipStreamDestroy(h->sh);
     delete h;
 }
 
@@ -546,10 +559,11 @@ int prcg_comm_unique_id(const char* rccl_path, void* id128) {
     return PRCG_OK;
 }
 
-int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* id128) {
+int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* id128, int n_ids) {
     if (!h) return PRCG_EINVAL;
     CHECK(h, nranks >= 1 && rank >= 0 && rank < nranks, "prcg_comm_init: bad rank %d of %d", rank, nranks);
     CHECK(h, id128 != nullptr, "prcg_comm_init: null unique id");
+    CHECK(h, n_ids == 1 || n_ids == 2, "prcg_comm_init: n_ids must be 1 or 2");
     CHECK(h, h->comm == nullptr, "prcg_comm_init: communicator already initialised");
     std::string err;
     h->rccl = Rccl::get(rccl_path, err);
@@ -558,6 +572,10 @@ int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     NCCLCHK(h, h->rccl->CommInitRank(&h->comm, nranks, id, rank));
+    if (n_ids == 2) {
+        memcpy(&id, static_cast<const char*>(id128) + sizeof id, sizeof id);
+        NCCLCHK(h, h->rccl->CommInitRank(&h->comm_halo, nranks, id, rank));
+    }
     h->rank = rank;
     h->nranks = nranks;
     return PRCG_OK;
@@ -850,6 +868,7 @@ int prcg_iterate(prcg_t* h, int iters) {
 int prcg_sync(prcg_t* h) {
     if (!h) return PRCG_EINVAL;
     HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipStreamSynchronize(h->sh));
     HIPCHK(h, hipStreamSynchronize(h->sm));
     HIPCHK(h, hipStreamSynchronize(h->sc));
     return PRCG_OK;

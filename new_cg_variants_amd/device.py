@@ -47,10 +47,12 @@ class DeviceCSR:
             raise L.PrcgError(rc, msg.decode() if msg else '?')
         self.rank, self.nranks = 0, 1
         if comm_init is not None:
-            rank, nranks, uid, path = comm_init
+            rank, nranks, uid, path = comm_init      # uid: 128 or 256 bytes (one or two RCCL ids)
+            ids = np.frombuffer(uid, dtype=np.uint8).copy()
+            assert ids.size in (128, 256)
             with _stdout_to_stderr():
                 self._check(self._lib.prcg_comm_init(self._h, path.encode() if path else None, rank, nranks,
-                                                     L.ptr(np.frombuffer(uid, dtype=np.uint8).copy())))
+                                                     L.ptr(ids), ids.size // 128))
             self.rank, self.nranks = rank, nranks
         self._set_matrix(A, halo)
 

@@ -100,10 +100,12 @@ class RowBlockOperator:
             lib = L.lib()
             uid = None
             if rank == 0:
-                buf = np.zeros(128, dtype=np.uint8)
+                # two ids: all-reduce communicator + halo communicator (they run side by side)
+                buf = np.zeros((2, 128), dtype=np.uint8)
                 from ..device import _stdout_to_stderr
                 with _stdout_to_stderr():
-                    L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf)))
+                    for i in range(2):
+                        L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf[i])))
                 uid = buf.tobytes()
             uid = comm.bcast_obj(uid, root=0)
             comm_init = (rank, size, uid, path)

@@ -20,6 +20,16 @@ import pytest
 from conftest import ROOT
 
 
+def rccl_ids(n_ids):
+    """n_ids fresh RCCL unique ids as one bytes object (rank-0 side of the bootstrap)."""
+    from new_cg_variants_amd import _lib as L
+    path = L.default_rccl_path()
+    buf = np.zeros((n_ids, 128), dtype=np.uint8)
+    for i in range(n_ids):
+        L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(buf[i])))
+    return buf.tobytes(), path
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -83,11 +93,9 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
     from new_cg_variants_amd.device import DeviceCSR
     A, z = matrices['nos7']
     n = A.shape[0]
-    path = L.default_rccl_path()
-    uid = np.zeros(128, dtype=np.uint8)
-    L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+    uid, path = rccl_ids(1)
     plain = DeviceCSR(A)
-    comm = DeviceCSR(A, comm_init=(0, 1, uid.tobytes(), path))
+    comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
     for variant in (L.PIPE_PR, L.HS, L.PR):
         outs = []
         for op in (plain, comm):
@@ -126,8 +134,8 @@ def loopback_problem(A, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workload,k', [('s1_small', 70), ('s3_small', 9)])
-def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k):
+@pytest.mark.parametrize('workload,k,n_ids', [('s1_small', 70, 2), ('s3_small', 9, 2), ('s3_small', 9, 1)])
+def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids):
     """pack kernel -> ncclSend/ncclRecv (to self) -> ghost slots -> interior/boundary tile
     split -> event choreography, all on one GPU.  Must be bit-identical to the plain path."""
     from new_cg_variants_amd import _lib as L
@@ -138,11 +146,9 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k):
     A_loop, halo, moved = loopback_problem(A, k)
     assert moved > 0
     b, x0, x_true = problems.reference_rhs(A, n)
-    path = L.default_rccl_path()
-    uid = np.zeros(128, dtype=np.uint8)
-    L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+    uid, path = rccl_ids(n_ids)      # 2 ids: halo exchange on its own communicator + stream
     plain = DeviceCSR(A)
-    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid.tobytes(), path), halo=halo)
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo)
     x = np.random.default_rng(2).standard_normal(n)
     y0, _ = plain.matvec(x)
     y1, _ = loop.matvec(x)
