@@ -151,6 +151,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     dev.iterate(K)
+    t_enq = time.perf_counter() - t0      # host time to enqueue K iterations (no sync inside)
     dev.sync()
     torch.cuda.synchronize()
     comm.Barrier()
@@ -186,7 +187,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
                        'partition': f'row blocks x{world}', 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
-                       'residual_finite': finite},
+                       'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': kname,
                          'algorithmic_bytes_per_launch': kbytes, 'avg_launch_ms': tim['spmv_ms'],
