@@ -95,6 +95,8 @@ def main():
         args.gpus = world
 
     import torch                                   # first: its HIP runtime is the process's runtime
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)          # torch.cuda.synchronize() below must mean THIS rank's GPU
     from new_cg_variants_amd import _lib as L
     from new_cg_variants_amd import partition, problems, scaling
 

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libprcg.so')
+LIB_PATH = os.environ.get('PRCG_LIB') or os.path.join(_HERE, 'libprcg.so')   # PRCG_LIB: A/B builds
 
 # constants of include/prcg.h
 OK, EINVAL, EHIP, ERCCL, ENOMEM = 0, 1, 2, 3, 4

@@ -237,9 +237,21 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
         } else {
             const int base = alo + st * 256 + lane * 4;
             const int lb = base < d.hi ? base : alo;
+#ifdef PRCG_NT_STREAM
+            // the matrix is read exactly once per product: keep it from displacing x in L2
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+            const v4i_t c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(A.col + lb));
+            const v2d_t a2 = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(A.val + lb));
+            const v2d_t b2 = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(A.val + lb + 2));
+            m.cc[st] = make_int4(c4.x, c4.y, c4.z, c4.w);
+            m.va[st] = make_double2(a2.x, a2.y);
+            m.vb[st] = make_double2(b2.x, b2.y);
+#else
             m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
             m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
             m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+#endif
         }
     }
 }
