@@ -110,7 +110,10 @@ struct prcg_handle {
     int k = 0;
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
-    DevBuf x, xp, p, rs, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf x, xp, p, rs, rs2, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
+    bool want_fused = true;      // PRCG_FUSED=0 turns it off
+    double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
     DevBuf dots, coef;
 
     // ---- profiling ----
@@ -365,8 +368,28 @@ PipeUpdateArgs pipe_args(prcg_t* h, int k) {
     return a;
 }
 
+// One launch per iteration (single GPU, unpreconditioned 'pr' flavours): state k-1 =
+// {XP, RS in rs_cur, dots[k-1]}; the kernel recomputes (w,u) = A [r s] row by row and
+// applies update k to the row at once.  The reduction of the inner products is NOT
+// overlapped with anything here (it is needed at the head of the next launch) -- which is
+// why ranks with a communicator keep the two-kernel schedule below.
+int iterate_pipe_fused(prcg_t* h, int k) {
+    double* rs_old = h->rs_cur;
+    double* rs_new = (h->rs_cur == h->rs.d()) ? h->rs2.d() : h->rs.d();
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int grid = launch_pipe_fused(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, rs_old, rs_new,
+                                       h->xp.d(), dots_at(h, k - 1), coef_at(h, k), h->partB.d(), meurant(h->variant));
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    launch_reduce_final(h->sc, h->partB.d(), grid, dots_at(h, k), 0, 0, 5);
+    h->rs_cur = rs_new;
+    return PRCG_OK;
+}
+
 int iterate_pipe(prcg_t* h, int k) {
     // pipe_pr_cg.py:61-75 / :169-187
+    if (h->fused) return iterate_pipe_fused(h, k);
     PipeUpdateArgs a = pipe_args(h, k);
     bool on = false;
     prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
@@ -460,10 +483,10 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         switch (which) {
         case PRCG_VEC_X: *base = h->xp.d(); *stride = 2; return true;
         case PRCG_VEC_P: *base = h->xp.d() + 1; *stride = 2; return true;
-        case PRCG_VEC_R: *base = h->rs.d(); *stride = 2; return true;
-        case PRCG_VEC_S: *base = h->rs.d() + 1; *stride = 2; return true;
-        case PRCG_VEC_W: *base = h->wu.d(); *stride = 2; return true;
-        case PRCG_VEC_U: *base = h->wu.d() + 1; *stride = 2; return true;
+        case PRCG_VEC_R: *base = (h->fused ? h->rs_cur : h->rs.d()); *stride = 2; return true;
+        case PRCG_VEC_S: *base = (h->fused ? h->rs_cur : h->rs.d()) + 1; *stride = 2; return true;
+        case PRCG_VEC_W: if (h->fused) return false; *base = h->wu.d(); *stride = 2; return true;
+        case PRCG_VEC_U: if (h->fused) return false; *base = h->wu.d() + 1; *stride = 2; return true;
         case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rst.d(); *stride = 2; return true;
         case PRCG_VEC_ST: if (!h->prec) return false; *base = h->rst.d() + 1; *stride = 2; return true;
         case PRCG_VEC_WT: if (!h->prec || pipe_recompute(v)) return false; *base = h->wt.d(); return true;
@@ -512,6 +535,7 @@ int prcg_create(prcg_t** out, int device_id) {
     h->dev = device_id;
     if (const char* e = getenv("PRCG_SIDE_STREAM")) h->side_stream = atoi(e) != 0;
     if (const char* e = getenv("PRCG_FUSED_FINAL")) h->fused_final = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_FUSED")) h->want_fused = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -737,6 +761,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     const size_t D = sizeof(double);
     h->in_session = false;
     h->variant = variant;
+    h->fused = false;
     h->prec = inv_diag != nullptr;
     h->max_iter = max_iter;
     h->hist_mask = hist_mask;
@@ -765,8 +790,11 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
 
     if (is_pipe(variant)) {
+        h->fused = h->want_fused && !h->multi() && !h->prec && pipe_recompute(variant) && h->g == 0;
         HIPCHK(h, h->xp.alloc((size_t)2 * n * D));
         HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
+        HIPCHK(h, h->rs2.alloc(h->fused ? (size_t)2 * ne * D : 16));
+        h->rs_cur = h->rs.d();
         HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
         HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
         HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
@@ -892,6 +920,13 @@ int prcg_get_vector(prcg_t* h, int which, double* out) {
     const int64_t n = h->n;
     double* base; int stride;
     if (!locate(h, which, &base, &stride)) {
+        // fused schedule: w = A r and u = A s are never stored -- recompute on request
+        if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U)) {
+            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, h->rs_cur,
+                                      h->wu.d(), 3));
+            launch_copy(h->sc, h->t1.d(), 1, h->wu.d() + (which == PRCG_VEC_U ? 1 : 0), 2, n);
+            return d2h(h, out, h->t1.d(), n);
+        }
         // derived tilde vectors of the Jacobi 'pr' flavours: w~ = M^-1 w, u~ = M^-1 u
         if (is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT)) {
             launch_mul(h->sc, h->t1.d(), 1, h->dinv.d(), 1, h->wu.d() + (which == PRCG_VEC_UT ? 1 : 0), 2, n);
@@ -912,6 +947,7 @@ int prcg_set_vector(prcg_t* h, int which, const double* in) {
     const int64_t n = h->n;
     double* base; int stride;
     if (!locate(h, which, &base, &stride)) {
+        if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U)) return PRCG_OK;                          // derived
         if (is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT)) return PRCG_OK;  // derived
         return fail(h, PRCG_EINVAL, "prcg_set_vector: vector %d is not part of variant %d", which, h->variant);
     }

@@ -26,6 +26,7 @@ enum SpmvEpilogue {
     kEpiNone = 0,
     kEpiDotXY = 1,   // partial[0] += x_i * y_i                       (HS: mu = p.s; e'Ae)
     kEpiPR = 2,      // st = d*y (or y); partials mu=p.s, dl=r.st, gm=st.s   (pr_pcg)
+    kEpiPipeFused = 3,   // two-vector only: the next pipelined vector update, fused row by row
 };
 
 struct CsrDev {
@@ -45,6 +46,14 @@ int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, 
 // [w u] = A [r s] on interleaved pairs.  write_mask: 1 = first, 2 = second, 3 = both.
 int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                  const double* rs, double* wu, int write_mask);
+
+// One launch per iteration of pipe_pr_cg / pipe_pr_m_cg on ONE GPU: [w u] = A [r s] with the
+// vector update of the following iteration applied to each row as soon as its (w_i,u_i)
+// exist.  w,u never reach memory; (r,s) are double-buffered (gathered from rs_old, written
+// to rs_new); the 4 inner products ride along (partials[grid][0..4]).  Returns the grid.
+int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
+                      const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
+                      double* coef_out, double* partials, int meurant);
 
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {

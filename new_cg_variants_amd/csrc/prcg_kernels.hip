@@ -156,12 +156,27 @@ __device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], doub
 //   reduce phase : lane i sums row i of the tile sequentially from LDS and stores it.
 // A row longer than a tile is summed by the whole wave (partial sums + butterfly).
 // ======================================================================================
+struct Coefs { double al, bt, nup; };
+
+__device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {
+    // a_k1 = nu/mu; nu_k = nu - 2 a dl + a^2 gm (or Meurant's -nu + a^2 gm); b_k = nu_k/nu
+    // (numerical_experiments/cg_variants/pipe_pr_cg.py:64-66,75; Python evaluates
+    //  ((nu - (2a)dl) + (a^2)gm) left to right)
+    const double mu = dp[0], dl = dp[1], gm = dp[2], nu = dp[3];
+    Coefs c;
+    c.al = nu / mu;
+    const double a2 = c.al * c.al;
+    c.nup = meurant ? (-nu + a2 * gm) : ((nu - (2 * c.al) * dl) + a2 * gm);
+    c.bt = c.nup / nu;
+    return c;
+}
+
 // per-row epilogue: store y (and the fused extras)
 template <int NV, int EPI>
 __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
                                            int write_mask, const typename VecT<NV>::type* __restrict__ X,
                                            const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-                                           double* __restrict__ ep_st, double (&acc)[3])
+                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
 {
     if constexpr (NV == 1) {
         double* Y = reinterpret_cast<double*>(yout_);
@@ -172,6 +187,22 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
             if (ep_st) ep_st[row] = stv;
             acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
         }
+    } else if constexpr (EPI == kEpiPipeFused) {
+        // The NEXT iteration's vector update, row by row, while (w_i,u_i) = sum is still in
+        // registers (pipe_pr_cg.py:61-74): w and u never touch memory.  r,s are read from
+        // the OLD pair array X (other rows still gather from it) and written to the NEW one.
+        double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
+        double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
+        const double2 xp = XP[row];
+        const double2 rs = X[row];
+        const double xn = xp.x + cf.al * xp.y;               // x += a p
+        const double rn = rs.x - cf.al * rs.y;               // r -= a s
+        const double wn = sum.x - cf.al * sum.y;             // w -= a u      (w = A r, u = A s: just computed)
+        const double pn = rn + cf.bt * xp.y;                 // p = r + b p
+        const double sn = wn + cf.bt * rs.y;                 // s = w + b s
+        XP[row] = make_double2(xn, pn);
+        RSN[row] = make_double2(rn, sn);
+        acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
     } else {
         if (write_mask == 3) {
             reinterpret_cast<double2*>(yout_)[row] = sum;
@@ -263,7 +294,7 @@ __device__ __forceinline__ void process_tile(
     const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS>& cur,
     typename VecT<NV>::type* my, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
-    const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[3])
+    const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
 {
     using V = typename VecT<NV>::type;
     constexpr int kCap = 256 * STEPS - 3;
@@ -273,7 +304,7 @@ __device__ __forceinline__ void process_tile(
         V sum; vzero(sum);
         for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
         sum = vwave_sum(sum);
-        if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+        if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
         return;
     }
     const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
@@ -301,12 +332,12 @@ __device__ __forceinline__ void process_tile(
         }
     }
     wave_lds_sync();
-    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
-    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
     for (int row = rb + 128 + lane; row < re; row += 64) {
         const int s = A.indptr[row] - alo;
         const int e = A.indptr[row + 1] - alo;
-        finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc);
+        finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
     }
     wave_lds_sync();
 }
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-    double* __restrict__ ep_st, double* __restrict__ partials, int chunked)
+    double* __restrict__ ep_st, double* __restrict__ partials, int chunked, double* __restrict__ aux)
 {
     using V = typename VecT<NV>::type;
     constexpr int kSlots = 256 * STEPS;
@@ -333,7 +364,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     V* my = prod[wv];
 
-    double acc[3] = {0.0, 0.0, 0.0};
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    Coefs cf = {0.0, 0.0, 0.0};
+    if constexpr (EPI == kEpiPipeFused) {
+        // ep_r = the reduced inner products of the previous iteration; bit 2 of write_mask =
+        // Meurant's prediction; aux = where alpha, beta, nu_pred of this iteration are kept
+        cf = predict(ep_r, (write_mask >> 2) & 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+    }
 
     // Tile order.  strided (default): wave `slot` takes tiles slot, slot+W, ... so the whole
     // chip sweeps the matrix as one front (stencil neighbours are fetched while their
@@ -367,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const int t2 = t + 2 * step;
             const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
             if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d1, lane, m1);
-            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d0 = d2;
             t += step;
         }
@@ -378,34 +416,23 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const int t2 = t + 2 * step;
             const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
             if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
-            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc);
+            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d1 = d2;
             t += step;
         }
     }
 
-    if constexpr (EPI != kEpiNone) block_reduce_store<3>(acc, partials, 0);
+    if constexpr (EPI == kEpiPipeFused) { acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+    else if constexpr (EPI != kEpiNone) {
+        double a3[3] = {acc[0], acc[1], acc[2]};
+        block_reduce_store<3>(a3, partials, 0);
+    }
 }
 
 // ======================================================================================
 // Fused vector updates + inner products.  Block b owns `trips` consecutive 512-element
 // trips; thread t handles elements 2t, 2t+1 of each trip with 16-byte accesses.
 // ======================================================================================
-struct Coefs { double al, bt, nup; };
-
-__device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {
-    // a_k1 = nu/mu; nu_k = nu - 2 a dl + a^2 gm (or Meurant's -nu + a^2 gm); b_k = nu_k/nu
-    // (numerical_experiments/cg_variants/pipe_pr_cg.py:64-66,75; Python evaluates
-    //  ((nu - (2a)dl) + (a^2)gm) left to right)
-    const double mu = dp[0], dl = dp[1], gm = dp[2], nu = dp[3];
-    Coefs c;
-    c.al = nu / mu;
-    const double a2 = c.al * c.al;
-    c.nup = meurant ? (-nu + a2 * gm) : ((nu - (2 * c.al) * dl) + a2 * gm);
-    c.bt = c.nup / nu;
-    return c;
-}
-
 // All state of the pipelined variants is stored as 16-byte pairs -- XP = (x,p), RS = (r,s),
 // WU = (w,u), RSt = (r~,s~) -- so that every global access of this kernel is one fully
 // coalesced 16-byte-per-lane instruction.  Thread t of block b handles elements
@@ -721,26 +748,27 @@ bool lane_strided() {
 
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
-                 int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials)
+                 int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
+                 double* aux = nullptr)
 {
     auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
-                       partials, chunked);
+                       partials, chunked, aux);
     return PRCG_LAUNCH_OK() ? grid : -1;
 }
 
 template <int NV, int EPI>
 int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
                        void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
-                       double* partials)
+                       double* partials, double* aux = nullptr)
 {
     switch (steps) {
-    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
-    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
-    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials);
+    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
+    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
+    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
     default: return -1;
     }
 }
@@ -764,6 +792,15 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
     if (ntiles <= 0) return 0;
     return launch_tiles_steps<2, kEpiNone>(steps, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr,
                                            nullptr);
+}
+
+int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
+                      const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
+                      double* coef_out, double* partials, int meurant)
+{
+    if (ntiles <= 0) return 0;
+    return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0),
+                                                dots_prev, nullptr, rs_new, partials, coef_out);
 }
 
 int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {

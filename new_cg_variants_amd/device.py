@@ -37,10 +37,23 @@ class DeviceCSR:
     ``partition.plan_halo`` (columns >= n_rows are ghosts).
     """
 
-    def __init__(self, A, device=0, comm_init=None, halo=None):
+    def __init__(self, A, device=0, comm_init=None, halo=None, knobs=None):
+        """knobs: dict of PRCG_* experiment switches read by prcg_create (e.g.
+        {'PRCG_FUSED': '0'} keeps the two-kernel schedule on one GPU)."""
         self._h = C.c_void_p()
         self._lib = L.lib()
-        rc = self._lib.prcg_create(C.byref(self._h), int(device))
+        saved = {}
+        for k, v in (knobs or {}).items():
+            saved[k] = os.environ.get(k)
+            os.environ[k] = str(v)
+        try:
+            rc = self._lib.prcg_create(C.byref(self._h), int(device))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if rc != L.OK:
             msg = self._lib.prcg_last_error(None)
             self._h = C.c_void_p()

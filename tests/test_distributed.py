@@ -94,7 +94,7 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
     A, z = matrices['nos7']
     n = A.shape[0]
     uid, path = rccl_ids(1)
-    plain = DeviceCSR(A)
+    plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})     # same two-kernel schedule as with a communicator
     comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
     for variant in (L.PIPE_PR, L.HS, L.PR):
         outs = []
@@ -147,7 +147,7 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids):
     assert moved > 0
     b, x0, x_true = problems.reference_rhs(A, n)
     uid, path = rccl_ids(n_ids)      # 2 ids: halo exchange on its own communicator + stream
-    plain = DeviceCSR(A)
+    plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
     loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo)
     x = np.random.default_rng(2).standard_normal(n)
     y0, _ = plain.matvec(x)

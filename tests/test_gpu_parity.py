@@ -279,7 +279,9 @@ def test_whole_trajectory_against_device_ordered_oracle(amd, matrices, matrix, f
     getattr(orc, method)(A, z['b'], np.zeros(n), max_iter, dot=device_dot, square=lambda a: a * a,
                          tap=lambda st: want.append((st.mu, st.dl, st.gm, st.nu)))
     want = np.array(want)
-    op = amd['device'].DeviceCSR(A)
+    # two-kernel schedule: its inner products come from the update kernel, whose reduction
+    # tree tests/device_order.py reproduces (the fused one-launch schedule sums per tile)
+    op = amd['device'].DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
     op.begin(getattr(L, VARIANT_OF[method]), z['b'], np.zeros(n), max_iter)
     op.iterate(max_iter - 1)
     op.sync()
@@ -289,6 +291,42 @@ def test_whole_trajectory_against_device_ordered_oracle(amd, matrices, matrix, f
     first_bad = int(np.argmin(same.all(axis=1))) if not same.all() else -1
     print(f'{matrix}/{method}: {max_iter} iterations, all four inner products bit-exact: {bool(same.all())}')
     assert same.all(), f'first mismatch at k={first_bad}: got {got[first_bad]} want {want[first_bad]}'
+
+
+@pytest.mark.parametrize('matrix,variant', [('bcsstk03', 'PIPE_PR'), ('nos7', 'PIPE_PR'), ('nos7', 'PIPE_PR_M')])
+def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant):
+    """One GPU runs pipe_pr_cg as ONE launch per iteration (SpMM with the next vector update
+    fused into its row epilogue; w,u never stored).  Same arithmetic per element as the
+    two-kernel schedule, different summation order of the inner products: single steps from
+    identical state agree to 1e-12, vectors bit for bit; derived w,u equal A r, A s."""
+    L = amd['L']
+    A, z = matrices[matrix]
+    n = A.shape[0]
+    ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_FUSED': f}) for f in ('1', '0')]
+    for op in ops:
+        op.begin(getattr(L, variant), z['b'], np.zeros(n), 64)
+    worst = 0.0
+    for k in range(40):
+        # teacher-force the fused engine with the two-kernel engine's state, step both
+        st = {v: ops[1].get_vector(v) for v in ('x', 'r', 'p', 's')}
+        sc = ops[1].get_scalars(k)
+        for v, a in st.items():
+            ops[0].set_vector(v, a)
+        ops[0].set_scalars(k, sc)
+        ops[0].set_iteration(k)
+        for op in ops:
+            op.iterate(1)
+        for v in ('x', 'r', 'p', 's'):
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v)), (k, v)
+        a, b = ops[0].get_scalars(k + 1)[:4], ops[1].get_scalars(k + 1)[:4]
+        worst = max(worst, float(np.max(np.abs(a - b) / np.abs(b))))
+        assert np.array_equal(ops[0].get_coefficients(k + 1), ops[1].get_coefficients(k + 1))
+    assert worst <= 1e-12, worst
+    r, s = ops[0].get_vector('r'), ops[0].get_vector('s')
+    assert np.array_equal(ops[0].get_vector('w'), A @ r) and np.array_equal(ops[0].get_vector('u'), A @ s)
+    for op in ops:
+        op.close()
+    print(f'{matrix}/{variant}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
 def test_device_results_are_reproducible(amd, matrices):
