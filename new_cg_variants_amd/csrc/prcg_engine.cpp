@@ -114,6 +114,10 @@ struct prcg_handle {
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
     double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
+    DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
+    int pend_parts = 0;          // fused: dots[pend_k] exist only as this many block partials ...
+    int pend_k = -1;             // ... of iteration pend_k, in pend_buf
+    double* pend_buf = nullptr;
     DevBuf dots, coef;
 
     // ---- profiling ----
@@ -231,10 +235,13 @@ int x_stride(prcg_t* h) { return is_pipe(h->variant) ? 2 : 1; }
 double* dots_at(prcg_t* h, int k) { return h->dots.d() + (size_t)k * kNS; }
 double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride; }
 
+void fused_flush(prcg_t* h);
+
 // ---- history recorders for the state of iteration k (compute stream) -------------------
 int record(prcg_t* h, int k) {
     const uint32_t m = h->hist_mask;
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
+    if (h->fused) fused_flush(h);    // the recorders reuse the partials buffers
     const int64_t n = h->n;
     int rc;
     if (m & PRCG_HIST_RESIDUAL_2_NORM) {
@@ -373,16 +380,32 @@ PipeUpdateArgs pipe_args(prcg_t* h, int k) {
 // applies update k to the row at once.  The reduction of the inner products is NOT
 // overlapped with anything here (it is needed at the head of the next launch) -- which is
 // why ranks with a communicator keep the two-kernel schedule below.
+// make dots[pend_k] real if the last fused launch left it as block partials
+void fused_flush(prcg_t* h) {
+    if (h->pend_parts > 0) {
+        launch_reduce_final(h->sc, h->pend_buf, h->pend_parts, dots_at(h, h->pend_k), 0, 0, 5);
+        h->pend_parts = 0;
+    }
+}
+
 int iterate_pipe_fused(prcg_t* h, int k) {
     double* rs_old = h->rs_cur;
     double* rs_new = (h->rs_cur == h->rs.d()) ? h->rs2.d() : h->rs.d();
+    // partials of iteration k-1 (if still pending) are consumed by this launch's prologue
+    FusedPrev prev{nullptr, 0, nullptr};
+    if (h->pend_parts > 0 && h->pend_k == k - 1) {
+        prev = FusedPrev{h->pend_buf, h->pend_parts, dots_at(h, k - 1)};
+    } else {
+        fused_flush(h);
+    }
+    double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_pipe_fused(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, rs_old, rs_new,
-                                       h->xp.d(), dots_at(h, k - 1), coef_at(h, k), h->partB.d(), meurant(h->variant));
+                                       h->xp.d(), dots_at(h, k - 1), coef_at(h, k), part_out, meurant(h->variant), prev);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
-    launch_reduce_final(h->sc, h->partB.d(), grid, dots_at(h, k), 0, 0, 5);
+    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
     h->rs_cur = rs_new;
     return PRCG_OK;
 }
@@ -794,6 +817,8 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->xp.alloc((size_t)2 * n * D));
         HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
         HIPCHK(h, h->rs2.alloc(h->fused ? (size_t)2 * ne * D : 16));
+        HIPCHK(h, h->partC.alloc(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16));
+        h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         h->rs_cur = h->rs.d();
         HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
         HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
@@ -890,6 +915,7 @@ int prcg_iterate(prcg_t* h, int iters) {
         if ((rc = record(h, k))) return rc;
         h->k = k;
     }
+    if (h->fused) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
     return PRCG_OK;
 }
 

@@ -51,9 +51,14 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 // vector update of the following iteration applied to each row as soon as its (w_i,u_i)
 // exist.  w,u never reach memory; (r,s) are double-buffered (gathered from rs_old, written
 // to rs_new); the 4 inner products ride along (partials[grid][0..4]).  Returns the grid.
+// `prev`: if prev.nprev > 0 the inner products of the previous iteration are still block
+// partials (prev.prev_partials[nprev][kPartialStride]); every block sums them itself in the
+// fixed order and block 0 stores the result to prev.dots_prev_out -- no reduction launch
+// between iterations.  Otherwise the reduced values are read from dots_prev.
+struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; };
 int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                       const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant);
+                      double* coef_out, double* partials, int meurant, FusedPrev prev);
 
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {

@@ -176,7 +176,8 @@ template <int NV, int EPI>
 __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
                                            int write_mask, const typename VecT<NV>::type* __restrict__ X,
                                            const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
+                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf,
+                                           const double2* pre_xp = nullptr)
 {
     if constexpr (NV == 1) {
         double* Y = reinterpret_cast<double*>(yout_);
@@ -193,7 +194,7 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
         // the OLD pair array X (other rows still gather from it) and written to the NEW one.
         double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
         double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
-        const double2 xp = XP[row];
+        const double2 xp = pre_xp ? *pre_xp : XP[row];
         const double2 rs = X[row];
         const double xn = xp.x + cf.al * xp.y;               // x += a p
         const double rn = rs.x - cf.al * rs.y;               // r -= a s
@@ -314,6 +315,14 @@ __device__ __forceinline__ void process_tile(
     const int* ip0 = A.indptr + (row0 < re ? row0 : rb);
     const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
     const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
+    double2 xp0 = make_double2(0.0, 0.0), xp1 = xp0;
+    if constexpr (EPI == kEpiPipeFused) {
+        // the rows' (x,p) pairs for the fused update: issued with the row pointers, used
+        // after the row sums
+        const double2* XPc = reinterpret_cast<const double2*>(yout_);
+        xp0 = XPc[row0 < re ? row0 : rb];
+        xp1 = XPc[row1 < re ? row1 : rb];
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
@@ -332,8 +341,8 @@ __device__ __forceinline__ void process_tile(
         }
     }
     wave_lds_sync();
-    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
-    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, EPI == kEpiPipeFused ? &xp0 : nullptr);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, EPI == kEpiPipeFused ? &xp1 : nullptr);
     for (int row = rb + 128 + lane; row < re; row += 64) {
         const int s = A.indptr[row] - alo;
         const int e = A.indptr[row + 1] - alo;
@@ -351,7 +360,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-    double* __restrict__ ep_st, double* __restrict__ partials, int chunked, double* __restrict__ aux)
+    double* __restrict__ ep_st, double* __restrict__ partials, int chunked, double* __restrict__ aux,
+    FusedPrev fz)
 {
     using V = typename VecT<NV>::type;
     constexpr int kSlots = 256 * STEPS;
@@ -369,7 +379,37 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     if constexpr (EPI == kEpiPipeFused) {
         // ep_r = the reduced inner products of the previous iteration; bit 2 of write_mask =
         // Meurant's prediction; aux = where alpha, beta, nu_pred of this iteration are kept
-        cf = predict(ep_r, (write_mask >> 2) & 1);
+        if (fz.nprev > 0) {
+            // The previous launch left one row of partial inner products per block.  Every
+            // block of THIS launch sums them itself, in the same fixed order (thread t: rows
+            // t, t+256, ...; butterfly; waves in order), so no separate reduction launch is
+            // needed and all blocks get bit-identical coefficients.  The kernel boundary
+            // makes the partials visible; nothing is exchanged inside a launch.
+            __shared__ double redp[kWaves][5];
+            __shared__ double dsum[5];
+            double tot[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = threadIdx.x; j < fz.nprev; j += kBlock) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) tot[q] += fz.prev_partials[(size_t)j * kPartialStride + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double v = wave_sum(tot[q]);
+                if (lane == 0) redp[wv][q] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 5) {
+                double v = redp[0][threadIdx.x];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) v += redp[w][threadIdx.x];
+                dsum[threadIdx.x] = v;
+                if (blockIdx.x == 0) fz.dots_prev_out[threadIdx.x] = v;    // history / get_scalars
+            }
+            __syncthreads();
+            cf = predict(dsum, (write_mask >> 2) & 1);
+        } else {
+            cf = predict(ep_r, (write_mask >> 2) & 1);
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
     }
 
@@ -749,26 +789,26 @@ bool lane_strided() {
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
-                 double* aux = nullptr)
+                 double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
     auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
-                       partials, chunked, aux);
+                       partials, chunked, aux, fz);
     return PRCG_LAUNCH_OK() ? grid : -1;
 }
 
 template <int NV, int EPI>
 int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
                        void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
-                       double* partials, double* aux = nullptr)
+                       double* partials, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
     switch (steps) {
-    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
-    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
-    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux);
+    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
     default: return -1;
     }
 }
@@ -796,11 +836,11 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 
 int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                       const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant)
+                      double* coef_out, double* partials, int meurant, FusedPrev prev)
 {
     if (ntiles <= 0) return 0;
     return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0),
-                                                dots_prev, nullptr, rs_new, partials, coef_out);
+                                                dots_prev, nullptr, rs_new, partials, coef_out, prev);
 }
 
 int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {
