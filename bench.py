@@ -40,6 +40,10 @@ def spmm2_bytes(n, nnz):    # B2: A once, two input and two output vectors
     return 12 * nnz + 4 * (n + 1) + 32 * n
 
 
+def fused_bytes(n, nnz):    # one-launch iteration: A once, (r,s) read + written, (x,p) read + written
+    return 12 * nnz + 4 * (n + 1) + 64 * n
+
+
 def cpu_baseline(A, b, x0, family, seconds=15.0):
     """The CPU line: the NumPy/SciPy restatement of the reference's loop (oracle/, pinned
     bitwise against the imported reference in the build container) timed on this host."""
@@ -168,7 +172,13 @@ def main():
 
     if rank == 0:
         n_local = hi - lo
-        if args.variant == 'pipe_pr_cg':
+        fused = (world == 1 and not args.force_comm and args.variant == 'pipe_pr_cg'
+                 and os.environ.get('PRCG_FUSED', '1') != '0')
+        if fused:
+            kbytes = fused_bytes(n_local, nnz_local)
+            kname = ('k_spmv_tiles<2,fused> (two-vector SpMM + next vector update + inner products, '
+                     'one launch per iteration)')
+        elif args.variant == 'pipe_pr_cg':
             kbytes = spmm2_bytes(n_local, nnz_local)
             kname = 'k_spmv_tiles<2> (two-vector SpMM, interior launch)'
         else:
@@ -179,7 +189,8 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f'{args.workload}:{args.variant}:{world}')
+                key = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
+                traffic = json.load(open(tfile)).get(key)
             except Exception:
                 traffic = None
         out = {
