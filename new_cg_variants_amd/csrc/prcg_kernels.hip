@@ -17,6 +17,10 @@
 
 #include "prcg_kernels.h"
 
+#ifndef PRCG_XP_PREFETCH
+#define PRCG_XP_PREFETCH 0   // measured slower on S3 (1.99-2.02k vs 2.07-2.10k it/s): more registers live across the gather
+#endif
+
 namespace prcg {
 namespace {
 
@@ -316,7 +320,7 @@ __device__ __forceinline__ void process_tile(
     const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
     const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
     double2 xp0 = make_double2(0.0, 0.0), xp1 = xp0;
-    if constexpr (EPI == kEpiPipeFused) {
+    if constexpr (PRCG_XP_PREFETCH && EPI == kEpiPipeFused) {
         // the rows' (x,p) pairs for the fused update: issued with the row pointers, used
         // after the row sums
         const double2* XPc = reinterpret_cast<const double2*>(yout_);
@@ -341,8 +345,8 @@ __device__ __forceinline__ void process_tile(
         }
     }
     wave_lds_sync();
-    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, EPI == kEpiPipeFused ? &xp0 : nullptr);
-    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, EPI == kEpiPipeFused ? &xp1 : nullptr);
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, PRCG_XP_PREFETCH && EPI == kEpiPipeFused ? &xp0 : nullptr);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, PRCG_XP_PREFETCH && EPI == kEpiPipeFused ? &xp1 : nullptr);
     for (int row = rb + 128 + lane; row < re; row += 64) {
         const int s = A.indptr[row] - alo;
         const int e = A.indptr[row + 1] - alo;
