@@ -147,9 +147,15 @@ def hs_cg(comm, A, b, max_iter):
     return _timed(comm, _as_operator(comm, A), L.HS, b, max_iter)
 
 
+def pipe_p_cg(comm, A, b, max_iter):
+    """Pipelined predict-only CG (no recompute of w = A r): the PETSc series "pipeprcg_0"
+    (scaling_experiments_petsc/strong_scaling_tests.py:60-62; cg_impls/pipeprcg.c:33)."""
+    return _timed(comm, _as_operator(comm, A), L.PIPE_P, b, max_iter)
+
+
 def pr_cg(comm, A, b, max_iter):
     """Predict-and-recompute CG, one (blocking) reduction per iteration (cg_variants/pr_cg.py)."""
     return _timed(comm, _as_operator(comm, A), L.PR, b, max_iter)
 
 
-__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'hs_cg', 'pr_cg']
+__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'pipe_p_cg', 'hs_cg', 'pr_cg']

@@ -396,3 +396,49 @@ def test_s3_banded_cg_monotone_error_and_residual_identity(amd):
         np.testing.assert_allclose(e[:20], want['error_A_norm'][:20], rtol=1e-6)
         np.testing.assert_allclose(e, want['error_A_norm'], rtol=1e-2)
         np.testing.assert_allclose(out['residual_2_norm'][:20], out['updated_residual_2_norm'][:20], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# driver-level drop-ins
+# ---------------------------------------------------------------------------------------
+def test_figure_run_reproduces_the_reference_table_row(amd, tmp_path):
+    """The figure_gen-compatible runner on the bcsstk03 fixture: saved dicts load like the
+    reference's, and the table statistics land on the published row within its own spread."""
+    import os
+    from conftest import GOLDEN
+    from new_cg_variants_amd.experiments import figure_run as fr
+    A = fr.load_matrix(os.path.join(GOLDEN, 'matrix_bcsstk03.npz'))
+    trials = fr.run_matrix(A, 1250, 'bcsstk03', None, fr.TABLE_METHODS, out=str(tmp_path))
+    saved = np.load(tmp_path / 'bcsstk03_None' / 'pipe_pr_pcg.npy', allow_pickle=True).item()
+    assert saved['name'] == 'pipe_pr_pcg' and saved['max_iter'] == 1250
+    assert set(saved) >= {'error_A_norm', 'residual_2_norm', 'error_2_norm', 'updated_residual_2_norm'}
+    # published row: hs 364 / m 425 / pr 380 / pipe_pr_m 492 / pipe_pr 411; -14.55 -14.40 -14.43 -12.65 -12.96
+    published = {'hs_pcg': (364, -14.55), 'm_pcg': (425, -14.40), 'pr_pcg': (380, -14.43),
+                 'pipe_pr_m_pcg': (492, -12.65), 'pipe_pr_pcg': (411, -12.96)}
+    for m, (its_pub, acc_pub) in published.items():
+        its, acc = fr.summarize(trials[m])
+        assert abs(its - its_pub) <= 0.10 * its_pub, (m, its, its_pub)
+        assert abs(acc - acc_pub) <= 1.5, (m, acc, acc_pub)
+    row = fr.table_row('bcsstk03', A, None, trials)
+    assert row.startswith('\\texttt{bcsstk03} & - & 112 & 640&') and row.rstrip().endswith('\\\\')
+
+
+def test_ex2b_driver_matches_the_published_petsc_errors(amd, capfd):
+    """The reference's PETSc run (n=650000, k=32, rho=.95, kappa=1e6, off=1e-4, 4000 iterations,
+    config_info/slurm-864568.out:129,186,205) printed
+        cg         Norm of error 1.60099e-07 iterations 4000
+        pipeprcg   Norm of error 3.24332e-07 iterations 4000
+        pipeprcg_0 Norm of error 8.94408e-05 iterations 4000
+    The same command line through the device must land in the same decade."""
+    from new_cg_variants_amd.experiments import ex2b
+    base = '-n 650000 -rho 0.95 -kappa 1e6 -k 32 -off_value 1e-4 -pc_type none -num_repeat 1 ' \
+           '-ksp_norm_type none -ksp_max_it 4000'
+    published = {'-ksp_type cg': 1.60099e-07, '-ksp_type pipeprcg': 3.24332e-07,
+                 '-ksp_type pipeprcg -recompute_q 0': 8.94408e-05}
+    for flags, err_pub in published.items():
+        ex2b.main((base + ' ' + flags).split())
+        out = capfd.readouterr().out.strip().splitlines()[-1]
+        assert out.startswith('Norm of error ') and out.endswith(' iterations 4000'), out
+        err = float(out.split()[3])
+        assert abs(np.log10(err) - np.log10(err_pub)) < 1.0, (flags, err, err_pub)
+        print(f'ex2b {flags}: {out}   (PETSc run published {err_pub:g})')
