@@ -437,8 +437,9 @@ def test_ex2b_driver_matches_the_published_petsc_errors(amd, capfd):
                  '-ksp_type pipeprcg -recompute_q 0': 8.94408e-05}
     for flags, err_pub in published.items():
         ex2b.main((base + ' ' + flags).split())
-        out = capfd.readouterr().out.strip().splitlines()[-1]
-        assert out.startswith('Norm of error ') and out.endswith(' iterations 4000'), out
+        lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith('Norm of error ')]
+        assert len(lines) == 1 and lines[0].endswith(' iterations 4000'), lines
+        out = lines[0]
         err = float(out.split()[3])
         assert abs(np.log10(err) - np.log10(err_pub)) < 1.0, (flags, err, err_pub)
         print(f'ex2b {flags}: {out}   (PETSc run published {err_pub:g})')
