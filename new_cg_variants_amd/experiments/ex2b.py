@@ -77,6 +77,9 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(fd, 1)              # give stdout back (main() may be called from a test or a notebook)
+    os.close(fd)
 
 
 if __name__ == '__main__':
