@@ -49,7 +49,9 @@ typedef struct prcg_handle prcg_t;
 #define PRCG_PIPE_P_M    4  /* pipe_p_m_cg / _pcg        pipe_pr_cg.py:95,207        */
 #define PRCG_PR          5  /* pr_pcg                    pr_cg.py:166                */
 #define PRCG_M           6  /* m_pcg                     pr_cg.py:172                */
-#define PRCG_NUM_VARIANTS 7
+#define PRCG_CG_CG       7  /* cg_cg / cg_pcg  (Chronopoulos-Gear)   cg_cg.py:9,76      */
+#define PRCG_GV          8  /* gv_cg / gv_pcg  (Ghysels-Vanroose)    gv_cg.py:9,93      */
+#define PRCG_NUM_VARIANTS 9
 
 /* ---- history recorders (bit mask), = the four callbacks of figure_gen.py:37 ---- */
 #define PRCG_HIST_UPDATED_RESIDUAL_2_NORM  1u  /* callbacks/updated_residual_2_norm.py:40 */
@@ -74,7 +76,7 @@ typedef struct prcg_handle prcg_t;
 
 /* ---- per-iteration scalars (one row of prcg_get_scalars) ---------------------- */
 #define PRCG_S_MU     0   /* p.s                                   */
-#define PRCG_S_DELTA  1   /* r.s~                                  */
+#define PRCG_S_DELTA  1   /* r.s~   (cg_cg / gv: eta = w.r~)        */
 #define PRCG_S_GAMMA  2   /* s~.s                                  */
 #define PRCG_S_NU     3   /* r~.r                                  */
 #define PRCG_S_RR     4   /* r.r   (= nu when unpreconditioned)    */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('PRCG_LIB') or os.path.join(_HERE, 'libprcg.so')   # P
 
 # constants of include/prcg.h
 OK, EINVAL, EHIP, ERCCL, ENOMEM = 0, 1, 2, 3, 4
-HS, PIPE_PR, PIPE_P, PIPE_PR_M, PIPE_P_M, PR, M = range(7)
+HS, PIPE_PR, PIPE_P, PIPE_PR_M, PIPE_P_M, PR, M, CG_CG, GV = range(9)
 HIST_UPDATED_RESIDUAL_2_NORM, HIST_RESIDUAL_2_NORM, HIST_ERROR_A_NORM, HIST_ERROR_2_NORM = 1, 2, 4, 8
 HIST_BITS = {
     'updated_residual_2_norm': HIST_UPDATED_RESIDUAL_2_NORM,

@@ -94,6 +94,10 @@ def _state_vectors(variant, prec):
         return ['x', 'r', 'p', 's'] + (['rt'] if prec else [])
     if variant in (L.PR, L.M):
         return ['x', 'r', 'p', 's'] + (['rt', 'st'] if prec else [])
+    if variant == L.CG_CG:
+        return ['x', 'r', 'p', 's', 'w'] + (['rt'] if prec else [])
+    if variant == L.GV:
+        return ['x', 'r', 'p', 's', 'w', 'u'] + (['rt', 'wt', 'st'] if prec else [])
     return ['x', 'r', 'p', 's', 'w', 'u'] + (['rt', 'st', 'wt', 'ut'] if prec else [])
 
 
@@ -138,6 +142,8 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
             env[_STATE_NAMES[v]] = op.get_vector(v)
         sc = op.get_scalars(k)
         env.update(nu_k=sc[L.S_NU], mu_k=sc[L.S_MU], del_k=sc[L.S_DELTA], gam_k=sc[L.S_GAMMA])
+        if variant in (L.CG_CG, L.GV):
+            env['eta_k'] = sc[L.S_DELTA]          # slot 1 holds eta = w.r~ for these two
         with np.errstate(all='ignore'):
             env['a_k'] = sc[L.S_NU] / sc[L.S_MU]
         env['b_k'] = op.get_coefficients(k)[1] if k > 0 else 0
@@ -157,11 +163,17 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
 
 
 def _make(variant, name, preconditioned):
+    def check(kwargs):
+        if kwargs.pop('w_replace', None) is not None:
+            # gv_cg.py:9 takes a residual-replacement predicate; its default never fires
+            raise NotImplementedError('w_replace (residual replacement) is not available on the device')
     if preconditioned:
         def f(A, b, x0, max_iter, preconditioner=None, callbacks=[], **kwargs):
+            check(kwargs)
             return _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs)
     else:
         def f(A, b, x0, max_iter, callbacks=[], **kwargs):
+            check(kwargs)
             kwargs.pop('preconditioner', None)   # figure_gen.py:59 always passes one
             return _run(variant, name, A, b, x0, max_iter, None, callbacks, kwargs)
     f.__name__ = f.__qualname__ = name
@@ -176,6 +188,10 @@ m_pcg = _make(L.M, 'm_pcg', True)                         # pr_cg.py:172
 # they are the identity-preconditioned recurrences, which is what they were meant to be
 pr_cg = _make(L.PR, 'pr_cg', False)
 m_cg = _make(L.M, 'm_cg', False)
+cg_cg = _make(L.CG_CG, 'cg_cg', False)                    # cg_cg.py:9   (Chronopoulos-Gear)
+cg_pcg = _make(L.CG_CG, 'cg_pcg', True)                   # cg_cg.py:76
+gv_cg = _make(L.GV, 'gv_cg', False)                       # gv_cg.py:9   (Ghysels-Vanroose, pipelined CG)
+gv_pcg = _make(L.GV, 'gv_pcg', True)                      # gv_cg.py:93
 pipe_p_cg = _make(L.PIPE_P, 'pipe_p_cg', False)           # pipe_pr_cg.py:83
 pipe_pr_cg = _make(L.PIPE_PR, 'pipe_pr_cg', False)        # pipe_pr_cg.py:89
 pipe_p_m_cg = _make(L.PIPE_P_M, 'pipe_p_m_cg', False)     # pipe_pr_cg.py:95
@@ -185,6 +201,6 @@ pipe_pr_pcg = _make(L.PIPE_PR, 'pipe_pr_pcg', True)       # pipe_pr_cg.py:201
 pipe_p_m_pcg = _make(L.PIPE_P_M, 'pipe_p_m_pcg', True)    # pipe_pr_cg.py:207
 pipe_pr_m_pcg = _make(L.PIPE_PR_M, 'pipe_pr_m_pcg', True) # pipe_pr_cg.py:213
 
-__all__ = ['hs_cg', 'hs_pcg', 'pr_cg', 'pr_pcg', 'm_cg', 'm_pcg',
+__all__ = ['hs_cg', 'hs_pcg', 'cg_cg', 'cg_pcg', 'gv_cg', 'gv_pcg', 'pr_cg', 'pr_pcg', 'm_cg', 'm_pcg',
            'pipe_p_cg', 'pipe_pr_cg', 'pipe_p_m_cg', 'pipe_pr_m_cg',
            'pipe_p_pcg', 'pipe_pr_pcg', 'pipe_p_m_pcg', 'pipe_pr_m_pcg', 'Jacobi', 'clear_operator_cache']

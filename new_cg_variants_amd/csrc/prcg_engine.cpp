@@ -111,6 +111,7 @@ struct prcg_handle {
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
     DevBuf x, xp, p, rs, rs2, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
     double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
@@ -181,6 +182,7 @@ int env_tile_steps() {
 
 bool is_pipe(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_P || v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M; }
 bool is_pr(int v) { return v == PRCG_PR || v == PRCG_M; }
+bool is_cg_family(int v) { return v == PRCG_CG_CG || v == PRCG_GV; }
 bool pipe_recompute(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_PR_M; }
 bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == PRCG_M; }
 
@@ -486,6 +488,69 @@ int iterate_pr(prcg_t* h, int k) {
     return pr_spmv_and_reduce(h, k, grid);
 }
 
+CgArgs cg_args(prcg_t* h, int k) {
+    CgArgs a{};
+    a.n = h->n;
+    a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
+    a.w = h->w.d(); a.wt = h->prec ? h->wt.d() : nullptr;
+    a.p = h->p.d(); a.s = h->s.d();
+    a.st_ = (h->prec && h->variant == PRCG_GV) ? h->st.d() : nullptr;
+    a.u = h->variant == PRCG_GV ? h->u.d() : nullptr;
+    a.t = h->tvec.d();
+    a.z = h->prec ? h->rt.d() : h->r.d();
+    a.d = h->prec ? h->dinv.d() : nullptr;
+    a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
+    a.dots_cur = dots_at(h, k);
+    a.dots_cur_w = dots_at(h, k);
+    a.coef_out = coef_at(h, k);
+    a.partials = h->partA.d();
+    return a;
+}
+
+// Chronopoulos-Gear (cg_cg.py:59-68): ONE reduction per iteration, after the SpMV it depends on
+int iterate_cgcg(prcg_t* h, int k) {
+    HsArgs a = hs_args(h, k);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    LAUNCHCHK(h, launch_hs_update_xr(h->sc, a));                              // x, r, (r~)
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    double* z = h->prec ? h->rt.d() : h->r.d();
+    int nparts = 0;
+    int rc = overlapped_spmv(h, k, z, h->w.d(), kEpiCG, h->r.d(), nullptr, nullptr, &nparts);   // w = A r~; nu, eta
+    if (rc) return rc;
+    launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, 0, 5);
+    if ((rc = allreduce(h, dots_at(h, k), 5, h->sc))) return rc;
+    LAUNCHCHK(h, launch_cg_update_ps(h->sc, cg_args(h, k)));                  // p, s; mu by recurrence
+    return PRCG_OK;
+}
+
+// Ghysels-Vanroose (gv_cg.py:65-81): the inner products come BEFORE the SpMV they overlap with
+int iterate_gv(prcg_t* h, int k) {
+    CgArgs a = cg_args(h, k);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    const int grid = launch_gv_update1(h->sc, a, false);                      // x, r, r~, w, w~; nu, eta
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    int rc;
+    const bool side = h->multi();
+    if (side) {
+        HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+        HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+        launch_reduce_final(h->sm, h->partA.d(), grid, dots_at(h, k), 0, 0, 5);
+        if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
+        HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+    } else {
+        launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), 0, 0, 5);
+    }
+    double* zt = h->prec ? h->wt.d() : h->w.d();
+    int nparts = 0;
+    if ((rc = overlapped_spmv(h, k, zt, h->tvec.d(), kEpiNone, nullptr, nullptr, nullptr, &nparts))) return rc;   // t = A w~
+    if (side) HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+    LAUNCHCHK(h, launch_cg_update_ps(h->sc, a));                              // p, s, s~, u; mu by recurrence
+    return PRCG_OK;
+}
+
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
     HIPCHK(h, hipStreamSynchronize(h->sc));
@@ -513,6 +578,20 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rst.d(); *stride = 2; return true;
         case PRCG_VEC_ST: if (!h->prec) return false; *base = h->rst.d() + 1; *stride = 2; return true;
         case PRCG_VEC_WT: if (!h->prec || pipe_recompute(v)) return false; *base = h->wt.d(); return true;
+        default: return false;
+        }
+    }
+    if (is_cg_family(v)) {
+        switch (which) {
+        case PRCG_VEC_X: *base = h->x.d(); return true;
+        case PRCG_VEC_P: *base = h->p.d(); return true;
+        case PRCG_VEC_R: *base = h->r.d(); return true;
+        case PRCG_VEC_S: *base = h->s.d(); return true;
+        case PRCG_VEC_W: *base = h->w.d(); return true;
+        case PRCG_VEC_U: if (v != PRCG_GV) return false; *base = h->u.d(); return true;
+        case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
+        case PRCG_VEC_WT: if (!h->prec || v != PRCG_GV) return false; *base = h->wt.d(); return true;
+        case PRCG_VEC_ST: if (!h->prec || v != PRCG_GV) return false; *base = h->st.d(); return true;
         default: return false;
         }
     }
@@ -856,6 +935,47 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         LAUNCHCHK(h, grid);
         if (!h->fused_final) launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
         if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+    } else if (is_cg_family(variant)) {
+        // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
+        HIPCHK(h, h->p.alloc((size_t)ne * D));
+        HIPCHK(h, h->r.alloc((size_t)ne * D));
+        HIPCHK(h, h->rt.alloc(h->prec ? (size_t)ne * D : 16));
+        HIPCHK(h, h->w.alloc((size_t)ne * D));
+        HIPCHK(h, h->wt.alloc(h->prec ? (size_t)ne * D : 16));
+        HIPCHK(h, h->s.alloc((size_t)n * D));
+        HIPCHK(h, h->st.alloc(h->prec ? (size_t)n * D : 16));
+        HIPCHK(h, h->u.alloc((size_t)n * D));
+        HIPCHK(h, h->tvec.alloc((size_t)n * D));
+        launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x      cg_cg.py:23
+        if (h->prec) launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r   :89
+        double* z = h->prec ? h->rt.d() : h->r.d();
+        launch_copy(sc, h->p.d(), 1, z, 1, n);                              // p = r~           :25 / :91
+        int grid = 0;
+        if (variant == PRCG_CG_CG) {
+            // w = A r~ with nu = r.r~, eta = w.r~ (:24,26,27); s = A p with mu = p.s (:28,30)
+            if ((rc = dist_spmv(h, z, h->w.d(), kEpiCG, h->r.d(), nullptr, nullptr, &grid))) return rc;
+            launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, 0, 5);
+            if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &grid))) return rc;
+            launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, PRCG_S_MU, 1);
+            if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+        } else {
+            // gv_cg.py:26-33 / gv_pcg :96-109
+            if ((rc = dist_spmv(h, z, h->w.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;   // w = A r~
+            if (h->prec) launch_mul(sc, h->wt.d(), 1, h->dinv.d(), 1, h->w.d(), 1, n);                         // w~
+            launch_copy(sc, h->s.d(), 1, h->w.d(), 1, n);                                                      // s = w
+            if (h->prec) launch_copy(sc, h->st.d(), 1, h->wt.d(), 1, n);                                       // s~ = w~
+            double* zt = h->prec ? h->wt.d() : h->w.d();
+            if ((rc = dist_spmv(h, zt, h->u.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;  // u = A w~
+            CgArgs a = cg_args(h, 0);
+            const int g1 = launch_gv_update1(sc, a, true);                                                     // nu, eta
+            LAUNCHCHK(h, g1);
+            launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), 0, 0, 5);
+            // mu = p.s as a true inner product at the start (gv_cg.py:33)
+            const int g2 = launch_dot(sc, h->p.d(), h->s.d(), n, h->partB.d(), 0);
+            LAUNCHCHK(h, g2);
+            launch_reduce_final(sc, h->partB.d(), g2, dots_at(h, 0), 0, PRCG_S_MU, 1);
+            if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+        }
     } else {
         // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)
         HIPCHK(h, h->p.alloc((size_t)ne * D));
@@ -910,6 +1030,8 @@ int prcg_iterate(prcg_t* h, int iters) {
         int rc;
         if (is_pipe(h->variant)) rc = iterate_pipe(h, k);
         else if (h->variant == PRCG_HS) rc = iterate_hs(h, k);
+        else if (h->variant == PRCG_CG_CG) rc = iterate_cgcg(h, k);
+        else if (h->variant == PRCG_GV) rc = iterate_gv(h, k);
         else rc = iterate_pr(h, k);
         if (rc) return rc;
         if ((rc = record(h, k))) return rc;

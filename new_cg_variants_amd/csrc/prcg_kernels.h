@@ -27,6 +27,7 @@ enum SpmvEpilogue {
     kEpiDotXY = 1,   // partial[0] += x_i * y_i                       (HS: mu = p.s; e'Ae)
     kEpiPR = 2,      // st = d*y (or y); partials mu=p.s, dl=r.st, gm=st.s   (pr_pcg)
     kEpiPipeFused = 3,   // two-vector only: the next pipelined vector update, fused row by row
+    kEpiCG = 4,      // partials nu = r.x, eta = y.x, rr = r.r                 (cg_cg: x = r~, y = w)
 };
 
 struct CsrDev {
@@ -98,6 +99,16 @@ struct PrArgs {   // non-pipelined predict-and-recompute (pr_pcg / m_pcg)
 int launch_pr_update(hipStream_t st, const PrArgs& a);      // x,r,rt,p; partial nu (3), rr (4)
 int launch_pr_init_dots(hipStream_t st, const PrArgs& a);
 
+struct CgArgs {   // Chronopoulos-Gear / Ghysels-Vanroose vector kernels
+    int64_t n;
+    double* x; double* r; double* rt; double* w; double* wt; double* p; double* s; double* st_; double* u;
+    const double* t; const double* z;   // t = A w~ (gv); z = r~ or r
+    const double* d;
+    const double* dots_prev; const double* dots_cur; double* dots_cur_w; double* coef_out; double* partials;
+};
+int launch_cg_update_ps(hipStream_t st, const CgArgs& a);                 // p,s,(s~),(u); mu by recurrence
+int launch_gv_update1(hipStream_t st, const CgArgs& a, bool dots_only);   // x,r,(r~),w,(w~); partials eta(1), nu(3), rr(4)
+
 // out[dst_first..+count) = fixed-order sum over blocks b of partials[b][src_first..+count)
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out,
                          int src_first, int dst_first, int count);
@@ -108,6 +119,8 @@ void launch_sub(hipStream_t st, double* dst, int ds, const double* a, int as, co
 void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, const double* b, int bs, int64_t n);
 // partial[slot] = sum (a[i*as] - b[i])^2
 int launch_diff_sq(hipStream_t st, const double* a, int as, const double* b, int64_t n, double* partials, int slot);
+// partial[slot] = sum a_i * b_i
+int launch_dot(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot);
 // buf[j*nc + c] = v[idx[j]*nc + c]
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc);
 

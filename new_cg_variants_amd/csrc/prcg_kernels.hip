@@ -192,6 +192,12 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
             if (ep_st) ep_st[row] = stv;
             acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
         }
+        if constexpr (EPI == kEpiCG) {
+            // Chronopoulos-Gear: w = A r~ with nu = r.r~, eta = w.r~ (cg_cg.py:61-63), r.r for the history
+            // (stored in the scalar-slot layout: eta -> 1, nu -> 3, r.r -> 4)
+            const double rv = ep_r[row], zv = X[row];
+            acc[3] += rv * zv; acc[1] += sum * zv; acc[4] += rv * rv;
+        }
     } else if constexpr (EPI == kEpiPipeFused) {
         // The NEXT iteration's vector update, row by row, while (w_i,u_i) = sum is still in
         // registers (pipe_pr_cg.py:61-74): w and u never touch memory.  r,s are read from
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     }
 
     if constexpr (EPI == kEpiPipeFused) { acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+    else if constexpr (EPI == kEpiCG) block_reduce_store<5>(acc, partials, 0);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
         block_reduce_store<3>(a3, partials, 0);
@@ -658,6 +665,69 @@ __global__ __launch_bounds__(kBlock) void k_pr_update(PrArgs a, int trips) {
     block_reduce_store<2>(acc, a.partials, 3);
 }
 
+// ---- competitor baselines: Chronopoulos-Gear (cg_cg.py:59-68) and Ghysels-Vanroose
+//      (gv_cg.py:65-81).  mu is a RECURRENCE here, not an inner product:
+//      mu_k = eta_k - (b_k / a_k1) nu_k, computed by thread 0 and stored with the scalars. ----
+__global__ __launch_bounds__(kBlock) void k_cg_update_ps(CgArgs a, int trips) {
+    // dots_prev: nu_k1 (slot 3), mu_k1 (slot 0); dots_cur: nu_k (3), eta_k (1)
+    const double al = a.dots_prev[3] / a.dots_prev[0];          // a_k1
+    const double nu = a.dots_cur[3], eta = a.dots_cur[1];
+    const double bt = nu / a.dots_prev[3];                      // b_k
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.coef_out[0] = al; a.coef_out[1] = bt;
+        a.dots_cur_w[0] = eta - (bt / al) * nu;                 // mu_k
+    }
+    const double* __restrict__ z = a.z;
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= a.n) break;
+            a.p[ie] = z[ie] + bt * a.p[ie];                     // p = r~ + b p
+            a.s[ie] = a.w[ie] + bt * a.s[ie];                   // s = w + b s
+            if (a.st_) a.st_[ie] = a.wt[ie] + bt * a.st_[ie];   // s~ = w~ + b s~   (gv_pcg)
+            if (a.u) a.u[ie] = a.t[ie] + bt * a.u[ie];          // u = t + b u      (gv)
+        }
+    }
+}
+
+// gv: x += a p; r -= a s; r~ -= a s~; w -= a u; w~ = M^-1 w; partials nu = r.r~, eta = w.r~, r.r
+template <bool PREC, bool DOTS_ONLY>
+__global__ __launch_bounds__(kBlock) void k_gv_update1(CgArgs a, int trips) {
+    double al = 0.0;
+    if constexpr (!DOTS_ONLY) al = a.dots_prev[3] / a.dots_prev[0];
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // slots: -, eta, -, nu, rr
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= a.n) break;
+            double rn = a.r[ie], wn = a.w[ie];
+            double zn = PREC ? a.rt[ie] : rn;
+            if constexpr (!DOTS_ONLY) {
+                a.x[ie] = a.x[ie] + al * a.p[ie];
+                rn = rn - al * a.s[ie];
+                a.r[ie] = rn;
+                wn = wn - al * a.u[ie];
+                a.w[ie] = wn;
+                if constexpr (PREC) {
+                    zn = zn - al * a.st_[ie];
+                    a.rt[ie] = zn;
+                    a.wt[ie] = a.d[ie] * wn;
+                } else {
+                    zn = rn;
+                }
+            }
+            // gv_pcg's initial eta is w.r, its loop's eta is w.r~ (gv_cg.py:107 vs :163)
+            acc[1] += wn * ((DOTS_ONLY && PREC) ? rn : zn);
+            acc[3] += rn * zn; acc[4] += rn * rn;
+        }
+    }
+    block_reduce_store<5>(acc, a.partials, 0);
+}
+
 // ---- fixed-order final reduction of per-block partials --------------------------------
 constexpr int kFinalThreads = 256;   // same tree as the fused last-block reduction
 __global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
@@ -711,6 +781,20 @@ __global__ __launch_bounds__(kBlock) void k_diff_sq(const double* __restrict__ a
             if (ie >= n) break;
             const double dlt = a[ie * as] - b[ie];
             acc[0] += dlt * dlt;
+        }
+    }
+    block_reduce_store<1>(acc, partials, slot);
+}
+__global__ __launch_bounds__(kBlock) void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                double* partials, int slot, int trips) {
+    double acc[1] = {0.0};
+    int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t ie = i + e;
+            if (ie >= n) break;
+            acc[0] += a[ie] * b[ie];
         }
     }
     block_reduce_store<1>(acc, partials, slot);
@@ -826,6 +910,8 @@ int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, 
     case kEpiNone: return launch_tiles_steps<1, kEpiNone>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
     case kEpiDotXY: return launch_tiles_steps<1, kEpiDotXY>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
     case kEpiPR: return launch_tiles_steps<1, kEpiPR>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+    case kEpiCG: return launch_tiles_steps<1, kEpiCG>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+    default: break;
     }
     return -1;
 }
@@ -891,6 +977,23 @@ int launch_pr_init_dots(hipStream_t st, const PrArgs& a) {
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 
+int launch_cg_update_ps(hipStream_t st, const CgArgs& a) {
+    const Chunking c = chunking(a.n);
+    hipLaunchKernelGGL(k_cg_update_ps, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_gv_update1(hipStream_t st, const CgArgs& a, bool dots_only) {
+    const Chunking c = chunking(a.n);
+    if (a.d) {
+        if (dots_only) hipLaunchKernelGGL((k_gv_update1<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+        else hipLaunchKernelGGL((k_gv_update1<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    } else {
+        if (dots_only) hipLaunchKernelGGL((k_gv_update1<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+        else hipLaunchKernelGGL((k_gv_update1<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    }
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+
 void launch_reduce_final(hipStream_t st, const double* partials, int nparts, double* out,
                          int src_first, int dst_first, int count) {
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kFinalThreads), 0, st, partials, nparts, out, src_first, dst_first, count);
@@ -911,6 +1014,11 @@ void launch_mul(hipStream_t st, double* dst, int ds, const double* a, int as, co
 int launch_diff_sq(hipStream_t st, const double* a, int as, const double* b, int64_t n, double* partials, int slot) {
     const Chunking c = chunking(n);
     hipLaunchKernelGGL(k_diff_sq, dim3(c.grid), dim3(kBlock), 0, st, a, as, b, n, partials, slot, c.trips);
+    return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+int launch_dot(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot) {
+    const Chunking c = chunking(n);
+    hipLaunchKernelGGL(k_dot, dim3(c.grid), dim3(kBlock), 0, st, a, b, n, partials, slot, c.trips);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc) {

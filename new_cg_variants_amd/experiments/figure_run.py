@@ -21,11 +21,11 @@ import scipy.sparse as sp
 from .. import cg_variants as cgv
 from ..callbacks import error_2_norm, error_A_norm, print_k, residual_2_norm, updated_residual_2_norm
 
-# the reference's method list minus the two competitor baselines that are not on the device yet
-DEVICE_METHODS = ['hs_pcg', 'm_pcg', 'pipe_p_m_pcg', 'pipe_pr_m_pcg', 'pr_pcg', 'pipe_p_pcg', 'pipe_pr_pcg']
-# columns of the paper's table that exist on the device (figure_gen.py:360 lists
-# hs, cg, m, pr, gv, pipe_pr_m, pipe_pr)
-TABLE_METHODS = ['hs_pcg', 'm_pcg', 'pr_pcg', 'pipe_pr_m_pcg', 'pipe_pr_pcg']
+# the reference's method list (figure_gen.py:346-348), all on the device
+DEVICE_METHODS = ['hs_pcg', 'cg_pcg', 'm_pcg', 'gv_pcg', 'pipe_p_m_pcg', 'pipe_pr_m_pcg', 'pr_pcg', 'pipe_p_pcg',
+                  'pipe_pr_pcg']
+# the columns of the paper's table (figure_gen.py:360)
+TABLE_METHODS = ['hs_pcg', 'cg_pcg', 'm_pcg', 'pr_pcg', 'gv_pcg', 'pipe_pr_m_pcg', 'pipe_pr_pcg']
 
 
 def load_matrix(path):

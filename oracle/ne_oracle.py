@@ -252,74 +252,102 @@ def pipe_advance(A, st, flavour='pr', prec=None, dot=np.dot, square=_pow2):
 
 
 # ---------------------------------------------------------------------------
-# Competitor baselines -- unpreconditioned only
-#   Chronopoulos-Gear  NE/cg_variants/cg_cg.py:9-76
-#   Ghysels-Vanroose   NE/cg_variants/gv_cg.py:9-91 (w_replace never fires by default)
+# Competitor baselines
+#   Chronopoulos-Gear  NE/cg_variants/cg_cg.py:9-74 (cg_cg), :76-143 (cg_pcg)
+#   Ghysels-Vanroose   NE/cg_variants/gv_cg.py:9-91 (gv_cg), :93-181 (gv_pcg); w_replace never fires by default
 # ---------------------------------------------------------------------------
 def cgcg_start(A, b, x0, prec=None, dot=np.dot):
-    assert prec is None
+    M = prec or _ident
     st = State()
     st.x = np.array(x0, dtype=np.float64, copy=True)
-    st.r = b - A @ st.x                                        # cg_cg.py:23
-    st.w = A @ st.r                                            # :24
-    st.p = st.r.copy()                                         # :25
-    st.nu = dot(st.r, st.r)                                    # :26
-    st.eta = dot(st.w, st.r)                                   # :27
-    st.s = A @ st.p                                            # :28
-    st.u = st.s.copy()                                         # :29
-    st.mu = dot(st.p, st.s)                                    # :30
-    st.alpha = st.nu / st.mu                                   # :31
+    st.r = b - A @ st.x                                        # cg_cg.py:23 / :88
+    st.rt = np.array(M(st.r), copy=True) if prec else None     # :89
+    z = st.rt if prec else st.r
+    st.w = A @ z                                               # :24 / :90
+    st.p = z.copy()                                            # :25 / :91
+    st.nu = dot(st.r, z)                                       # :26 / :92
+    st.eta = dot(st.w, z)                                      # :27 / :93
+    st.s = A @ st.p                                            # :28 / :94
+    st.u = st.s.copy()                                         # :29 / :95
+    st.mu = dot(st.p, st.s)                                    # :30 / :96
+    st.alpha = st.nu / st.mu                                   # :31 / :97
     return st
 
 
 def cgcg_advance(A, st, prec=None, dot=np.dot):
+    M = prec or _ident
     a = st.alpha
     nu_old = st.nu
-    st.x = st.x + a * st.p                                     # :59
-    st.r = st.r - a * st.s                                     # :60
-    st.w = A @ st.r                                            # :61
-    st.nu = dot(st.r, st.r)                                    # :62
-    st.eta = dot(st.w, st.r)                                   # :63
-    st.beta = st.nu / nu_old                                   # :64
-    st.p = st.r + st.beta * st.p                               # :65
-    st.s = st.w + st.beta * st.s                               # :66
-    st.mu = st.eta - (st.beta / a) * st.nu                     # :67
-    st.alpha = st.nu / st.mu                                   # :68
+    st.x = st.x + a * st.p                                     # :59 / :127
+    st.r = st.r - a * st.s                                     # :60 / :128
+    if prec:
+        st.rt = np.array(M(st.r), copy=True)                   # :129
+    z = st.rt if prec else st.r
+    st.w = A @ z                                               # :61 / :130
+    st.nu = dot(st.r, z)                                       # :62 / :131
+    st.eta = dot(st.w, z)                                      # :63 / :132
+    st.beta = st.nu / nu_old                                   # :64 / :133
+    st.p = z + st.beta * st.p                                  # :65 / :134
+    st.s = st.w + st.beta * st.s                               # :66 / :135
+    st.mu = st.eta - (st.beta / a) * st.nu                     # :67 / :136
+    st.alpha = st.nu / st.mu                                   # :68 / :137
     st.k += 1
     return st
 
 
 def gv_start(A, b, x0, prec=None, dot=np.dot):
-    assert prec is None
     st = State()
     st.x = np.array(x0, dtype=np.float64, copy=True)
-    st.r = b - A @ st.x                                        # gv_cg.py:26
-    st.w = A @ st.r                                            # :27
-    st.p = st.r.copy()                                         # :28
-    st.s = st.w.copy()                                         # :29
-    st.u = A @ st.w                                            # :30
-    st.nu = dot(st.r, st.r)                                    # :31
-    st.eta = dot(st.w, st.r)                                   # :32
-    st.mu = dot(st.p, st.s)                                    # :33
-    st.alpha = st.nu / st.mu                                   # :34
+    st.r = b - A @ st.x                                        # gv_cg.py:26 / :107
+    if prec is None:
+        st.w = A @ st.r                                        # :27
+        st.p = st.r.copy()                                     # :28
+        st.s = st.w.copy()                                     # :29
+        st.u = A @ st.w                                        # :30
+        st.nu = dot(st.r, st.r)                                # :31
+        st.eta = dot(st.w, st.r)                               # :32
+    else:
+        st.rt = np.array(prec(st.r), copy=True)                # :108
+        st.w = A @ st.rt                                       # :109
+        st.wt = np.array(prec(st.w), copy=True)                # :110
+        st.p = st.rt.copy()                                    # :111
+        st.s = st.w.copy()                                     # :112
+        st.st = st.wt.copy()                                   # :113
+        st.u = A @ st.wt                                       # :114
+        st.nu = dot(st.r, st.rt)                               # :115
+        st.eta = dot(st.w, st.r)                               # :116  (r, not r~ -- as the reference has it)
+    st.mu = dot(st.p, st.s)                                    # :33 / :117
+    st.alpha = st.nu / st.mu                                   # :34 / :118
     return st
 
 
 def gv_advance(A, st, prec=None, dot=np.dot):
     a = st.alpha
     nu_old = st.nu
-    st.x = st.x + a * st.p                                     # :65
-    st.r = st.r - a * st.s                                     # :66
-    st.w = st.w - a * st.u                                     # :67
-    t = A @ st.w                                               # :73
-    st.nu = dot(st.r, st.r)                                    # :74
-    st.eta = dot(st.w, st.r)                                   # :75
-    st.beta = st.nu / nu_old                                   # :76
-    st.p = st.r + st.beta * st.p                               # :77
-    st.s = st.w + st.beta * st.s                               # :78
-    st.u = t + st.beta * st.u                                  # :79
-    st.mu = st.eta - (st.beta / a) * st.nu                     # :80
-    st.alpha = st.nu / st.mu                                   # :81
+    st.x = st.x + a * st.p                                     # :65 / :152
+    st.r = st.r - a * st.s                                     # :66 / :153
+    if prec is None:
+        st.w = st.w - a * st.u                                 # :67
+        t = A @ st.w                                           # :73
+        st.nu = dot(st.r, st.r)                                # :74
+        st.eta = dot(st.w, st.r)                               # :75
+        z, zt = st.r, st.w
+    else:
+        st.rt = st.rt - a * st.st                              # :154
+        st.w = st.w - a * st.u                                 # :155
+        st.wt = np.array(prec(st.w), copy=True)                # :161
+        t = A @ st.wt                                          # :162
+        st.nu = dot(st.r, st.rt)                               # :163
+        st.eta = dot(st.w, st.rt)                              # :164
+        z, zt = st.rt, st.wt
+    st.beta = st.nu / nu_old                                   # :76 / :165
+    st.p = z + st.beta * st.p                                  # :77 / :166
+    st.s = st.w + st.beta * st.s                               # :78 / :167
+    if prec is not None:
+        st.st = zt + st.beta * st.st                           # :168
+    st.u = t + st.beta * st.u                                  # :79 / :169
+    st.mu = st.eta - (st.beta / a) * st.nu                     # :80 / :170
+    st.alpha = st.nu / st.mu                                   # :81 / :171
     st.k += 1
     return st
 
@@ -418,7 +446,9 @@ pipe_pr_pcg = _public('pipe', 'pr', 'pipe_pr_pcg', True)       # :201
 pipe_p_m_pcg = _public('pipe', 'p_m', 'pipe_p_m_pcg', True)    # :207
 pipe_pr_m_pcg = _public('pipe', 'pr_m', 'pipe_pr_m_pcg', True) # :213
 cg_cg = _public('cg_cg', None, 'cg_cg', False)                 # NE/cg_variants/cg_cg.py:9
+cg_pcg = _public('cg_cg', None, 'cg_pcg', True)                # :76
 gv_cg = _public('gv', None, 'gv_cg', False)                    # NE/cg_variants/gv_cg.py:9
+gv_pcg = _public('gv', None, 'gv_pcg', True)                    # :93
 
 
 def convergence_summary(error_A_norm_history, tol=1e-5):

@@ -30,7 +30,7 @@ def load_run(matrix, method, prec):
 def golden_state(run, k):
     """dict of the stored reference iterate at k (vectors and scalars)."""
     out = {}
-    for f in ('x', 'r', 'p', 's', 'w', 'u', 'rt', 'st', 'wt', 'ut', 'nu', 'mu', 'dl', 'gm', 'alpha', 'beta'):
+    for f in ('x', 'r', 'p', 's', 'w', 'u', 'rt', 'st', 'wt', 'ut', 'nu', 'mu', 'dl', 'gm', 'eta', 'alpha', 'beta'):
         key = f'state{k}_{f}'
         if key in run.files:
             out[f] = run[key]

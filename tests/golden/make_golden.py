@@ -59,10 +59,10 @@ def problem(A):
 
 
 STATE_VECS = ['x', 'r', 'p', 's', 'w', 'u', 'rt', 'st', 'wt', 'ut']
-STATE_SCAL = ['nu', 'mu', 'dl', 'gm', 'alpha', 'beta']
+STATE_SCAL = ['nu', 'mu', 'dl', 'gm', 'eta', 'alpha', 'beta']
 REF_NAMES = {'x': 'x_k', 'r': 'r_k', 'p': 'p_k', 's': 's_k', 'w': 'w_k', 'u': 'u_k',
              'rt': 'rt_k', 'st': 'st_k', 'wt': 'wt_k', 'ut': 'ut_k',
-             'nu': 'nu_k', 'mu': 'mu_k', 'dl': 'del_k', 'gm': 'gam_k', 'alpha': 'a_k', 'beta': 'b_k'}
+             'nu': 'nu_k', 'mu': 'mu_k', 'dl': 'del_k', 'gm': 'gam_k', 'eta': 'eta_k', 'alpha': 'a_k', 'beta': 'b_k'}
 
 
 def ref_state_grabber(store, ks):
@@ -222,6 +222,12 @@ def main():
         ('bcsstk03', 'pr_pcg', 250, 'jacobi', pairs([0, 1, 10, 100, 200])),
         ('bcsstk03', 'pipe_pr_pcg', 250, 'jacobi', pairs([0, 1, 10, 100, 200])),
         ('bcsstk03', 'pipe_p_pcg', 250, 'jacobi', pairs([0, 1, 10, 100])),
+        ('bcsstk03', 'cg_pcg', 250, 'jacobi', pairs([0, 1, 10, 100, 200])),
+        ('bcsstk03', 'gv_pcg', 250, 'jacobi', pairs([0, 1, 10, 100, 200])),
+        ('nos7', 'cg_cg', 1000, None, pairs(few_n)),
+        ('nos7', 'gv_cg', 1000, None, pairs(few_n)),
+        ('nos7', 'cg_pcg', 200, 'jacobi', pairs([0, 1, 10, 66, 150])),
+        ('nos7', 'gv_pcg', 200, 'jacobi', pairs([0, 1, 10, 66, 150])),
         ('nos7', 'hs_cg', 7000, None, pairs(sparse_n)),
         ('nos7', 'pipe_pr_cg', 7000, None, pairs(sparse_n)),
         ('nos7', 'pr_pcg', 1000, None, pairs(few_n)),

@@ -130,14 +130,18 @@ def test_spmv_full_size_properties(amd):
 # ---------------------------------------------------------------------------------------
 VARIANT_OF = {'hs_cg': 'HS', 'hs_pcg': 'HS', 'pipe_pr_cg': 'PIPE_PR', 'pipe_pr_pcg': 'PIPE_PR',
               'pipe_p_cg': 'PIPE_P', 'pipe_p_pcg': 'PIPE_P', 'pipe_pr_m_cg': 'PIPE_PR_M',
-              'pipe_p_m_cg': 'PIPE_P_M', 'pr_pcg': 'PR', 'm_pcg': 'M'}
+              'pipe_p_m_cg': 'PIPE_P_M', 'pr_pcg': 'PR', 'm_pcg': 'M',
+              'cg_cg': 'CG_CG', 'cg_pcg': 'CG_CG', 'gv_cg': 'GV', 'gv_pcg': 'GV'}
 FORCED = [('bcsstk03', 'hs_cg', 'None'), ('bcsstk03', 'pipe_pr_cg', 'None'), ('nos7', 'hs_cg', 'None'),
           ('nos7', 'pipe_pr_cg', 'None'), ('bcsstk03', 'pr_pcg', 'None'), ('bcsstk03', 'm_pcg', 'None'),
           ('bcsstk03', 'pipe_p_cg', 'None'), ('bcsstk03', 'pipe_pr_m_cg', 'None'),
           ('bcsstk03', 'pipe_p_m_cg', 'None'), ('nos7', 'pr_pcg', 'None'), ('nos7', 'pipe_p_cg', 'None'),
           ('bcsstk03', 'hs_pcg', 'jacobi'), ('bcsstk03', 'pr_pcg', 'jacobi'),
           ('bcsstk03', 'pipe_pr_pcg', 'jacobi'), ('bcsstk03', 'pipe_p_pcg', 'jacobi'),
-          ('nos7', 'hs_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi')]
+          ('nos7', 'hs_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi'),
+          ('bcsstk03', 'cg_cg', 'None'), ('bcsstk03', 'gv_cg', 'None'), ('nos7', 'cg_cg', 'None'),
+          ('nos7', 'gv_cg', 'None'), ('bcsstk03', 'cg_pcg', 'jacobi'), ('bcsstk03', 'gv_pcg', 'jacobi'),
+          ('nos7', 'cg_pcg', 'jacobi'), ('nos7', 'gv_pcg', 'jacobi')]
 
 
 @pytest.mark.parametrize('matrix,method,prec', FORCED)
@@ -183,6 +187,8 @@ def test_teacher_forced_single_step(amd, matrices, matrix, method, prec):
                 if f in ('dl', 'gm') and VARIANT_OF[method] == 'HS':
                     continue
                 err = srel(got_sc[slot], float(v))
+            elif f == 'eta':
+                err = srel(got_sc[L.S_DELTA], float(v))
             elif f == 'beta':
                 err = srel(op.get_coefficients(k + 1)[1], float(v))
             elif f == 'alpha':
@@ -210,6 +216,9 @@ PUBLISHED = {
     ('nos7', 'None', 'hs_cg'): (2869, -9.01), ('nos7', 'None', 'pipe_pr_cg'): (2899, -7.24),
     ('bcsstk03', 'jacobi', 'hs_pcg'): (118, -14.10), ('bcsstk03', 'jacobi', 'pipe_pr_pcg'): (121, -13.50),
     ('nos7', 'jacobi', 'hs_pcg'): (67, -8.91), ('nos7', 'jacobi', 'pipe_pr_pcg'): (67, -9.41),
+    ('bcsstk03', 'None', 'cg_cg'): (439, -14.49), ('bcsstk03', 'None', 'gv_cg'): (598, -6.86),
+    ('bcsstk03', 'jacobi', 'cg_pcg'): (118, -14.11), ('bcsstk03', 'jacobi', 'gv_pcg'): (120, -9.48),
+    ('nos7', 'jacobi', 'cg_pcg'): (67, -9.21), ('nos7', 'jacobi', 'gv_pcg'): (67, -6.41),
 }
 
 # Free-running prefix on which 1e-12 holds.  It is set by how fast these ill-conditioned
@@ -220,7 +229,9 @@ PREFIX = {'bcsstk03': 6, 'nos7': 12}
 FREE = [('bcsstk03', 'hs_cg', 'None'), ('bcsstk03', 'pipe_pr_cg', 'None'), ('nos7', 'hs_cg', 'None'),
         ('nos7', 'pipe_pr_cg', 'None'), ('bcsstk03', 'pr_pcg', 'None'), ('bcsstk03', 'pipe_p_cg', 'None'),
         ('bcsstk03', 'pipe_pr_m_cg', 'None'), ('bcsstk03', 'hs_pcg', 'jacobi'),
-        ('bcsstk03', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'hs_pcg', 'jacobi')]
+        ('bcsstk03', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'pipe_pr_pcg', 'jacobi'), ('nos7', 'hs_pcg', 'jacobi'),
+        ('bcsstk03', 'cg_cg', 'None'), ('bcsstk03', 'gv_cg', 'None'), ('bcsstk03', 'cg_pcg', 'jacobi'),
+        ('bcsstk03', 'gv_pcg', 'jacobi'), ('nos7', 'cg_pcg', 'jacobi'), ('nos7', 'gv_pcg', 'jacobi')]
 
 
 @pytest.mark.parametrize('matrix,method,prec', FREE)
@@ -413,8 +424,8 @@ def test_figure_run_reproduces_the_reference_table_row(amd, tmp_path):
     assert saved['name'] == 'pipe_pr_pcg' and saved['max_iter'] == 1250
     assert set(saved) >= {'error_A_norm', 'residual_2_norm', 'error_2_norm', 'updated_residual_2_norm'}
     # published row: hs 364 / m 425 / pr 380 / pipe_pr_m 492 / pipe_pr 411; -14.55 -14.40 -14.43 -12.65 -12.96
-    published = {'hs_pcg': (364, -14.55), 'm_pcg': (425, -14.40), 'pr_pcg': (380, -14.43),
-                 'pipe_pr_m_pcg': (492, -12.65), 'pipe_pr_pcg': (411, -12.96)}
+    published = {'hs_pcg': (364, -14.55), 'cg_pcg': (439, -14.49), 'm_pcg': (425, -14.40), 'pr_pcg': (380, -14.43),
+                 'gv_pcg': (598, -6.86), 'pipe_pr_m_pcg': (492, -12.65), 'pipe_pr_pcg': (411, -12.96)}
     for m, (its_pub, acc_pub) in published.items():
         its, acc = fr.summarize(trials[m])
         assert abs(its - its_pub) <= 0.10 * its_pub, (m, its, its_pub)

@@ -24,7 +24,7 @@ METHODS = {
     'hs_cg': ('hs', None), 'hs_pcg': ('hs', None), 'pr_pcg': ('pr', 'pr'), 'm_pcg': ('pr', 'm'),
     'pipe_p_cg': ('pipe', 'p'), 'pipe_pr_cg': ('pipe', 'pr'), 'pipe_p_m_cg': ('pipe', 'p_m'),
     'pipe_pr_m_cg': ('pipe', 'pr_m'), 'pipe_p_pcg': ('pipe', 'p'), 'pipe_pr_pcg': ('pipe', 'pr'),
-    'cg_cg': ('cg_cg', None), 'gv_cg': ('gv', None),
+    'cg_cg': ('cg_cg', None), 'gv_cg': ('gv', None), 'cg_pcg': ('cg_cg', None), 'gv_pcg': ('gv', None),
 }
 
 
