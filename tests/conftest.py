@@ -37,6 +37,28 @@ def golden_state(run, k):
     return out
 
 
+class _LazyMatrices(dict):
+    def __missing__(self, name):
+        self[name] = load_matrix(name)
+        return self[name]
+
+
 @pytest.fixture(scope='session')
 def matrices():
-    return {m: load_matrix(m) for m in ('bcsstk03', 'nos7')}
+    """name -> (CSR matrix, fixture arrays) for every tests/golden/matrix_<name>.npz, loaded on demand."""
+    return _LazyMatrices()
+
+
+def all_runs():
+    """(matrix, method, prec) of every golden run file."""
+    import glob
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, 'run_*.npz'))):
+        tag = os.path.basename(p)[4:-4]
+        for m in sorted((os.path.basename(q)[7:-4] for q in glob.glob(os.path.join(GOLDEN, 'matrix_*.npz'))),
+                        key=len, reverse=True):
+            if tag.startswith(m + '_'):
+                method, prec = tag[len(m) + 1:].rsplit('_', 1)
+                out.append((m, method, prec))
+                break
+    return out

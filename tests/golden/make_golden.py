@@ -196,7 +196,7 @@ def mp_goldens():
 
 def main():
     print('numpy', np.__version__, 'scipy', scipy.__version__)
-    mats = {m: load_matrix(m) for m in ('bcsstk03', 'nos7')}
+    mats = {m: load_matrix(m) for m in ('bcsstk03', 'nos7', 'nos4', '494_bus', 'bcsstk14', 'bcsstm22', 'model_48_8_3')}
     for m, A in mats.items():
         assert A.has_sorted_indices and A.indices.dtype == np.int32
         matrix_fixture(m, A)
@@ -228,6 +228,22 @@ def main():
         ('nos7', 'gv_cg', 1000, None, pairs(few_n)),
         ('nos7', 'cg_pcg', 200, 'jacobi', pairs([0, 1, 10, 66, 150])),
         ('nos7', 'gv_pcg', 200, 'jacobi', pairs([0, 1, 10, 66, 150])),
+        # further matrices of the paper's list (max_iter: NE/figure_gen.py:247-339), histories + a few states
+        ('nos4', 'hs_pcg', 150, None, pairs([0, 5, 60])),
+        ('nos4', 'pipe_pr_pcg', 150, None, pairs([0, 5, 60])),
+        ('nos4', 'pipe_pr_pcg', 120, 'jacobi', pairs([0, 5, 60])),
+        ('494_bus', 'hs_pcg', 2500, None, pairs([0, 7, 900])),
+        ('494_bus', 'pipe_pr_pcg', 2500, None, pairs([0, 7, 900])),
+        ('494_bus', 'pr_pcg', 500, 'jacobi', pairs([0, 7, 300])),
+        ('494_bus', 'pipe_pr_pcg', 500, 'jacobi', pairs([0, 7, 300])),
+        ('bcsstk14', 'hs_pcg', 800, 'jacobi', pairs([0, 9, 400])),
+        ('bcsstk14', 'pipe_pr_pcg', 800, 'jacobi', pairs([0, 9, 400])),
+        ('bcsstk14', 'gv_pcg', 800, 'jacobi', pairs([0, 9])),
+        ('bcsstm22', 'hs_pcg', 85, None, pairs([0, 20])),
+        ('bcsstm22', 'pipe_pr_pcg', 85, None, pairs([0, 20])),
+        ('model_48_8_3', 'hs_pcg', 110, None, pairs([0, 30])),
+        ('model_48_8_3', 'pipe_pr_pcg', 110, None, pairs([0, 30])),
+        ('model_48_8_3', 'pipe_pr_pcg', 200, 'jacobi', pairs([0, 30])),
         ('nos7', 'hs_cg', 7000, None, pairs(sparse_n)),
         ('nos7', 'pipe_pr_cg', 7000, None, pairs(sparse_n)),
         ('nos7', 'pr_pcg', 1000, None, pairs(few_n)),

@@ -13,11 +13,11 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_state, load_matrix, load_run
+from conftest import GOLDEN, all_runs, golden_state, load_matrix, load_run
 from oracle import mp_oracle, ne_oracle as orc
 
 FOUR = ['error_A_norm', 'residual_2_norm', 'error_2_norm', 'updated_residual_2_norm']
-RUNS = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, 'run_*.npz')))
+RUNS = ['|'.join(r) for r in all_runs()]
 
 # method -> (family, flavour)
 METHODS = {
@@ -29,9 +29,7 @@ METHODS = {
 
 
 def split_tag(tag):
-    matrix, rest = tag.split('_', 1)
-    method, prec = rest.rsplit('_', 1)
-    return matrix, method, prec
+    return tuple(tag.split('|'))
 
 
 def rel(a, b):
@@ -42,7 +40,8 @@ def rel(a, b):
 
 
 def test_spmv_known_answers(matrices):
-    for name, (A, z) in matrices.items():
+    for name in sorted({r[0] for r in all_runs()}):
+        A, z = matrices[name]
         for i in range(z['spmv_x'].shape[0]):
             assert np.array_equal(A @ z['spmv_x'][i], z['spmv_y'][i]), name
         # problem setup of figure_gen.py:31-34
@@ -62,7 +61,7 @@ def test_free_running_prefix_and_convergence(tag, matrices):
     out = getattr(orc, method)(A, z['b'], np.zeros(A.shape[0]), max_iter, callbacks=FOUR,
                                x_true=z['x_true'], **kw)
     assert out['name'] == str(run['name'])
-    prefix = 7 if matrix == "bcsstk03" else 14
+    prefix = {"bcsstk03": 7, "nos7": 14}.get(matrix, 5)
     for q in FOUR:
         ref = run['hist_' + q]
         assert out[q].shape == ref.shape == (max_iter,)
@@ -77,7 +76,7 @@ def test_free_running_prefix_and_convergence(tag, matrices):
         assert its == 0
 
 
-@pytest.mark.parametrize('tag', [t for t in RUNS if len(np.load(os.path.join(GOLDEN, f'run_{t}.npz'))['state_ks'])])
+@pytest.mark.parametrize('tag', [t for t in RUNS if len(load_run(*t.split('|'))['state_ks'])])
 def test_teacher_forced_single_step(tag, matrices):
     matrix, method, prec_name = split_tag(tag)
     family, flavour = METHODS[method]
@@ -103,6 +102,8 @@ def test_teacher_forced_single_step(tag, matrices):
         for f, v in g1.items():
             if f == 'beta' and k + 1 == 0:
                 continue
+            if prec is None and f in ('rt', 'st', 'wt', 'ut'):
+                continue    # identity preconditioner: the oracle does not carry tilde copies
             got = getattr(st, f)
             if got is None:
                 continue
