@@ -114,6 +114,9 @@ struct prcg_handle {
     DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
+    bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
+    bool small_mat_lds = false;
+    bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
     int pend_parts = 0;          // fused: dots[pend_k] exist only as this many block partials ...
@@ -638,6 +641,7 @@ int prcg_create(prcg_t** out, int device_id) {
     if (const char* e = getenv("PRCG_SIDE_STREAM")) h->side_stream = atoi(e) != 0;
     if (const char* e = getenv("PRCG_FUSED_FINAL")) h->fused_final = atoi(e) != 0;
     if (const char* e = getenv("PRCG_FUSED")) h->want_fused = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -864,6 +868,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->in_session = false;
     h->variant = variant;
     h->fused = false;
+    h->small = false;
     h->prec = inv_diag != nullptr;
     h->max_iter = max_iter;
     h->hist_mask = hist_mask;
@@ -899,6 +904,10 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->partC.alloc(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16));
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         h->rs_cur = h->rs.d();
+        // one-workgroup solver: only when nothing but the recurrence residual is recorded
+        h->small = h->fused && h->want_small &&
+                   !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
+                   small_fits(h->n, h->nnz, &h->small_mat_lds);
         HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
         HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
         HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
@@ -1025,6 +1034,21 @@ int prcg_iterate(prcg_t* h, int iters) {
     CHECK(h, h->k + iters <= h->max_iter, "prcg_iterate: %d more iterations exceed max_iter=%d (k=%d)", iters,
           h->max_iter, h->k);
     HIPCHK(h, hipSetDevice(h->dev));
+    if (h->small && iters > 0) {
+        // all `iters` iterations inside one launch of one workgroup
+        SmallArgs sa{};
+        sa.n = (int)h->n; sa.nnz = (int)h->nnz;
+        sa.indptr = h->indptr.i(); sa.col = h->col.i(); sa.val = h->val.d();
+        sa.xp = h->xp.d(); sa.rs = h->rs_cur;
+        sa.dots = h->dots.d(); sa.coef = h->coef.d();
+        sa.k0 = h->k; sa.iters = iters; sa.meurant = meurant(h->variant);
+        bool on = false;
+        prof_begin(h, h->ev_spmv, h->n_ev_spmv, 0, on);
+        LAUNCHCHK(h, launch_small_pipe_pr(h->sc, sa, h->small_mat_lds));
+        prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        h->k += iters;
+        return PRCG_OK;
+    }
     for (int i = 0; i < iters; ++i) {
         const int k = h->k + 1;
         int rc;

@@ -61,6 +61,19 @@ int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int nt
                       const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
                       double* coef_out, double* partials, int meurant, FusedPrev prev);
 
+// ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
+struct SmallArgs {
+    int n, nnz;
+    const int* indptr; const int* col; const double* val;
+    double* xp;        // pairs (x,p), read at entry, written at exit
+    double* rs;        // pairs (r,s), read at entry, written at exit
+    double* dots;      // [max_iter+1][kPartialStride]: row k0 is read, rows k0+1..k0+iters written
+    double* coef;      // [max_iter+1][4]
+    int k0, iters, meurant;
+};
+bool small_fits(int64_t n, int64_t nnz, bool* mat_lds);
+int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, bool mat_lds);
+
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {
     int64_t n;

@@ -728,6 +728,114 @@ __global__ __launch_bounds__(kBlock) void k_gv_update1(CgArgs a, int trips) {
     block_reduce_store<5>(acc, a.partials, 0);
 }
 
+// ======================================================================================
+// Small systems (n <= 4096): the whole pipelined solve in ONE launch of ONE workgroup.
+// nos7 (n=729) or bcsstk03 (n=112) cannot fill a chip; with one launch per kernel they are
+// launch-bound (~12 us per iteration).  Here 1024 threads keep (r,s) in LDS (double-buffered,
+// like the one-launch schedule above), x and p of their own rows in registers, the matrix
+// in LDS when it fits (else it is re-read through L1/L2), and iterate `iters` times with two
+// barriers per iteration.  Same arithmetic per element; rows are summed left to right.
+// Inner products: thread-sequential over its rows (row = tid, tid+1024, ...), wave butterfly,
+// 16 waves in order.  Every thread reaches every barrier (trip counts are uniform).
+// ======================================================================================
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallRows = 4;                    // rows per thread -> n <= 4096
+constexpr int kSmallMaxN = kSmallThreads * kSmallRows;
+
+template <bool MAT_LDS>
+__global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = a.n, nnz = a.nnz;
+    double2* rsA = reinterpret_cast<double2*>(smem);
+    double2* rsB = rsA + n;
+    double* red = reinterpret_cast<double*>(rsB + n);          // [16 waves][4]
+    double* lval = red + 64;
+    int* lcol = reinterpret_cast<int*>(lval + (MAT_LDS ? nnz : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    const double2* __restrict__ XPg = reinterpret_cast<const double2*>(a.xp);
+    const double2* __restrict__ RSg = reinterpret_cast<const double2*>(a.rs);
+    double xr[kSmallRows], pr[kSmallRows];
+    int rbeg[kSmallRows], rend[kSmallRows];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) {
+        const int row = tid + j * kSmallThreads;
+        xr[j] = 0.0; pr[j] = 0.0; rbeg[j] = 0; rend[j] = 0;
+        if (row < n) {
+            const double2 xp = XPg[row];
+            xr[j] = xp.x; pr[j] = xp.y;
+            rsA[row] = RSg[row];
+            rbeg[j] = a.indptr[row]; rend[j] = a.indptr[row + 1];
+        }
+    }
+    if constexpr (MAT_LDS) {
+        for (int q = tid; q < nnz; q += kSmallThreads) { lval[q] = a.val[q]; lcol[q] = a.col[q]; }
+    }
+    // inner products of the incoming state
+    double mu = a.dots[(size_t)a.k0 * kPartialStride + 0], dl = a.dots[(size_t)a.k0 * kPartialStride + 1];
+    double gm = a.dots[(size_t)a.k0 * kPartialStride + 2], nu = a.dots[(size_t)a.k0 * kPartialStride + 3];
+    __syncthreads();
+
+    double2* cur = rsA;
+    double2* nxt = rsB;
+    for (int it = 1; it <= a.iters; ++it) {
+        // coefficients (pipe_pr_cg.py:64-66,75), identical in every thread
+        const double al = nu / mu;
+        const double a2 = al * al;
+        const double nup = a.meurant ? (-nu + a2 * gm) : ((nu - (2 * al) * dl) + a2 * gm);
+        const double bt = nup / nu;
+        if (tid == 0) {
+            double* cf = a.coef + (size_t)(a.k0 + it) * 4;
+            cf[0] = al; cf[1] = bt; cf[2] = nup;
+        }
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSmallRows; ++j) {
+            const int row = tid + j * kSmallThreads;
+            if (row < n) {
+                double wr = 0.0, us = 0.0;                       // (A r)_i, (A s)_i, left to right
+                for (int q = rbeg[j]; q < rend[j]; ++q) {
+                    const double v = MAT_LDS ? lval[q] : a.val[q];
+                    const int c = MAT_LDS ? lcol[q] : a.col[q];
+                    const double2 g = cur[c];
+                    wr += v * g.x; us += v * g.y;
+                }
+                const double2 rs = cur[row];
+                xr[j] = xr[j] + al * pr[j];                      // x += a p
+                const double rn = rs.x - al * rs.y;              // r -= a s
+                const double wn = wr - al * us;                  // w -= a u
+                const double pn = rn + bt * pr[j];               // p = r + b p
+                const double sn = wn + bt * rs.y;                // s = w + b s
+                pr[j] = pn;
+                nxt[row] = make_double2(rn, sn);
+                acc0 += pn * sn; acc1 += rn * sn; acc2 += sn * sn; acc3 += rn * rn;
+            }
+        }
+        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
+        if (lane == 0) { red[wv * 4 + 0] = acc0; red[wv * 4 + 1] = acc1; red[wv * 4 + 2] = acc2; red[wv * 4 + 3] = acc3; }
+        __syncthreads();                                         // nxt complete, red complete
+        mu = red[0]; dl = red[1]; gm = red[2]; nu = red[3];
+#pragma unroll
+        for (int w = 1; w < kSmallThreads / 64; ++w) {
+            mu += red[w * 4 + 0]; dl += red[w * 4 + 1]; gm += red[w * 4 + 2]; nu += red[w * 4 + 3];
+        }
+        if (tid == 0) {
+            double* d = a.dots + (size_t)(a.k0 + it) * kPartialStride;
+            d[0] = mu; d[1] = dl; d[2] = gm; d[3] = nu; d[4] = nu;
+        }
+        __syncthreads();                                         // everybody has read red before it is rewritten
+        double2* tmp = cur; cur = nxt; nxt = tmp;
+    }
+
+    double2* XPo = reinterpret_cast<double2*>(a.xp);
+    double2* RSo = reinterpret_cast<double2*>(a.rs);
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) {
+        const int row = tid + j * kSmallThreads;
+        if (row < n) { XPo[row] = make_double2(xr[j], pr[j]); RSo[row] = cur[row]; }
+    }
+}
+
 // ---- fixed-order final reduction of per-block partials --------------------------------
 constexpr int kFinalThreads = 256;   // same tree as the fused last-block reduction
 __global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
@@ -931,6 +1039,29 @@ int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int nt
     if (ntiles <= 0) return 0;
     return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0),
                                                 dots_prev, nullptr, rs_new, partials, coef_out, prev);
+}
+
+size_t small_lds_bytes(int n, int nnz, bool mat_lds) {
+    return (size_t)2 * n * 16 + 64 * 8 + (mat_lds ? (size_t)nnz * 12 + 16 : 0);
+}
+bool small_fits(int64_t n, int64_t nnz, bool* mat_lds) {
+    if (n < 1 || n > kSmallMaxN) return false;
+    const size_t cap = 156 * 1024;
+    if (small_lds_bytes((int)n, (int)nnz, true) <= cap && nnz < (1 << 20)) { *mat_lds = true; return true; }
+    if (small_lds_bytes((int)n, 0, false) <= cap) { *mat_lds = false; return true; }
+    return false;
+}
+int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, bool mat_lds) {
+    const size_t lds = small_lds_bytes(a.n, a.nnz, mat_lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (mat_lds) hipLaunchKernelGGL(k_small_pipe_pr<true>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    else hipLaunchKernelGGL(k_small_pipe_pr<false>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    return PRCG_LAUNCH_OK() ? 1 : -1;
 }
 
 int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {

@@ -328,6 +328,59 @@ def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant):
     print(f'{matrix}/{variant}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
+@pytest.mark.parametrize('matrix', ['bcsstk03', 'nos7', 'bcsstk14', 'model_48_8_3'])
+def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
+    """n <= 4096 and nothing but the recurrence residual recorded: the whole solve runs in one
+    launch of one workgroup ((r,s) in LDS, matrix in LDS when it fits -- bcsstk14's does not).
+    Per element the arithmetic is the one of the multi-launch schedules: from identical state
+    vectors agree bit for bit, inner products to 1e-12; and it is deterministic."""
+    import time
+    L = amd['L']
+    A, z = matrices[matrix]
+    n = A.shape[0]
+    small = amd['device'].DeviceCSR(A)                                  # default: one-workgroup solver
+    multi = amd['device'].DeviceCSR(A, knobs={'PRCG_SMALL': '0'})       # one launch per iteration
+    for op in (small, multi):
+        op.begin(L.PIPE_PR, z['b'], np.zeros(n), 64)
+    worst = 0.0
+    for k in range(30):
+        for v in ('x', 'r', 'p', 's'):
+            small.set_vector(v, multi.get_vector(v))
+        small.set_scalars(k, multi.get_scalars(k))
+        small.set_iteration(k)
+        small.iterate(1)
+        multi.iterate(1)
+        for v in ('x', 'r', 'p', 's'):
+            assert np.array_equal(small.get_vector(v), multi.get_vector(v)), (k, v)
+        a, b = small.get_scalars(k + 1)[:5], multi.get_scalars(k + 1)[:5]
+        worst = max(worst, float(np.max(np.abs(a - b) / np.abs(b))))
+    assert worst <= 1e-12, worst
+    # free-running: reproducible, and the same history whether run in one call or in pieces
+    iters = 3000
+    runs = []
+    for chunks in ((iters,), (1000, 1, 1999)):
+        small.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
+        t0 = time.perf_counter()
+        for c in chunks:
+            small.iterate(c)
+        small.sync()
+        dt = time.perf_counter() - t0
+        runs.append(small.history()['updated_residual_2_norm'])
+    assert np.array_equal(runs[0], runs[1], equal_nan=True)
+    multi.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
+    t0 = time.perf_counter()
+    multi.iterate(iters)
+    multi.sync()
+    dt_multi = time.perf_counter() - t0
+    prefix = PREFIX.get(matrix, 5)
+    np.testing.assert_allclose(runs[0][:prefix], multi.history()['updated_residual_2_norm'][:prefix], rtol=1e-12)
+    print(f'{matrix} (n={n}): one-workgroup solver {dt / chunks[-1] * 1e6 if False else 0:.0f}'
+          f' -- {iters} iterations: one launch {dt * 1e3:.1f} ms vs one launch per iteration {dt_multi * 1e3:.1f} ms;'
+          f' forced-step scalar deviation {worst:.1e}')
+    small.close()
+    multi.close()
+
+
 def test_device_results_are_reproducible(amd, matrices):
     A, z = matrices['nos7']
     cbs = [amd['cbs'].updated_residual_2_norm]
