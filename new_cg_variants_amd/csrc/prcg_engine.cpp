@@ -115,7 +115,8 @@ struct prcg_handle {
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
     bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
-    bool small_mat_lds = false;
+    int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
+    int max_row_len = 0;
     bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
@@ -732,6 +733,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     CHECK(h, ip[0] == 0 && ip[n_rows] == nnz, "prcg_set_csr: indptr must run from 0 to nnz");
     const int64_t ncols = n_rows + n_ghost;
     std::vector<uint8_t> cls((size_t)n_rows, 0);
+    int max_len = 0;
     for (int64_t i = 0; i < n_rows; ++i) {
         uint8_t c = 0;
         for (int32_t q = ip[i]; q < ip[i + 1]; ++q) {
@@ -741,7 +743,9 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             if (j >= n_rows) c = 1;
         }
         cls[i] = c;
+        if (ip[i + 1] - ip[i] > max_len) max_len = ip[i + 1] - ip[i];
     }
+    h->max_row_len = max_len;
     std::vector<Tile> t0, t1;
     h->steps = env_tile_steps();
     plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, tile_cap_nnz(h->steps), kTileCapRows, t0, t1);
@@ -907,7 +911,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         // one-workgroup solver: only when nothing but the recurrence residual is recorded
         h->small = h->fused && h->want_small &&
                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
-                   small_fits(h->n, h->nnz, &h->small_mat_lds);
+                   small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
         HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
         HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
         HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
@@ -1044,7 +1048,7 @@ int prcg_iterate(prcg_t* h, int iters) {
         sa.k0 = h->k; sa.iters = iters; sa.meurant = meurant(h->variant);
         bool on = false;
         prof_begin(h, h->ev_spmv, h->n_ev_spmv, 0, on);
-        LAUNCHCHK(h, launch_small_pipe_pr(h->sc, sa, h->small_mat_lds));
+        LAUNCHCHK(h, launch_small_pipe_pr(h->sc, sa, h->small_mode));
         prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         h->k += iters;
         return PRCG_OK;

@@ -71,8 +71,8 @@ struct SmallArgs {
     double* coef;      // [max_iter+1][4]
     int k0, iters, meurant;
 };
-bool small_fits(int64_t n, int64_t nnz, bool* mat_lds);
-int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, bool mat_lds);
+bool small_fits(int64_t n, int64_t nnz, int max_row_len, int* mode);
+int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode);
 
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_gv_update1(CgArgs a, int trips) {
 // nos7 (n=729) or bcsstk03 (n=112) cannot fill a chip; with one launch per kernel they are
 // launch-bound (~12 us per iteration).  Here 1024 threads keep (r,s) in LDS (double-buffered,
 // like the one-launch schedule above), x and p of their own rows in registers, the matrix
-// in LDS when it fits (else it is re-read through L1/L2), and iterate `iters` times with two
+// in registers or LDS, and iterate `iters` times with two
 // barriers per iteration.  Same arithmetic per element; rows are summed left to right.
 // Inner products: thread-sequential over its rows (row = tid, tid+1024, ...), wave butterfly,
 // 16 waves in order.  Every thread reaches every barrier (trip counts are uniform).
@@ -742,23 +742,29 @@ constexpr int kSmallThreads = 1024;
 constexpr int kSmallRows = 4;                    // rows per thread -> n <= 4096
 constexpr int kSmallMaxN = kSmallThreads * kSmallRows;
 
-template <bool MAT_LDS>
+// MODE 0: matrix in LDS (any row length, up to 4 rows per thread)
+// MODE 1: matrix in REGISTERS: n <= 1024 (one row per thread) and every row <= kSmallRegLen
+//         nonzeros -- the paper's small test matrices (nos7: rows of 4-7, bcsstk03: 4-6).
+constexpr int kSmallRegLen = 8;
+
+template <int MODE>
 __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int ROWS = MODE == 1 ? 1 : kSmallRows;
     const int n = a.n, nnz = a.nnz;
     double2* rsA = reinterpret_cast<double2*>(smem);
     double2* rsB = rsA + n;
     double* red = reinterpret_cast<double*>(rsB + n);          // [16 waves][4]
     double* lval = red + 64;
-    int* lcol = reinterpret_cast<int*>(lval + (MAT_LDS ? nnz : 0));
+    int* lcol = reinterpret_cast<int*>(lval + (MODE == 0 ? nnz : 0));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     const double2* __restrict__ XPg = reinterpret_cast<const double2*>(a.xp);
     const double2* __restrict__ RSg = reinterpret_cast<const double2*>(a.rs);
-    double xr[kSmallRows], pr[kSmallRows];
-    int rbeg[kSmallRows], rend[kSmallRows];
+    double xr[ROWS], pr[ROWS];
+    int rbeg[ROWS], rend[ROWS];
 #pragma unroll
-    for (int j = 0; j < kSmallRows; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         const int row = tid + j * kSmallThreads;
         xr[j] = 0.0; pr[j] = 0.0; rbeg[j] = 0; rend[j] = 0;
         if (row < n) {
@@ -768,7 +774,22 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
             rbeg[j] = a.indptr[row]; rend[j] = a.indptr[row + 1];
         }
     }
-    if constexpr (MAT_LDS) {
+    // MODE 1: this thread's row, padded with (0.0, own column) -- adding +-0.0 products at the
+    // END of the row sum cannot change it (x + 0.0 == x, and a finite entry times 0.0 is 0.0;
+    // inf/nan entries poison the row either way)... except that 0.0 * inf = nan: so padded
+    // slots are skipped by a length test instead of being multiplied.
+    double rv[kSmallRegLen];
+    int rc[kSmallRegLen];
+    int rlen = 0;
+    if constexpr (MODE == 1) {
+        rlen = rend[0] - rbeg[0];
+#pragma unroll
+        for (int q = 0; q < kSmallRegLen; ++q) {
+            const bool ok = q < rlen;
+            rv[q] = ok ? a.val[rbeg[0] + q] : 0.0;
+            rc[q] = ok ? a.col[rbeg[0] + q] : 0;
+        }
+    } else {
         for (int q = tid; q < nnz; q += kSmallThreads) { lval[q] = a.val[q]; lcol[q] = a.col[q]; }
     }
     // inner products of the incoming state
@@ -790,15 +811,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
         }
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < kSmallRows; ++j) {
+        for (int j = 0; j < ROWS; ++j) {
             const int row = tid + j * kSmallThreads;
             if (row < n) {
                 double wr = 0.0, us = 0.0;                       // (A r)_i, (A s)_i, left to right
-                for (int q = rbeg[j]; q < rend[j]; ++q) {
-                    const double v = MAT_LDS ? lval[q] : a.val[q];
-                    const int c = MAT_LDS ? lcol[q] : a.col[q];
-                    const double2 g = cur[c];
-                    wr += v * g.x; us += v * g.y;
+                if constexpr (MODE == 1) {
+                    double2 g[kSmallRegLen];
+#pragma unroll
+                    for (int q = 0; q < kSmallRegLen; ++q) g[q] = cur[rc[q]];      // all gathers in flight
+#pragma unroll
+                    for (int q = 0; q < kSmallRegLen; ++q)
+                        if (q < rlen) { wr += rv[q] * g[q].x; us += rv[q] * g[q].y; }
+                } else {
+                    for (int q = rbeg[j]; q < rend[j]; ++q) {
+                        const double v = lval[q];
+                        const double2 g = cur[lcol[q]];
+                        wr += v * g.x; us += v * g.y;
+                    }
                 }
                 const double2 rs = cur[row];
                 xr[j] = xr[j] + al * pr[j];                      // x += a p
@@ -814,11 +843,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
         acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
         if (lane == 0) { red[wv * 4 + 0] = acc0; red[wv * 4 + 1] = acc1; red[wv * 4 + 2] = acc2; red[wv * 4 + 3] = acc3; }
         __syncthreads();                                         // nxt complete, red complete
-        mu = red[0]; dl = red[1]; gm = red[2]; nu = red[3];
-#pragma unroll
-        for (int w = 1; w < kSmallThreads / 64; ++w) {
-            mu += red[w * 4 + 0]; dl += red[w * 4 + 1]; gm += red[w * 4 + 2]; nu += red[w * 4 + 3];
-        }
+        // 16 wave partials -> every wave sums them with the same butterfly (lanes 0..15 hold them)
+        mu = wave_sum(lane < 16 ? red[lane * 4 + 0] : 0.0);
+        dl = wave_sum(lane < 16 ? red[lane * 4 + 1] : 0.0);
+        gm = wave_sum(lane < 16 ? red[lane * 4 + 2] : 0.0);
+        nu = wave_sum(lane < 16 ? red[lane * 4 + 3] : 0.0);
         if (tid == 0) {
             double* d = a.dots + (size_t)(a.k0 + it) * kPartialStride;
             d[0] = mu; d[1] = dl; d[2] = gm; d[3] = nu; d[4] = nu;
@@ -830,7 +859,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
     double2* XPo = reinterpret_cast<double2*>(a.xp);
     double2* RSo = reinterpret_cast<double2*>(a.rs);
 #pragma unroll
-    for (int j = 0; j < kSmallRows; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         const int row = tid + j * kSmallThreads;
         if (row < n) { XPo[row] = make_double2(xr[j], pr[j]); RSo[row] = cur[row]; }
     }
@@ -1041,26 +1070,29 @@ int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int nt
                                                 dots_prev, nullptr, rs_new, partials, coef_out, prev);
 }
 
-size_t small_lds_bytes(int n, int nnz, bool mat_lds) {
-    return (size_t)2 * n * 16 + 64 * 8 + (mat_lds ? (size_t)nnz * 12 + 16 : 0);
+size_t small_lds_bytes(int n, int nnz, int mode) {
+    return (size_t)2 * n * 16 + 64 * 8 + (mode == 0 ? (size_t)nnz * 12 + 16 : 0);
 }
-bool small_fits(int64_t n, int64_t nnz, bool* mat_lds) {
+// mode 1 (matrix in registers) if n <= 1024 and the longest row has <= 8 nonzeros; mode 0
+// (matrix in LDS) if it fits beside the vectors; otherwise the multi-launch schedule is
+// faster (measured: bcsstk14, 63 k nonzeros re-read through L2 by one CU: 58 us/iteration).
+bool small_fits(int64_t n, int64_t nnz, int max_row_len, int* mode) {
     if (n < 1 || n > kSmallMaxN) return false;
+    if (n <= kSmallThreads && max_row_len <= kSmallRegLen) { *mode = 1; return true; }
     const size_t cap = 156 * 1024;
-    if (small_lds_bytes((int)n, (int)nnz, true) <= cap && nnz < (1 << 20)) { *mat_lds = true; return true; }
-    if (small_lds_bytes((int)n, 0, false) <= cap) { *mat_lds = false; return true; }
+    if (nnz < (1 << 20) && small_lds_bytes((int)n, (int)nnz, 0) <= cap && max_row_len <= 64) { *mode = 0; return true; }
     return false;
 }
-int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, bool mat_lds) {
-    const size_t lds = small_lds_bytes(a.n, a.nnz, mat_lds);
+int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode) {
+    const size_t lds = small_lds_bytes(a.n, a.nnz, mode);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_pipe_pr<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (mat_lds) hipLaunchKernelGGL(k_small_pipe_pr<true>, dim3(1), dim3(kSmallThreads), lds, st, a);
-    else hipLaunchKernelGGL(k_small_pipe_pr<false>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    if (mode == 1) hipLaunchKernelGGL(k_small_pipe_pr<1>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    else hipLaunchKernelGGL(k_small_pipe_pr<0>, dim3(1), dim3(kSmallThreads), lds, st, a);
     return PRCG_LAUNCH_OK() ? 1 : -1;
 }
 

@@ -357,14 +357,14 @@ def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
     assert worst <= 1e-12, worst
     # free-running: reproducible, and the same history whether run in one call or in pieces
     iters = 3000
-    runs = []
+    runs, times = [], []
     for chunks in ((iters,), (1000, 1, 1999)):
         small.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
         t0 = time.perf_counter()
         for c in chunks:
             small.iterate(c)
         small.sync()
-        dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
         runs.append(small.history()['updated_residual_2_norm'])
     assert np.array_equal(runs[0], runs[1], equal_nan=True)
     multi.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
@@ -374,9 +374,9 @@ def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
     dt_multi = time.perf_counter() - t0
     prefix = PREFIX.get(matrix, 5)
     np.testing.assert_allclose(runs[0][:prefix], multi.history()['updated_residual_2_norm'][:prefix], rtol=1e-12)
-    print(f'{matrix} (n={n}): one-workgroup solver {dt / chunks[-1] * 1e6 if False else 0:.0f}'
-          f' -- {iters} iterations: one launch {dt * 1e3:.1f} ms vs one launch per iteration {dt_multi * 1e3:.1f} ms;'
-          f' forced-step scalar deviation {worst:.1e}')
+    print(f'{matrix} (n={n}): {iters} iterations in one launch {times[0] * 1e3:.2f} ms '
+          f'({times[0] / iters * 1e6:.2f} us/iteration) vs one launch per iteration {dt_multi * 1e3:.2f} ms '
+          f'({dt_multi / iters * 1e6:.2f} us/iteration); forced-step scalar deviation {worst:.1e}')
     small.close()
     multi.close()
 
