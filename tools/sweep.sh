@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_sweep.sh <workload> "<steps list>" "<grid/CU list (0=auto)>"
+# usage: tools/sweep.sh <workload> "<steps list>" "<grid/CU list (0=auto)>"
 w=${1:-s3}; steps=${2:-"1 2 4"}; grids=${3:-"0"}
 mkdir -p gpurun_out
 for s in $steps; do for g in $grids; do
