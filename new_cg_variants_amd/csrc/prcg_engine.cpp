@@ -192,8 +192,11 @@ bool meurant(int v) { return v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M || v == P
 
 // ---- halo exchange of an nc-component extended vector, all on `st` ----------------------
 int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
-    if (!h->multi() || h->g == 0) return PRCG_OK;
-    CHECK(h, h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
+    // a rank takes part in the exchange if it has ghosts OR if a peer needs its rows (with a
+    // pattern-symmetric operator the two coincide, but the plan decides, not the pattern)
+    if (!h->multi()) return PRCG_OK;
+    CHECK(h, h->g == 0 || h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
+    if (!h->have_halo || h->n_peers == 0) return PRCG_OK;
     // the halo communicator may only be used on its own stream (operations of one
     // communicator must be enqueued in one order)
     ncclComm_t cm = (h->comm_halo && st == h->sh) ? h->comm_halo : h->comm;
@@ -307,7 +310,7 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         return PRCG_OK;
     }
-    const bool halo = h->multi() && h->g > 0;
+    const bool halo = h->multi() && h->have_halo && h->n_peers > 0;
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
     if (halo) {
         // chain 1 (halo stream, halo communicator): pack -> grouped send/recv
