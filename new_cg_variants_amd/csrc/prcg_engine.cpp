@@ -174,13 +174,17 @@ int fail(prcg_t* h, int code, const char* fmt, ...) {
 #define CHECK(h, cond, ...)                                                                   \
     do { if (!(cond)) return fail(h, PRCG_EINVAL, __VA_ARGS__); } while (0)
 
-// experiment knob: PRCG_TILE_STEPS = 1 | 2 | 4 (256-nnz steps per wave tile)
-int env_tile_steps() {
+// Tile size (256-nnz steps per wave tile).  Short rows (stencils: 5-7 nonzeros) do better
+// with 256-slot tiles -- more rows per lane would otherwise serialise the reduce phase
+// (measured: S1 34.3 k vs 31.3 k it/s, S2 3236 vs 3013) -- longer rows with 512-slot tiles
+// (S3, 15 per row: 2115 vs 1885 it/s).  PRCG_TILE_STEPS = 1 | 2 | 4 overrides.
+int env_tile_steps(int64_t n = 0, int64_t nnz = 0) {
     const char* e = getenv("PRCG_TILE_STEPS");
     if (e) {
         const int s = atoi(e);
         if (s == 1 || s == 2 || s == 4) return s;
     }
+    if (n > 0 && nnz < 10 * n) return 1;
     return kDefaultTileSteps;
 }
 
@@ -750,7 +754,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     h->max_row_len = max_len;
     std::vector<Tile> t0, t1;
-    h->steps = env_tile_steps();
+    h->steps = env_tile_steps(n_rows, nnz);
     plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, tile_cap_nnz(h->steps), kTileCapRows, t0, t1);
     std::vector<Tile> all(t0);
     all.insert(all.end(), t1.begin(), t1.end());

@@ -993,8 +993,9 @@ int tile_grid(K kernel, int ntiles) {
             // Measured on MI355X (profiles/r01_sweeps.md): beyond ~12 resident waves per CU
             // of this two-deep pipeline the extra outstanding streams cost more HBM
             // efficiency than the latency hiding they add (S3: 3 blocks/CU 5.2 TB/s,
-            // 4 blocks/CU 4.6 TB/s at 512-slot tiles; 4 blocks/CU best at 256-slot tiles).
-            const int tuned = (TAG % 10 == 1) ? 4 : (TAG % 10 == 2) ? 3 : 2;
+            // 4 blocks/CU 4.6 TB/s at 512-slot tiles; 256-slot tiles, which are chosen for
+            // short-row operators, likewise: S2 3/CU 3236 it/s vs 4/CU 3065, S1 35.2 k vs 34.1 k).
+            const int tuned = (TAG % 10 == 4) ? 2 : 3;
             if (occ > tuned) occ = tuned;
         }
         // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
