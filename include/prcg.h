@@ -107,9 +107,10 @@ int  prcg_version(void);
  * rccl_path: path of the librccl.so to dlopen (NULL -> "librccl.so.1").  Rank 0
  * calls prcg_comm_unique_id (once per id) and ships the 128-byte ids to the other
  * ranks by any means (torch.distributed in bench.py); then every rank calls
- * prcg_comm_init with n_ids = 1 or 2 consecutive ids.  With 2 ids the halo exchange
- * gets a communicator and a stream of its own, so the neighbour exchange and the
- * all-reduce of one iteration run side by side instead of one after the other. */
+ * prcg_comm_init with n_ids = 1 or 2 consecutive ids.  With 1 id the neighbour exchange
+ * and the all-reduce of an iteration form one chain on the communication stream; with 2
+ * ids the halo exchange gets a communicator and a stream of its own and the two run
+ * side by side. */
 int prcg_comm_unique_id(const char* rccl_path, void* id128);
 int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* ids, int n_ids);
 

@@ -201,8 +201,7 @@ int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
     if (!h->multi()) return PRCG_OK;
     CHECK(h, h->g == 0 || h->have_halo, "matrix has ghost columns but prcg_set_halo was not called");
     if (!h->have_halo || h->n_peers == 0) return PRCG_OK;
-    // the halo communicator may only be used on its own stream (operations of one
-    // communicator must be enqueued in one order)
+    // the halo communicator is used on its own stream only
     ncclComm_t cm = (h->comm_halo && st == h->sh) ? h->comm_halo : h->comm;
     const int64_t nsend = h->send_ptr[h->n_peers];
     launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);
@@ -316,14 +315,18 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     }
     const bool halo = h->multi() && h->have_halo && h->n_peers > 0;
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
-    if (halo) {
-        // chain 1 (halo stream, halo communicator): pack -> grouped send/recv
-        HIPCHK(h, hipStreamWaitEvent(h->sh, h->e_upd, 0));
-        if ((rc = exchange(h, in_ext, 2, h->sh))) return rc;
-        HIPCHK(h, hipEventRecord(h->e_halo, h->sh));
-    }
-    // chain 2 (reduction stream): block partials -> 5 doubles -> the one all-reduce
+    // With a halo communicator of its own the neighbour exchange runs on its own stream,
+    // beside the reduction chain; with ONE communicator everything is one chain on the
+    // reduction stream (halo first: the boundary rows need it before the next update needs
+    // the inner products).
+    hipStream_t hs = h->comm_halo ? h->sh : h->sm;
     HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    if (halo) {
+        if (hs != h->sm) HIPCHK(h, hipStreamWaitEvent(hs, h->e_upd, 0));
+        if ((rc = exchange(h, in_ext, 2, hs))) return rc;
+        HIPCHK(h, hipEventRecord(h->e_halo, hs));
+    }
+    // block partials -> 5 doubles -> the one all-reduce
     if (!h->fused_final) launch_reduce_final(h->sm, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
     if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
@@ -353,11 +356,12 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
         *nparts = grid;
         return PRCG_OK;
     }
+    hipStream_t hs = h->comm_halo ? h->sh : h->sm;
     HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
-    HIPCHK(h, hipStreamWaitEvent(h->sh, h->e_upd, 0));
-    int rc = exchange(h, x_ext, 1, h->sh);
+    HIPCHK(h, hipStreamWaitEvent(hs, h->e_upd, 0));
+    int rc = exchange(h, x_ext, 1, hs);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->e_halo, h->sh));
+    HIPCHK(h, hipEventRecord(h->e_halo, hs));
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d());

@@ -100,11 +100,16 @@ class RowBlockOperator:
             lib = L.lib()
             uid = None
             if rank == 0:
-                # two ids: all-reduce communicator + halo communicator (they run side by side)
-                buf = np.zeros((2, 128), dtype=np.uint8)
+                # One RCCL communicator by default: halo exchange and all-reduce form one chain
+                # on the communication stream.  PRCG_DUAL_COMM=1 gives the halo a communicator
+                # and a stream of its own so the two run side by side -- faster on paper, but two
+                # communicators progressing concurrently is only safe while the GPU can keep both
+                # kernels resident, and this build has not been on more than one GPU yet.
+                n_ids = 2 if os.environ.get('PRCG_DUAL_COMM', '0') == '1' else 1
+                buf = np.zeros((n_ids, 128), dtype=np.uint8)
                 from ..device import _stdout_to_stderr
                 with _stdout_to_stderr():
-                    for i in range(2):
+                    for i in range(n_ids):
                         L.check(None, lib.prcg_comm_unique_id(path.encode(), L.ptr(buf[i])))
                 uid = buf.tobytes()
             uid = comm.bcast_obj(uid, root=0)
