@@ -31,8 +31,16 @@ _OPERATORS = OrderedDict()   # small cache: figure_gen runs nine variants on one
 _MAX_CACHED = 2
 
 
+def _fingerprint(A):
+    """Cheap content check so that a matrix modified in place is uploaded again."""
+    nnz = A.nnz
+    stride = max(1, nnz // 4096)
+    return (float(A.data.sum()) if nnz else 0.0, int(A.indices[::stride].sum()) if nnz else 0,
+            int(A.indptr[-1]))
+
+
 def _operator(A, device):
-    key = (id(A), A.shape, A.nnz, A.data.__array_interface__['data'][0], device)
+    key = (id(A), A.shape, A.nnz, A.data.__array_interface__['data'][0], device, _fingerprint(A))
     op = _OPERATORS.get(key)
     if op is None:
         op = DeviceCSR(A, device=device)
