@@ -303,7 +303,6 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
 template <int NV, int EPI, int STEPS, bool LS>
 __device__ __forceinline__ void process_tile(
     const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS>& cur,
-    bool prefetch, const TileDesc& dn, MatRegs<STEPS, LS>& nxt,
     typename VecT<NV>::type* my, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
     const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
@@ -313,7 +312,6 @@ __device__ __forceinline__ void process_tile(
     const int rb = d.rb, re = d.re, lo = d.lo, hi = d.hi;
     if (hi - lo > kCap) {
         // ---- long row: the planner gives it a tile of its own (re == rb+1) ----------
-        if (prefetch) load_tile_stream<STEPS, LS>(A, dn, lane, nxt);
         V sum; vzero(sum);
         for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
         sum = vwave_sum(sum);
@@ -335,19 +333,9 @@ __device__ __forceinline__ void process_tile(
         xp0 = XPc[row0 < re ? row0 : rb];
         xp1 = XPc[row1 < re ? row1 : rb];
     }
-    // Issue order matters: s_waitcnt vmcnt counts loads IN ORDER, so whatever is issued before
-    // the gathers has to land before the gathers count as done.  The gathers (L1/L2 hits) go
-    // first, the next tile's val/col stream (HBM latency) after them: the wait for the gathers
-    // then leaves the stream in flight, and it arrives while this tile is reduced.
-    V g[STEPS][4];
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        g[st][0] = X[cur.cc[st].x]; g[st][1] = X[cur.cc[st].y]; g[st][2] = X[cur.cc[st].z]; g[st][3] = X[cur.cc[st].w];
-    }
-    if (prefetch) load_tile_stream<STEPS, LS>(A, dn, lane, nxt);
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        const V g0 = g[st][0], g1 = g[st][1], g2 = g[st][2], g3 = g[st][3];
+        const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
         if constexpr (LS) {
             const int o = st * 256 + lane;
             my[o] = vmul(cur.va[st].x, g0);
@@ -466,8 +454,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
             const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
-            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, has_next && (d1.hi - d1.lo <= kCap), d1, m1, my, X, yout_,
-                                             write_mask, ep_r, ep_d, ep_st, acc, cf);
+            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d1, lane, m1);
+            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d0 = d2;
             t += step;
         }
@@ -477,8 +465,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
             const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
-            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, has_next && (d0.hi - d0.lo <= kCap), d0, m0, my, X, yout_,
-                                             write_mask, ep_r, ep_d, ep_st, acc, cf);
+            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
+            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d1 = d2;
             t += step;
         }
