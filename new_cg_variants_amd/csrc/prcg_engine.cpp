@@ -83,6 +83,9 @@ struct prcg_handle {
     bool have_csr = false;
     int64_t n = 0, g = 0, nnz = 0;
     DevBuf indptr, col, val, tiles;
+    DevBuf col16, tile_base;             // 16-bit tile-relative column encoding (see CsrDev)
+    bool c16_int = false, c16_bnd = false;   // ... usable for all interior / all boundary tiles
+    bool want_c16 = true;                // PRCG_COL16=0 turns it off
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
@@ -132,7 +135,14 @@ struct prcg_handle {
     double last_tot_ms = 0.0;
     int64_t last_iters = 0;
 
-    CsrDev csr() const { return CsrDev{indptr.i(), col.i(), val.d()}; }
+    // operator view for a launch over tiles [first, ...): interior launches pass first = 0,
+    // boundary launches first = nt_int; a launch over ALL tiles needs both classes to qualify
+    CsrDev csr(int first = 0, bool all = true) const {
+        const bool boundary = first >= nt_int && nt_bnd > 0;
+        const bool ok = all ? (c16_int && (nt_bnd == 0 || c16_bnd)) : (boundary ? c16_bnd : c16_int);
+        return CsrDev{indptr.i(), col.i(), val.d(), ok ? static_cast<const unsigned short*>(col16.p) : nullptr,
+                      ok ? static_cast<const int*>(tile_base.p) + first : nullptr};
+    }
     const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
     bool multi() const { return comm != nullptr; }
@@ -332,11 +342,11 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
 
     if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
+    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
     if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     if (halo) {
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
     }
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
     return PRCG_OK;
@@ -363,12 +373,12 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->e_halo, hs));
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int g1 = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
+    const int g1 = launch_spmv(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d());
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-    const int g2 = launch_spmv(h->sc, h->csr(), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
+    const int g2 = launch_spmv(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
                                h->partB.d() + (size_t)g1 * kPartialStride);
     LAUNCHCHK(h, g2);
     *nparts = g1 + g2;
@@ -654,6 +664,7 @@ int prcg_create(prcg_t** out, int device_id) {
     if (const char* e = getenv("PRCG_FUSED_FINAL")) h->fused_final = atoi(e) != 0;
     if (const char* e = getenv("PRCG_FUSED")) h->want_fused = atoi(e) != 0;
     if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_COL16")) h->want_c16 = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -763,6 +774,36 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     std::vector<Tile> all(t0);
     all.insert(all.end(), t1.begin(), t1.end());
 
+    // --- 16-bit tile-relative column encoding (host, once) ---
+    std::vector<int32_t> tbase(all.size() + 1, 0);
+    std::vector<uint16_t> c16;
+    bool fit_int = h->want_c16 && !all.empty(), fit_bnd = h->want_c16;
+    if (h->want_c16) {
+        const int cap = tile_cap_nnz(h->steps);
+        for (size_t ti = 0; ti < all.size(); ++ti) {
+            const Tile& tl = all[ti];
+            if (tl.nnz_end - tl.nnz_begin > cap || tl.nnz_end == tl.nnz_begin) continue;   // long row / empty: not streamed
+            int32_t lo_c = indices[tl.nnz_begin], hi_c = lo_c;
+            for (int32_t q = tl.nnz_begin; q < tl.nnz_end; ++q) {
+                lo_c = indices[q] < lo_c ? indices[q] : lo_c;
+                hi_c = indices[q] > hi_c ? indices[q] : hi_c;
+            }
+            tbase[ti] = lo_c;
+            if (hi_c - lo_c >= 65536) { if (ti < t0.size()) fit_int = false; else fit_bnd = false; }
+        }
+        if (fit_int || (fit_bnd && !t1.empty())) {
+            c16.assign((size_t)nnz + 8, 0);
+            for (size_t ti = 0; ti < all.size(); ++ti) {
+                const bool ok = ti < t0.size() ? fit_int : fit_bnd;
+                const Tile& tl = all[ti];
+                if (!ok || tl.nnz_end - tl.nnz_begin > cap) continue;
+                for (int32_t q = tl.nnz_begin; q < tl.nnz_end; ++q) c16[q] = (uint16_t)(indices[q] - tbase[ti]);
+            }
+        }
+    }
+    h->c16_int = fit_int && !c16.empty();
+    h->c16_bnd = fit_bnd && !c16.empty() && !t1.empty();
+
     // --- upload (arrays padded so the 16-byte stream loads never leave the allocation) ---
     const size_t pad = 8;
     HIPCHK(h, h->indptr.alloc(((size_t)n_rows + 1 + pad) * sizeof(int32_t)));
@@ -776,6 +817,11 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     if (!all.empty())
         HIPCHK(h, hipMemcpy(h->tiles.p, all.data(), all.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    HIPCHK(h, h->tile_base.alloc(tbase.size() * sizeof(int32_t)));
+    HIPCHK(h, hipMemcpy(h->tile_base.p, tbase.data(), tbase.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, h->col16.alloc(c16.empty() ? 16 : c16.size() * sizeof(uint16_t)));
+    if (!c16.empty())
+        HIPCHK(h, hipMemcpy(h->col16.p, c16.data(), c16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
     h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
     HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost) * sizeof(double)));

@@ -34,11 +34,19 @@ struct CsrDev {
     const int* indptr;
     const int* col;
     const double* val;
+    // Device-internal re-encoding of the column indices, built at prcg_set_csr when every
+    // tile's columns span < 65536: col16[q] = col[q] - tile_base[tile of q].  Same indices,
+    // 2 bytes instead of 4 on the HBM stream (12 -> 10 bytes per nonzero).  Lossless; the
+    // arithmetic is untouched.  Null when not built.
+    const unsigned short* col16;
+    const int* tile_base;      // per tile, same indexing as the tile table
 };
 
 // y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
 // partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.
 // returns the grid size used (needed to reduce the partials), <0 on launch failure.
+// (tile_first: index of tiles[0] in the full tile table = index into A.tile_base;
+//  use16: stream the 16-bit column encoding -- only if all tiles of the range qualified)
 int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
                 const double* ep_r, const double* ep_d, double* ep_st,

@@ -251,20 +251,23 @@ struct MatRegs {
     double2 va[STEPS], vb[STEPS];
 };
 
-struct TileDesc { int rb, re, lo, hi; };
+struct TileDesc { int rb, re, lo, hi, base; };
 
-__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, int t) {
+template <bool C16>
+__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const int* __restrict__ tile_base, int t) {
     const int4 d = T4[t];
     TileDesc o;
     o.rb = __builtin_amdgcn_readfirstlane(d.x); o.re = __builtin_amdgcn_readfirstlane(d.y);
     o.lo = __builtin_amdgcn_readfirstlane(d.z); o.hi = __builtin_amdgcn_readfirstlane(d.w);
+    o.base = 0;
+    if constexpr (C16) o.base = __builtin_amdgcn_readfirstlane(tile_base[t]);
     return o;
 }
 
 // Branch-free 16-byte loads of the tile's column indices and values: a lane whose chunk
 // lies past the tile re-reads the tile's first chunk (one hot line); its products land in
 // LDS slots nobody reads.
-template <int STEPS, bool LS>
+template <int STEPS, bool LS, bool C16>
 __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS>& m) {
     const int alo = d.lo & ~3;
 #pragma unroll
@@ -290,7 +293,20 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
             m.va[st] = make_double2(a2.x, a2.y);
             m.vb[st] = make_double2(b2.x, b2.y);
 #else
-            m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+            if constexpr (C16) {
+                // 4 column indices in 8 bytes, relative to the tile's smallest column
+                // (entries of the 16-byte chunk that belong to a neighbouring tile were encoded
+                //  against ANOTHER base: they must not be decoded into an address -- they get the
+                //  tile's own base column, a valid index, and their products are never read)
+                const ushort4 c = *reinterpret_cast<const ushort4*>(A.col16 + lb);
+                const int b = d.base;
+                m.cc[st] = make_int4((lb >= d.lo && lb < d.hi) ? b + (int)c.x : b,
+                                     (lb + 1 >= d.lo && lb + 1 < d.hi) ? b + (int)c.y : b,
+                                     (lb + 2 >= d.lo && lb + 2 < d.hi) ? b + (int)c.z : b,
+                                     (lb + 3 >= d.lo && lb + 3 < d.hi) ? b + (int)c.w : b);
+            } else {
+                m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
+            }
             m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
             m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
 #endif
@@ -365,7 +381,7 @@ __device__ __forceinline__ void process_tile(
 // stream of tile t+W is already in flight (second register image) and the descriptor of
 // tile t+2W is being fetched.  The dependent chain per tile is then just
 // gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
-template <int NV, int EPI, int STEPS, bool LS>
+template <int NV, int EPI, int STEPS, bool LS, bool C16>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -441,11 +457,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     }
 
     MatRegs<STEPS, LS> m0, m1;
-    TileDesc d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+    TileDesc d0 = {0, 0, 0, 0, 0}, d1 = {0, 0, 0, 0, 0};
     if (t < tend) {
-        d0 = read_desc(T4, t);
-        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
-        if (t + step < tend) d1 = read_desc(T4, t + step);
+        d0 = read_desc<C16>(T4, A.tile_base, t);
+        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS, C16>(A, d0, lane, m0);
+        if (t + step < tend) d1 = read_desc<C16>(T4, A.tile_base, t + step);
     }
 
     while (t < tend) {
@@ -453,8 +469,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         {
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
-            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d1, lane, m1);
+            const TileDesc d2 = read_desc<C16>(T4, A.tile_base, t2 < tend ? t2 : t);
+            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS, C16>(A, d1, lane, m1);
             process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d0 = d2;
             t += step;
@@ -464,8 +480,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         {
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc(T4, t2 < tend ? t2 : t);
-            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS>(A, d0, lane, m0);
+            const TileDesc d2 = read_desc<C16>(T4, A.tile_base, t2 < tend ? t2 : t);
+            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS, C16>(A, d0, lane, m0);
             process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d1 = d2;
             t += step;
@@ -1026,7 +1042,10 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
                  double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
-    auto k = lane_strided() ? k_spmv_tiles<NV, EPI, STEPS, true> : k_spmv_tiles<NV, EPI, STEPS, false>;
+    const bool ls = lane_strided();
+    const bool c16 = !ls && A.col16 != nullptr && A.tile_base != nullptr;
+    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, false>
+                : (c16 ? k_spmv_tiles<NV, EPI, STEPS, false, true> : k_spmv_tiles<NV, EPI, STEPS, false, false>);
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }

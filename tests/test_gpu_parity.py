@@ -107,6 +107,38 @@ def test_spmv_ragged_empty_and_long_rows(amd):
         op.close()
 
 
+def test_spmv_column_encodings_agree(amd):
+    """The device streams the column indices as 16-bit offsets from each tile's smallest column
+    when every tile's columns span < 65536, else as the int32 it was given.  Both are the same
+    indices: bit-identical products.  Covers: banded (16-bit), wide random (int32 fallback), a
+    matrix whose tiles mix both spans (fallback), and the knob that turns the encoding off."""
+    rng = np.random.default_rng(9)
+    P = amd['problems']
+    cases = {'banded': P.banded_ex2b(300_000, 7)}
+    n = 200_000
+    lens = rng.integers(1, 12, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = rng.integers(0, n, size=int(indptr[-1])).astype(np.int32)
+    cases['wide'] = sp.csr_matrix((rng.standard_normal(cols.size), cols, indptr), shape=(n, n))
+    near = (np.repeat(np.arange(n), lens) + rng.integers(-50, 50, size=cols.size)).clip(0, n - 1).astype(np.int32)
+    near[indptr[n // 2]:indptr[n // 2] + 5] = [0, n - 1, 7, n - 3, 11]          # one tile with a huge span
+    cases['mixed'] = sp.csr_matrix((rng.standard_normal(cols.size), near, indptr), shape=(n, n))
+    for name, A in cases.items():
+        x = rng.standard_normal(A.shape[0])
+        ref = A @ x
+        outs = []
+        for knobs in (None, {'PRCG_COL16': '0'}):
+            op = amd['device'].DeviceCSR(A, knobs=knobs)
+            y, _ = op.matvec(x)
+            RS = np.stack([x, 0.5 * x], axis=1)
+            WU, _ = op.matmat2(RS)
+            outs.append((y, WU))
+            op.close()
+        assert np.array_equal(outs[0][0], ref), name
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
+        assert np.array_equal(outs[0][1][:, 0], ref) and np.array_equal(outs[0][1][:, 1], A @ (0.5 * x)), name
+
+
 def test_spmv_full_size_properties(amd):
     """S1 at full size (n=1e6): bit-exact vs SciPy, plus size-independent properties:
     A*1 = row sums, symmetry x'(Ay) = y'(Ax), linearity."""
