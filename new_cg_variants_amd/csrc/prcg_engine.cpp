@@ -83,9 +83,11 @@ struct prcg_handle {
     bool have_csr = false;
     int64_t n = 0, g = 0, nnz = 0;
     DevBuf indptr, col, val, tiles;
-    DevBuf col16, tile_base;             // 16-bit tile-relative column encoding (see CsrDev)
+    DevBuf col16, col8, tile_base;       // 16- / 8-bit tile-relative column encodings (see CsrDev)
     bool c16_int = false, c16_bnd = false;   // ... usable for all interior / all boundary tiles
+    bool c8_int = false, c8_bnd = false;
     bool want_c16 = true;                // PRCG_COL16=0 turns it off
+    bool want_c8 = true;                 // PRCG_COL8=0: never narrower than 16 bit
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
@@ -140,8 +142,10 @@ struct prcg_handle {
     CsrDev csr(int first = 0, bool all = true) const {
         const bool boundary = first >= nt_int && nt_bnd > 0;
         const bool ok = all ? (c16_int && (nt_bnd == 0 || c16_bnd)) : (boundary ? c16_bnd : c16_int);
+        const bool ok8 = all ? (c8_int && (nt_bnd == 0 || c8_bnd)) : (boundary ? c8_bnd : c8_int);
         return CsrDev{indptr.i(), col.i(), val.d(), ok ? static_cast<const unsigned short*>(col16.p) : nullptr,
-                      ok ? static_cast<const int*>(tile_base.p) + first : nullptr};
+                      ok8 ? static_cast<const unsigned char*>(col8.p) : nullptr,
+                      (ok || ok8) ? static_cast<const int*>(tile_base.p) + first : nullptr};
     }
     const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -665,6 +669,7 @@ int prcg_create(prcg_t** out, int device_id) {
     if (const char* e = getenv("PRCG_FUSED")) h->want_fused = atoi(e) != 0;
     if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
     if (const char* e = getenv("PRCG_COL16")) h->want_c16 = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_COL8")) h->want_c8 = atoi(e) != 0;
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -777,7 +782,9 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     // --- 16-bit tile-relative column encoding (host, once) ---
     std::vector<int32_t> tbase(all.size() + 1, 0);
     std::vector<uint16_t> c16;
+    std::vector<uint8_t> c8;
     bool fit_int = h->want_c16 && !all.empty(), fit_bnd = h->want_c16;
+    bool fit8_int = fit_int && h->want_c8, fit8_bnd = fit_bnd && h->want_c8;
     if (h->want_c16) {
         const int cap = tile_cap_nnz(h->steps);
         for (size_t ti = 0; ti < all.size(); ++ti) {
@@ -790,6 +797,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             }
             tbase[ti] = lo_c;
             if (hi_c - lo_c >= 65536) { if (ti < t0.size()) fit_int = false; else fit_bnd = false; }
+            if (hi_c - lo_c >= 256) { if (ti < t0.size()) fit8_int = false; else fit8_bnd = false; }
         }
         if (fit_int || (fit_bnd && !t1.empty())) {
             c16.assign((size_t)nnz + 8, 0);
@@ -803,6 +811,19 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     h->c16_int = fit_int && !c16.empty();
     h->c16_bnd = fit_bnd && !c16.empty() && !t1.empty();
+    fit8_int = fit8_int && h->c16_int;
+    fit8_bnd = fit8_bnd && h->c16_bnd;
+    if (fit8_int || fit8_bnd) {
+        c8.assign((size_t)nnz + 8, 0);
+        for (size_t ti = 0; ti < all.size(); ++ti) {
+            const bool ok = ti < t0.size() ? fit8_int : fit8_bnd;
+            const Tile& tl = all[ti];
+            if (!ok || tl.nnz_end - tl.nnz_begin > tile_cap_nnz(h->steps)) continue;
+            for (int32_t q = tl.nnz_begin; q < tl.nnz_end; ++q) c8[q] = (uint8_t)(indices[q] - tbase[ti]);
+        }
+    }
+    h->c8_int = fit8_int;
+    h->c8_bnd = fit8_bnd;
 
     // --- upload (arrays padded so the 16-byte stream loads never leave the allocation) ---
     const size_t pad = 8;
@@ -822,6 +843,8 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     HIPCHK(h, h->col16.alloc(c16.empty() ? 16 : c16.size() * sizeof(uint16_t)));
     if (!c16.empty())
         HIPCHK(h, hipMemcpy(h->col16.p, c16.data(), c16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(h, h->col8.alloc(c8.empty() ? 16 : c8.size()));
+    if (!c8.empty()) HIPCHK(h, hipMemcpy(h->col8.p, c8.data(), c8.size(), hipMemcpyHostToDevice));
     h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
     h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
     HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost) * sizeof(double)));

@@ -39,6 +39,7 @@ struct CsrDev {
     // 2 bytes instead of 4 on the HBM stream (12 -> 10 bytes per nonzero).  Lossless; the
     // arithmetic is untouched.  Null when not built.
     const unsigned short* col16;
+    const unsigned char* col8;  // the same with 1 byte, when every tile spans < 256 columns (narrow bands)
     const int* tile_base;      // per tile, same indexing as the tile table
 };
 

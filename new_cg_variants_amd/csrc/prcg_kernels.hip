@@ -253,21 +253,22 @@ struct MatRegs {
 
 struct TileDesc { int rb, re, lo, hi, base; };
 
-template <bool C16>
+template <int C16>
 __device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const int* __restrict__ tile_base, int t) {
     const int4 d = T4[t];
     TileDesc o;
     o.rb = __builtin_amdgcn_readfirstlane(d.x); o.re = __builtin_amdgcn_readfirstlane(d.y);
     o.lo = __builtin_amdgcn_readfirstlane(d.z); o.hi = __builtin_amdgcn_readfirstlane(d.w);
     o.base = 0;
-    if constexpr (C16) o.base = __builtin_amdgcn_readfirstlane(tile_base[t]);
+    if constexpr (C16 != 0) o.base = __builtin_amdgcn_readfirstlane(tile_base[t]);
     return o;
 }
 
 // Branch-free 16-byte loads of the tile's column indices and values: a lane whose chunk
 // lies past the tile re-reads the tile's first chunk (one hot line); its products land in
 // LDS slots nobody reads.
-template <int STEPS, bool LS, bool C16>
+// C16: width of the streamed column encoding: 0 = the int32 given, 16 / 8 = tile-relative offsets
+template <int STEPS, bool LS, int C16>
 __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS>& m) {
     const int alo = d.lo & ~3;
 #pragma unroll
@@ -293,7 +294,15 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
             m.va[st] = make_double2(a2.x, a2.y);
             m.vb[st] = make_double2(b2.x, b2.y);
 #else
-            if constexpr (C16) {
+            if constexpr (C16 == 8) {
+                // 4 column indices in 4 bytes
+                const uchar4 c = *reinterpret_cast<const uchar4*>(A.col8 + lb);
+                const int b = d.base;
+                m.cc[st] = make_int4((lb >= d.lo && lb < d.hi) ? b + (int)c.x : b,
+                                     (lb + 1 >= d.lo && lb + 1 < d.hi) ? b + (int)c.y : b,
+                                     (lb + 2 >= d.lo && lb + 2 < d.hi) ? b + (int)c.z : b,
+                                     (lb + 3 >= d.lo && lb + 3 < d.hi) ? b + (int)c.w : b);
+            } else if constexpr (C16 == 16) {
                 // 4 column indices in 8 bytes, relative to the tile's smallest column
                 // (entries of the 16-byte chunk that belong to a neighbouring tile were encoded
                 //  against ANOTHER base: they must not be decoded into an address -- they get the
@@ -381,7 +390,7 @@ __device__ __forceinline__ void process_tile(
 // stream of tile t+W is already in flight (second register image) and the descriptor of
 // tile t+2W is being fetched.  The dependent chain per tile is then just
 // gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
-template <int NV, int EPI, int STEPS, bool LS, bool C16>
+template <int NV, int EPI, int STEPS, bool LS, int C16>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -1043,9 +1052,10 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
                  double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
     const bool ls = lane_strided();
-    const bool c16 = !ls && A.col16 != nullptr && A.tile_base != nullptr;
-    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, false>
-                : (c16 ? k_spmv_tiles<NV, EPI, STEPS, false, true> : k_spmv_tiles<NV, EPI, STEPS, false, false>);
+    const int cw = (ls || A.tile_base == nullptr) ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
+    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, 0>
+                : (cw == 8 ? k_spmv_tiles<NV, EPI, STEPS, false, 8>
+                           : (cw == 16 ? k_spmv_tiles<NV, EPI, STEPS, false, 16> : k_spmv_tiles<NV, EPI, STEPS, false, 0>));
     const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }

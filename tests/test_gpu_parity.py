@@ -108,10 +108,11 @@ def test_spmv_ragged_empty_and_long_rows(amd):
 
 
 def test_spmv_column_encodings_agree(amd):
-    """The device streams the column indices as 16-bit offsets from each tile's smallest column
-    when every tile's columns span < 65536, else as the int32 it was given.  Both are the same
-    indices: bit-identical products.  Covers: banded (16-bit), wide random (int32 fallback), a
-    matrix whose tiles mix both spans (fallback), and the knob that turns the encoding off."""
+    """The device streams the column indices as 8- or 16-bit offsets from each tile's smallest
+    column when every tile's columns span < 256 resp. < 65536, else as the int32 it was given.
+    All are the same indices: bit-identical products.  Covers: banded (8-bit), wide random
+    (int32 fallback), a matrix whose tiles mix spans (fallback), and the knobs that force the
+    wider encodings."""
     rng = np.random.default_rng(9)
     P = amd['problems']
     cases = {'banded': P.banded_ex2b(300_000, 7)}
@@ -127,7 +128,7 @@ def test_spmv_column_encodings_agree(amd):
         x = rng.standard_normal(A.shape[0])
         ref = A @ x
         outs = []
-        for knobs in (None, {'PRCG_COL16': '0'}):
+        for knobs in (None, {'PRCG_COL8': '0'}, {'PRCG_COL16': '0'}):
             op = amd['device'].DeviceCSR(A, knobs=knobs)
             y, _ = op.matvec(x)
             RS = np.stack([x, 0.5 * x], axis=1)
@@ -135,7 +136,8 @@ def test_spmv_column_encodings_agree(amd):
             outs.append((y, WU))
             op.close()
         assert np.array_equal(outs[0][0], ref), name
-        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]), name
         assert np.array_equal(outs[0][1][:, 0], ref) and np.array_equal(outs[0][1][:, 1], A @ (0.5 * x)), name
 
 
