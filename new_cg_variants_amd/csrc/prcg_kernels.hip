@@ -1020,7 +1020,10 @@ int tile_grid(K kernel, int ntiles) {
             // efficiency than the latency hiding they add (S3: 3 blocks/CU 5.2 TB/s,
             // 4 blocks/CU 4.6 TB/s at 512-slot tiles; 256-slot tiles, which are chosen for
             // short-row operators, likewise: S2 3/CU 3236 it/s vs 4/CU 3065, S1 35.2 k vs 34.1 k).
-            const int tuned = (TAG % 10 == 4) ? 2 : 3;
+            // TAG = NV*1000 + EPI*100 + STEPS*10 + (column bytes on the stream: 0 = int32, 1, 2);
+            // with the narrower column stream one more resident block pays (S3: 2394 vs 2317 it/s)
+            const int steps_ = (TAG / 10) % 10, narrow_ = TAG % 10;
+            const int tuned = steps_ == 4 ? 2 : ((steps_ == 2 && narrow_ != 0) ? 4 : 3);
             if (occ > tuned) occ = tuned;
         }
         // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
@@ -1056,7 +1059,10 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
     auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, 0>
                 : (cw == 8 ? k_spmv_tiles<NV, EPI, STEPS, false, 8>
                            : (cw == 16 ? k_spmv_tiles<NV, EPI, STEPS, false, 16> : k_spmv_tiles<NV, EPI, STEPS, false, 0>));
-    const int grid = tile_grid<NV * 100 + EPI * 10 + STEPS>(k, ntiles);
+    int grid;
+    if (cw == 8) grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles);
+    else if (cw == 16) grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles);
+    else grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
