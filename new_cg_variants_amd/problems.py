@@ -94,6 +94,10 @@ def irregular_standin(n, mean_len=76, max_len=2000, reach=50_000, seed=0):
     return A
 
 
+def _row_slice(A, rows):
+    return A if rows is None else A[rows[0]:rows[1]]
+
+
 def reference_rhs(A_rows, n):
     """The reference's problem setup (numerical_experiments/figure_gen.py:31-34):
     x_true = 1/sqrt(N), b = A x_true, x0 = 0 -- for the row block ``A_rows``."""
@@ -122,6 +126,8 @@ WORKLOADS = {
                n=10_000_000, make=lambda rows=None: banded_ex2b(10_000_000, 7, rows=rows)),
     's3_8th': dict(desc='one eighth of S3: ex2b banded n=1.25e6, 15 diagonals', n=1_250_000,
                    make=lambda rows=None: banded_ex2b(1_250_000, 7, rows=rows)),
+    's4': dict(desc='S4 stand-in for Queen_4147: irregular symmetric SPD, n=1e6, log-normal row lengths (mean ~76, max 2000), reach 50000, seed 0',
+               n=1_000_000, make=lambda rows=None: _row_slice(irregular_standin(1_000_000), rows)),
     # reduced sizes for tests / smoke
     's1_small': dict(desc='5-pt Laplacian 64x48', n=64 * 48, make=lambda rows=None: laplace_2d(64, 48, rows)),
     's3_small': dict(desc='ex2b banded n=20000 k=7', n=20000,
