@@ -94,6 +94,32 @@ def irregular_standin(n, mean_len=76, max_len=2000, reach=50_000, seed=0):
     return A
 
 
+def fem_like_3d(m, dof=3, rows=None):
+    """Structured stand-in for 3-D elasticity matrices such as Queen_4147 (n=4.1 M, ~76 nonzeros
+    per row): m^3 nodes, `dof` unknowns per node, every node coupled to its 27 neighbours ->
+    up to 27*dof = 81 nonzeros per row, columns clustered like an FEM assembly.  Symmetric,
+    strictly diagonally dominant (SPD).  m=111, dof=3: n=4,102,893."""
+    n = dof * m ** 3
+    lo, hi = _rows(n, rows)
+    I = np.arange(lo, hi, dtype=np.int64)
+    node, d = I // dof, I % dof
+    ix, iy, iz = node % m, (node // m) % m, node // (m * m)
+    offs = [(a, b, c) for c in (-1, 0, 1) for b in (-1, 0, 1) for a in (-1, 0, 1)]
+    cols, valid = [], []
+    for (a, b, c) in offs:
+        ok = (ix + a >= 0) & (ix + a < m) & (iy + b >= 0) & (iy + b < m) & (iz + c >= 0) & (iz + c < m)
+        nb = (ix + a) + m * (iy + b) + m * m * (iz + c)
+        for e in range(dof):
+            cols.append(nb * dof + e)
+            valid.append(ok)
+    J = np.stack(cols, axis=1)
+    valid = np.stack(valid, axis=1)
+    # symmetric values: a function of the unordered pair {row, col}
+    V = -(1.0 + ((I[:, None] + J) % 7) / 16.0) / (27.0 * dof)
+    V[J == I[:, None]] = 2.0
+    return _assemble(I[:, None], J, V, valid, hi - lo, n)
+
+
 def _row_slice(A, rows):
     return A if rows is None else A[rows[0]:rows[1]]
 
@@ -128,6 +154,8 @@ WORKLOADS = {
                    make=lambda rows=None: banded_ex2b(1_250_000, 7, rows=rows)),
     's4': dict(desc='S4 stand-in for Queen_4147: irregular symmetric SPD, n=1e6, log-normal row lengths (mean ~76, max 2000), reach 50000, seed 0',
                n=1_000_000, make=lambda rows=None: _row_slice(irregular_standin(1_000_000), rows)),
+    's4b': dict(desc='FEM-like stand-in for Queen_4147: 3 dof x 27-point coupling on 80^3 nodes (n=1,536,000, ~81 nnz/row)',
+                n=3 * 80 ** 3, make=lambda rows=None: fem_like_3d(80, 3, rows)),
     # reduced sizes for tests / smoke
     's1_small': dict(desc='5-pt Laplacian 64x48', n=64 * 48, make=lambda rows=None: laplace_2d(64, 48, rows)),
     's3_small': dict(desc='ex2b banded n=20000 k=7', n=20000,
