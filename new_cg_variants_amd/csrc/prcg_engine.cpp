@@ -199,6 +199,9 @@ int env_tile_steps(int64_t n = 0, int64_t nnz = 0) {
         if (s == 1 || s == 2 || s == 4) return s;
     }
     if (n > 0 && nnz < 10 * n) return 1;
+    // medium rows (FEM-like, ~50+ nonzeros): the lane-per-row sums are a serial chain per row, so
+    // bigger tiles (more rows summed side by side per wave) win (s4b: 2983 vs 2740 it/s)
+    if (n > 0 && nnz >= 48 * n) return 4;
     return kDefaultTileSteps;
 }
 

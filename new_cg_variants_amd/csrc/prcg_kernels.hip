@@ -225,11 +225,32 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
     }
 }
 
+#ifndef PRCG_ROWSUM_UNROLL
+#define PRCG_ROWSUM_UNROLL 8
+#endif
+
 template <int NV>
 __device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename VecT<NV>::type* my, int s, int e) {
     using V = typename VecT<NV>::type;
     V sum; vzero(sum);
     int q = s;
+#if PRCG_ROWSUM_UNROLL >= 16
+    for (; q + 16 <= e; q += 16) {
+        V p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = my[q + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vacc(sum, p[i]);
+    }
+#endif
+#if PRCG_ROWSUM_UNROLL >= 8
+    for (; q + 8 <= e; q += 8) {   // 8 LDS reads in flight (medium rows: the read latency, not the adds, is the chain)
+        const V p0 = my[q], p1 = my[q + 1], p2 = my[q + 2], p3 = my[q + 3];
+        const V p4 = my[q + 4], p5 = my[q + 5], p6 = my[q + 6], p7 = my[q + 7];
+        vacc(sum, p0); vacc(sum, p1); vacc(sum, p2); vacc(sum, p3);
+        vacc(sum, p4); vacc(sum, p5); vacc(sum, p6); vacc(sum, p7);
+    }
+#endif
     for (; q + 4 <= e; q += 4) {   // 4 LDS reads in flight, adds stay in row order
         const V p0 = my[q], p1 = my[q + 1], p2 = my[q + 2], p3 = my[q + 3];
         vacc(sum, p0); vacc(sum, p1); vacc(sum, p2); vacc(sum, p3);

@@ -1,10 +1,11 @@
 #!/bin/bash
-# usage: tools/sweep.sh <workload> "<steps list>" "<grid/CU list (0=auto)>"
+# usage: tools/sweep.sh <workload> "<steps list (0=auto)>" "<grid/CU list (0=auto)>"
 w=${1:-s3}; steps=${2:-"1 2 4"}; grids=${3:-"0"}
 mkdir -p gpurun_out
 for s in $steps; do for g in $grids; do
   if [ $g = 0 ]; then unset PRCG_GRID_PER_CU; else export PRCG_GRID_PER_CU=$g; fi
-  PRCG_TILE_STEPS=$s timeout -k 10 200 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/sw.json 2>/dev/null
+  if [ $s = 0 ]; then unset PRCG_TILE_STEPS; else export PRCG_TILE_STEPS=$s; fi
+  timeout -k 10 200 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/sw.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/sw.json"))
