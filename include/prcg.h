@@ -157,6 +157,17 @@ int prcg_iterate(prcg_t* h, int iters);
 int prcg_sync(prcg_t* h);
 /* current iteration index k (0 after begin) */
 int prcg_iteration(const prcg_t* h);
+/* which schedule the current session runs (valid after prcg_solve_begin): bit 0 one launch per
+ * iteration (fused SpMM + update), bit 1 one-workgroup solver, bit 2 communicator present,
+ * bit 3 merged exchange (halo rows ride on the one all-gather that carries the partial inner
+ * products), bit 4 second halo communicator; bits 8..11 tile size in 256-slot steps.
+ * No counterpart in the reference (diagnostics for tests and benchmarks). */
+#define PRCG_SCHED_FUSED 1
+#define PRCG_SCHED_SMALL 2
+#define PRCG_SCHED_COMM 4
+#define PRCG_SCHED_GATHER 8
+#define PRCG_SCHED_DUAL_COMM 16
+int prcg_schedule(const prcg_t* h);
 /* teacher forcing: declare that the state now loaded (prcg_set_vector / prcg_set_scalars
  * for iteration k) IS iteration k; the next prcg_iterate(h,1) produces k+1 */
 int prcg_set_iteration(prcg_t* h, int k);

@@ -59,6 +59,7 @@ _SIGNATURES = {
     'prcg_iterate': (C.c_int, [_P, C.c_int]),
     'prcg_sync': (C.c_int, [_P]),
     'prcg_iteration': (C.c_int, [_P]),
+    'prcg_schedule': (C.c_int, [_P]),
     'prcg_set_iteration': (C.c_int, [_P, C.c_int]),
     'prcg_get_vector': (C.c_int, [_P, C.c_int, _P]),
     'prcg_set_vector': (C.c_int, [_P, C.c_int, _P]),

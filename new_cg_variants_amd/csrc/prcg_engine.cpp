@@ -107,6 +107,15 @@ struct prcg_handle {
     DevBuf send_idx, send_buf;
     bool have_halo = false;
 
+    // ---- merged exchange: with a small halo, ONE all-gather per iteration carries the rank's five
+    // partial inner products and the rows its neighbours need (pipelined variants) ----
+    bool want_gather = true;             // PRCG_GATHER=0 turns it off (must agree on all ranks)
+    int64_t gather_max_bytes = 8192;     // PRCG_GATHER_MAX_BYTES: largest per-rank slot that still rides along
+    bool gather_planned = false, gather_ok = false;
+    bool gather = false;                 // this session uses it
+    int g_slot = 0;                      // doubles per rank slot: 8 + 2 * (largest send list of any rank)
+    DevBuf gbuf, ghost_src, gtab;
+
     // ---- session ----
     bool in_session = false;
     int variant = -1;
@@ -243,6 +252,69 @@ int allreduce(prcg_t* h, double* buf, int count, hipStream_t st) {
     return PRCG_OK;
 }
 
+// Collective (every rank calls it, from prcg_solve_begin): is the halo small enough to ride
+// on the reduction?  If so, learn where in each neighbour's slot this rank's ghost rows lie:
+// the ranks all-gather their (peer, offset, count) send tables once.
+int plan_gather(prcg_t* h) {
+    h->gather = false;
+    if (!h->multi() || !h->want_gather || h->fused_final) return PRCG_OK;
+    if (h->gather_planned) { h->gather = h->gather_ok; return PRCG_OK; }
+    h->gather_planned = true;
+    h->gather_ok = false;
+    const int np = h->have_halo ? h->n_peers : 0;
+    const int64_t nsend = np > 0 ? h->send_ptr[np] : 0;
+    const int R = h->nranks;
+    // (a) largest send list / peer count of any rank
+    HIPCHK(h, h->gtab.alloc(2 * sizeof(double)));
+    double mine[2] = {(double)nsend, (double)np}, mx[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(h->gtab.p, mine, sizeof mine, hipMemcpyHostToDevice, h->sc));
+    NCCLCHK(h, h->rccl->AllReduce(h->gtab.p, h->gtab.p, 2, ncclDouble, ncclMax, h->comm, h->sc));
+    HIPCHK(h, hipMemcpyAsync(mx, h->gtab.p, sizeof mx, hipMemcpyDeviceToHost, h->sc));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    const int64_t max_send = (int64_t)mx[0];
+    const int max_peers = (int)mx[1];
+    const int64_t slot = 8 + 2 * max_send;
+    if (slot * (int64_t)sizeof(double) > h->gather_max_bytes) return PRCG_OK;      // same verdict on every rank
+    // (b) everybody's send table: [n_peers, (peer, first row of the list, rows) ...]
+    const int T = 1 + 3 * max_peers;
+    std::vector<double> tab((size_t)R * T, 0.0);
+    double* my = tab.data() + (size_t)h->rank * T;
+    my[0] = np;
+    for (int q = 0; q < np; ++q) {
+        my[1 + 3 * q] = h->peer_rank[q];
+        my[2 + 3 * q] = (double)h->send_ptr[q];
+        my[3 + 3 * q] = (double)(h->send_ptr[q + 1] - h->send_ptr[q]);
+    }
+    HIPCHK(h, h->gtab.alloc((size_t)R * T * sizeof(double)));
+    HIPCHK(h, hipMemcpyAsync(h->gtab.d() + (size_t)h->rank * T, my, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->sc));
+    NCCLCHK(h, h->rccl->AllGather(h->gtab.d() + (size_t)h->rank * T, h->gtab.p, (size_t)T, ncclDouble, h->comm, h->sc));
+    HIPCHK(h, hipMemcpyAsync(tab.data(), h->gtab.p, tab.size() * sizeof(double), hipMemcpyDeviceToHost, h->sc));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    // (c) ghost j  <-  pair index into the gathered buffer
+    std::vector<int32_t> src((size_t)h->g + 1, 0);
+    for (int q = 0; q < np; ++q) {
+        const int64_t want = h->recv_ptr[q + 1] - h->recv_ptr[q];
+        if (want == 0) continue;
+        const int pr = h->peer_rank[q];
+        const double* pt = tab.data() + (size_t)pr * T;
+        int64_t off = -1;
+        for (int e = 0; e < (int)pt[0]; ++e)
+            if ((int)pt[1 + 3 * e] == h->rank && (int64_t)pt[3 + 3 * e] == want) { off = (int64_t)pt[2 + 3 * e]; break; }
+        CHECK(h, off >= 0, "halo plans disagree: rank %d sends no list of %lld rows to rank %d", pr, (long long)want, h->rank);
+        const int64_t first = ((int64_t)pr * slot + 8) / 2 + off;
+        CHECK(h, first + want < (int64_t)INT32_MAX, "merged exchange: index overflow");
+        for (int64_t i = 0; i < want; ++i) src[(size_t)(h->recv_ptr[q] + i)] = (int32_t)(first + i);
+    }
+    HIPCHK(h, h->ghost_src.alloc(src.size() * sizeof(int32_t)));
+    HIPCHK(h, hipMemcpy(h->ghost_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, h->gbuf.alloc((size_t)R * slot * sizeof(double)));
+    HIPCHK(h, hipMemset(h->gbuf.p, 0, (size_t)R * slot * sizeof(double)));
+    h->g_slot = (int)slot;
+    h->gather_ok = true;
+    h->gather = true;
+    return PRCG_OK;
+}
+
 // y = A x (x extended, ghosts exchanged), everything on the compute stream.  Used by the
 // initialisation, the recorders and prcg_spmv -- not by the timed loop.
 int dist_spmv(prcg_t* h, double* x_ext, double* y, SpmvEpilogue epi, const double* ep_r,
@@ -328,6 +400,27 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
         LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        return PRCG_OK;
+    }
+    if (h->gather) {
+        // small halo: pack (fixed-order reduction of the partials + the neighbours' rows) ->
+        // ONE all-gather -> unpack (sums in rank order, ghost rows into place), all beside the
+        // interior product
+        const int np = h->have_halo ? h->n_peers : 0;
+        double* slot = h->gbuf.d() + (size_t)h->rank * h->g_slot;
+        HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+        HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+        launch_gather_pack(h->sm, h->partA.d(), grid_upd, slot, in_ext, h->send_idx.i(), np > 0 ? (int)h->send_ptr[np] : 0);
+        NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
+        launch_gather_unpack(h->sm, h->gbuf.d(), h->g_slot, h->nranks, dots_at(h, k), in_ext + 2 * h->n,
+                             h->ghost_src.i(), (int)h->g);
+        HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+        if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
+        if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+        if (h->nt_bnd > 0)
+            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
         return PRCG_OK;
     }
     const bool halo = h->multi() && h->have_halo && h->n_peers > 0;
@@ -673,6 +766,8 @@ int prcg_create(prcg_t** out, int device_id) {
     if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
     if (const char* e = getenv("PRCG_COL16")) h->want_c16 = atoi(e) != 0;
     if (const char* e = getenv("PRCG_COL8")) h->want_c8 = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_GATHER")) h->want_gather = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_GATHER_MAX_BYTES")) { const long v = atol(e); if (v >= 64) h->gather_max_bytes = v; }
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -857,6 +952,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     HIPCHK(h, h->ticket.alloc(64));
     h->have_csr = true;
     h->have_halo = false;
+    h->gather_planned = false;
     return PRCG_OK;
 }
 
@@ -893,6 +989,7 @@ int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank, const int64_
     if (nsend > 0)
         HIPCHK(h, hipMemcpy(h->send_idx.p, send_idx, (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
     h->have_halo = true;
+    h->gather_planned = false;
     return PRCG_OK;
 }
 
@@ -956,6 +1053,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->variant = variant;
     h->fused = false;
     h->small = false;
+    h->gather = false;
     h->prec = inv_diag != nullptr;
     h->max_iter = max_iter;
     h->hist_mask = hist_mask;
@@ -985,6 +1083,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
 
     if (is_pipe(variant)) {
         h->fused = h->want_fused && !h->multi() && !h->prec && pipe_recompute(variant) && h->g == 0;
+        if ((rc = plan_gather(h))) return rc;
         HIPCHK(h, h->xp.alloc((size_t)2 * n * D));
         HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
         HIPCHK(h, h->rs2.alloc(h->fused ? (size_t)2 * ne * D : 16));
@@ -1162,6 +1261,12 @@ int prcg_sync(prcg_t* h) {
 }
 
 int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
+
+int prcg_schedule(const prcg_t* h) {
+    if (!h) return -1;
+    return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+           (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8);
+}
 
 int prcg_set_iteration(prcg_t* h, int k) {
     if (!h) return PRCG_EINVAL;

@@ -145,5 +145,10 @@ int launch_diff_sq(hipStream_t st, const double* a, int as, const double* b, int
 int launch_dot(hipStream_t st, const double* a, const double* b, int64_t n, double* partials, int slot);
 // buf[j*nc + c] = v[idx[j]*nc + c]
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc);
+// merged exchange for small halos: see k_gather_pack / k_gather_unpack
+void launch_gather_pack(hipStream_t st, const double* partials, int nparts, double* slot, const double* rs,
+                        const int* send_idx, int nsend);
+void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
+                          double* rs_ghost, const int* ghost_src, int nghost);
 
 }  // namespace prcg

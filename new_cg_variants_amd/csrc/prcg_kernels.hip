@@ -949,6 +949,55 @@ __global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
     }
 }
 
+// ---- merged exchange (small halos) -----------------------------------------------------
+// One all-gather per iteration carries both the rank's five partial inner products and the
+// (r,s) rows its neighbours need.  Slot layout per rank: 8 doubles (sums 0..4, 3 pad), then
+// the packed rows as pairs.
+// pack: the fixed-order reduction of k_reduce_final, written into the slot header, plus the rows.
+__global__ __launch_bounds__(kFinalThreads) void k_gather_pack(
+    const double* __restrict__ partials, int nparts, double* __restrict__ slot,
+    const double2* __restrict__ rs, const int* __restrict__ send_idx, int nsend)
+{
+    __shared__ double red[kFinalThreads / 64][kPartialStride];
+    double acc[kPartialStride];
+#pragma unroll
+    for (int q = 0; q < kPartialStride; ++q) acc[q] = 0.0;
+    for (int j = threadIdx.x; j < nparts; j += kFinalThreads) {
+#pragma unroll
+        for (int q = 0; q < kPartialStride; ++q)
+            if (q < 5) acc[q] += partials[(size_t)j * kPartialStride + q];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kPartialStride; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 5) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < kFinalThreads / 64; ++w) v += red[w][threadIdx.x];
+        slot[threadIdx.x] = v;
+    }
+    double2* rows = reinterpret_cast<double2*>(slot + 8);
+    for (int j = threadIdx.x; j < nsend; j += kFinalThreads) rows[j] = rs[send_idx[j]];
+}
+
+// unpack: global sums = the ranks' partial sums added in rank order (the same bits on every
+// rank, whatever algorithm RCCL picked for the transport); ghost rows copied into place.
+__global__ __launch_bounds__(kFinalThreads) void k_gather_unpack(
+    const double* __restrict__ gbuf, int slot_doubles, int nranks, double* __restrict__ dots_out,
+    double2* __restrict__ rs_ghost, const int* __restrict__ ghost_src, int nghost)
+{
+    if ((int)threadIdx.x < 5) {
+        double v = gbuf[threadIdx.x];
+        for (int r = 1; r < nranks; ++r) v += gbuf[(size_t)r * slot_doubles + threadIdx.x];
+        dots_out[threadIdx.x] = v;
+    }
+    const double2* g2 = reinterpret_cast<const double2*>(gbuf);
+    for (int j = threadIdx.x; j < nghost; j += kFinalThreads) rs_ghost[j] = g2[ghost_src[j]];
+}
+
 // ---- utilities -------------------------------------------------------------------------
 __global__ void k_copy(double* dst, int ds, const double* src, int ss, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -1249,6 +1298,16 @@ int launch_dot(hipStream_t st, const double* a, const double* b, int64_t n, doub
     const Chunking c = chunking(n);
     hipLaunchKernelGGL(k_dot, dim3(c.grid), dim3(kBlock), 0, st, a, b, n, partials, slot, c.trips);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
+}
+void launch_gather_pack(hipStream_t st, const double* partials, int nparts, double* slot, const double* rs,
+                        const int* send_idx, int nsend) {
+    hipLaunchKernelGGL(k_gather_pack, dim3(1), dim3(kFinalThreads), 0, st, partials, nparts, slot,
+                       reinterpret_cast<const double2*>(rs), send_idx, nsend);
+}
+void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
+                          double* rs_ghost, const int* ghost_src, int nghost) {
+    hipLaunchKernelGGL(k_gather_unpack, dim3(1), dim3(kFinalThreads), 0, st, gbuf, slot_doubles, nranks, dots_out,
+                       reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost);
 }
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc) {
     if (count <= 0) return;

@@ -32,6 +32,7 @@ Rccl* Rccl::get(const char* path, std::string& err) {
     r->CommInitRank = reinterpret_cast<decltype(r->CommInitRank)>(sym("ncclCommInitRank"));
     r->CommDestroy = reinterpret_cast<decltype(r->CommDestroy)>(sym("ncclCommDestroy"));
     r->AllReduce = reinterpret_cast<decltype(r->AllReduce)>(sym("ncclAllReduce"));
+    r->AllGather = reinterpret_cast<decltype(r->AllGather)>(sym("ncclAllGather"));
     r->Send = reinterpret_cast<decltype(r->Send)>(sym("ncclSend"));
     r->Recv = reinterpret_cast<decltype(r->Recv)>(sym("ncclRecv"));
     r->GroupStart = reinterpret_cast<decltype(r->GroupStart)>(sym("ncclGroupStart"));

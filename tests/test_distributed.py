@@ -134,10 +134,15 @@ def loopback_problem(A, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workload,k,n_ids', [('s1_small', 70, 2), ('s3_small', 9, 2), ('s3_small', 9, 1)])
-def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids):
+@pytest.mark.parametrize('workload,k,n_ids,gather', [
+    ('s1_small', 70, 2, '0'), ('s3_small', 9, 2, '0'), ('s3_small', 9, 1, '0'),
+    ('s1_small', 70, 1, '1'), ('s3_small', 9, 1, '1'), ('s3_small', 300, 1, '1')])
+def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids, gather):
     """pack kernel -> ncclSend/ncclRecv (to self) -> ghost slots -> interior/boundary tile
-    split -> event choreography, all on one GPU.  Must be bit-identical to the plain path."""
+    split -> event choreography, all on one GPU.  Must be bit-identical to the plain path.
+    gather='1': the pipelined variants move a small halo inside the one ncclAllGather that
+    also carries the partial inner products (k=300 exceeds the slot limit: falls back to
+    send/recv + all-reduce by itself)."""
     from new_cg_variants_amd import _lib as L
     from new_cg_variants_amd import problems
     from new_cg_variants_amd.device import DeviceCSR
@@ -148,7 +153,7 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids):
     b, x0, x_true = problems.reference_rhs(A, n)
     uid, path = rccl_ids(n_ids)      # 2 ids: halo exchange on its own communicator + stream
     plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
-    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo)
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo, knobs={'PRCG_GATHER': gather})
     x = np.random.default_rng(2).standard_normal(n)
     y0, _ = plain.matvec(x)
     y1, _ = loop.matvec(x)
@@ -164,6 +169,10 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids):
         iters = 120 if pipelined else 25
         for op in (plain, loop):
             op.begin(variant, b, x0, iters, x_true=x_true, hist_mask=15)
+            if op is loop:
+                sched = op.schedule()
+                assert sched['comm'] and not sched['fused']
+                assert sched['gather'] == (pipelined and gather == '1' and k < 300), sched
             op.iterate(iters - 1)
             op.sync()
             outs.append((op.history(), op.get_vector('x')))
