@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ (run ONCE, in the build container).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          # everything
+    python tests/golden/make_golden.py table    # only the published convergence table + its matrices
 
 What it does
   1. imports the reference (read-only mount at /root/reference) -- the serial
@@ -194,8 +195,70 @@ def mp_goldens():
     np.savez_compressed(os.path.join(HERE, 'mp_model_problem.npz'), **fx)
 
 
+# The reference's experiment list: (matrix, max_iter, preconditioner), NE/figure_gen.py:247-339,
+# restricted to the matrices the reference ships under matrices/.
+PAPER_RUNS = [
+    ('model_48_8_3', 110, None), ('model_48_8_3', 200, 'jacobi'),
+    ('bcsstk03', 250, 'jacobi'), ('bcsstk14', 800, 'jacobi'), ('bcsstk15', 830, 'jacobi'),
+    ('bcsstk16', 320, 'jacobi'), ('bcsstk18', 2700, 'jacobi'), ('bcsstk27', 380, 'jacobi'),
+    ('bcsstk03', 1250, None), ('bcsstk14', 25000, None), ('bcsstk15', 35000, None),
+    ('bcsstk16', 900, None), ('bcsstk18', 1750000, None), ('bcsstk27', 2300, None),
+    ('nos1', 900, 'jacobi'), ('nos2', 11000, 'jacobi'), ('nos3', 350, 'jacobi'), ('nos4', 120, 'jacobi'),
+    ('nos5', 350, 'jacobi'), ('nos6', 130, 'jacobi'), ('nos7', 200, 'jacobi'),
+    ('nos1', 4500, None), ('nos2', 45000, None), ('nos3', 400, None), ('nos4', 150, None),
+    ('nos5', 600, None), ('nos6', 2400, None), ('nos7', 7000, None),
+    ('bcsstm19', 1100, None), ('bcsstm20', 700, None), ('bcsstm21', 10, None), ('bcsstm22', 85, None),
+    ('bcsstm23', 10000, None), ('bcsstm24', 45000, None), ('bcsstm25', 130000, None),
+    ('494_bus', 2500, None), ('662_bus', 1200, None), ('685_bus', 950, None), ('1138_bus', 5000, None),
+    ('494_bus', 500, 'jacobi'), ('662_bus', 350, 'jacobi'), ('685_bus', 350, 'jacobi'), ('1138_bus', 1300, 'jacobi'),
+]
+PAPER_COLUMNS = ['hs_pcg', 'cg_pcg', 'm_pcg', 'pr_pcg', 'gv_pcg', 'pipe_pr_m_pcg', 'pipe_pr_pcg']   # NE/figure_gen.py:360
+
+
+def paper_table():
+    """The published convergence table (NE/figures/convergence_table_data.tex: iterations to a
+    relative A-norm error of 1e-5 and log10 of the best relative error, seven variants per
+    row) as JSON, plus the CSR arrays of every matrix it needs -- so that the GPU box can
+    redo the paper's table without the reference."""
+    import json
+    import re
+    published = {}
+    for line in open(f'{REF}/numerical_experiments/figures/convergence_table_data.tex'):
+        line = line.strip()
+        if not line:
+            continue
+        cells = [c.strip() for c in line.rstrip('\\ ').split('&')]
+        name = re.match(r'\\texttt\{(.*)\}', cells[0]).group(1).replace('\\_', '_')
+        vals = [re.sub(r'\\tableemph|[{}]', '', c) for c in cells[4:]]
+        assert len(vals) == 14, line
+        prec = 'jacobi' if cells[1].startswith('Jac') else 'None'
+        published[(name, prec)] = dict(
+            n=int(cells[2]), nnz=int(cells[3]),
+            iters=[None if v == '-' else int(v) for v in vals[:7]],
+            log10_min_rel_error_A=[float(v) for v in vals[7:]])
+    rows = []
+    done = set()
+    for name, max_iter, prec in PAPER_RUNS:
+        A = load_matrix(name)
+        pub = published[(name, str(prec))]
+        assert A.shape[0] == pub['n'] and A.nnz == pub['nnz'], (name, A.shape, A.nnz, pub)
+        assert A.has_sorted_indices and A.indices.dtype == np.int32
+        if name not in done:
+            np.savez_compressed(os.path.join(HERE, f'tablemat_{name}.npz'), n=np.int64(A.shape[0]),
+                                indptr=A.indptr, indices=A.indices, data=A.data)
+            done.add(name)
+        rows.append(dict(matrix=name, preconditioner=str(prec), max_iter=max_iter, columns=PAPER_COLUMNS, **pub))
+    with open(os.path.join(HERE, 'paper_convergence_table.json'), 'w') as f:
+        json.dump(rows, f, indent=1)
+    total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.startswith('tablemat_'))
+    print(f'paper table: {len(rows)} rows, {len(done)} matrices, {total/1e6:.2f} MB')
+
+
 def main():
     print('numpy', np.__version__, 'scipy', scipy.__version__)
+    if sys.argv[1:] == ['table']:
+        paper_table()
+        return
     mats = {m: load_matrix(m) for m in ('bcsstk03', 'nos7', 'nos4', '494_bus', 'bcsstk14', 'bcsstm22', 'model_48_8_3')}
     for m, A in mats.items():
         assert A.has_sorted_indices and A.indices.dtype == np.int32
@@ -254,6 +317,7 @@ def main():
     for matrix, method, max_iter, prec, ks in plan:
         run_pair(matrix, mats[matrix], method, max_iter, prec, [k for k in ks if k < max_iter])
     mp_goldens()
+    paper_table()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith('.npz'))
     print(f'fixtures: {total/1e6:.2f} MB')
 
