@@ -160,13 +160,17 @@ int prcg_iteration(const prcg_t* h);
 /* which schedule the current session runs (valid after prcg_solve_begin): bit 0 one launch per
  * iteration (fused SpMM + update), bit 1 one-workgroup solver, bit 2 communicator present,
  * bit 3 merged exchange (halo rows ride on the one all-gather that carries the partial inner
- * products), bit 4 second halo communicator; bits 8..11 tile size in 256-slot steps.
+ * products), bit 4 second halo communicator, bits 5..7 the operator's stream encodings (valid after
+ * prcg_set_csr); bits 8..11 tile size in 256-slot steps.
  * No counterpart in the reference (diagnostics for tests and benchmarks). */
 #define PRCG_SCHED_FUSED 1
 #define PRCG_SCHED_SMALL 2
 #define PRCG_SCHED_COMM 4
 #define PRCG_SCHED_GATHER 8
 #define PRCG_SCHED_DUAL_COMM 16
+#define PRCG_SCHED_VALDICT 32   /* interior tiles stream 1-byte value-dictionary indices (lossless) */
+#define PRCG_SCHED_COL8 64      /* ... and 1-byte tile-relative column offsets */
+#define PRCG_SCHED_COL16 128    /* ... 2-byte */
 int prcg_schedule(const prcg_t* h);
 /* teacher forcing: declare that the state now loaded (prcg_set_vector / prcg_set_scalars
  * for iteration k) IS iteration k; the next prcg_iterate(h,1) produces k+1 */

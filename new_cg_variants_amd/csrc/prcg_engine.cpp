@@ -88,6 +88,9 @@ struct prcg_handle {
     bool c8_int = false, c8_bnd = false;
     bool want_c16 = true;                // PRCG_COL16=0 turns it off
     bool want_c8 = true;                 // PRCG_COL8=0: never narrower than 16 bit
+    DevBuf vidx8, vdict, vdesc;          // value dictionary (see CsrDev): 1-byte indices, entries, {first,count} per tile
+    bool vd_int = false, vd_bnd = false;
+    bool want_vdict = true;              // PRCG_VALDICT=0 turns it off
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
@@ -152,9 +155,13 @@ struct prcg_handle {
         const bool boundary = first >= nt_int && nt_bnd > 0;
         const bool ok = all ? (c16_int && (nt_bnd == 0 || c16_bnd)) : (boundary ? c16_bnd : c16_int);
         const bool ok8 = all ? (c8_int && (nt_bnd == 0 || c8_bnd)) : (boundary ? c8_bnd : c8_int);
+        const bool okv = all ? (vd_int && (nt_bnd == 0 || vd_bnd)) : (boundary ? vd_bnd : vd_int);
         return CsrDev{indptr.i(), col.i(), val.d(), ok ? static_cast<const unsigned short*>(col16.p) : nullptr,
                       ok8 ? static_cast<const unsigned char*>(col8.p) : nullptr,
-                      (ok || ok8) ? static_cast<const int*>(tile_base.p) + first : nullptr};
+                      (ok || ok8) ? static_cast<const int*>(tile_base.p) + first : nullptr,
+                      okv ? static_cast<const unsigned char*>(vidx8.p) : nullptr,
+                      okv ? static_cast<const double*>(vdict.p) : nullptr,
+                      okv ? static_cast<const int2*>(vdesc.p) + first : nullptr};
     }
     const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -766,6 +773,7 @@ int prcg_create(prcg_t** out, int device_id) {
     if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
     if (const char* e = getenv("PRCG_COL16")) h->want_c16 = atoi(e) != 0;
     if (const char* e = getenv("PRCG_COL8")) h->want_c8 = atoi(e) != 0;
+    if (const char* e = getenv("PRCG_VALDICT")) h->want_vdict = atoi(e) != 0;
     if (const char* e = getenv("PRCG_GATHER")) h->want_gather = atoi(e) != 0;
     if (const char* e = getenv("PRCG_GATHER_MAX_BYTES")) { const long v = atol(e); if (v >= 64) h->gather_max_bytes = v; }
     // the communication stream outranks the compute stream: its small kernels (halo pack,
@@ -923,6 +931,55 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     h->c8_int = fit8_int;
     h->c8_bnd = fit8_bnd;
 
+    // --- value dictionary (host, once): per streamed tile the distinct bit patterns of its values;
+    // a class of tiles qualifies if none of its tiles needs more than kDictMax entries.
+    std::vector<uint8_t> vidx;
+    std::vector<double> vdict;
+    std::vector<int32_t> vdesc;     // {first entry, count} per tile
+    bool vd_int = h->want_vdict && !t0.empty(), vd_bnd = h->want_vdict && !t1.empty();
+    if (vd_int || vd_bnd) {
+        const int cap = tile_cap_nnz(h->steps);
+        vidx.assign((size_t)nnz + 8, 0);
+        vdesc.assign(2 * (all.size() + 1), 0);
+        vdict.reserve(all.size() * 4);
+        constexpr int kHash = 256;          // open addressing, <= kDictMax live keys
+        uint64_t keys[kHash];
+        int16_t slot_of[kHash];
+        for (size_t ti = 0; ti < all.size(); ++ti) {
+            const bool interior = ti < t0.size();
+            if (!(interior ? vd_int : vd_bnd)) continue;
+            const Tile& tl = all[ti];
+            if (tl.nnz_end - tl.nnz_begin > cap || tl.nnz_end == tl.nnz_begin) continue;   // long row / empty: not streamed
+            for (int i = 0; i < kHash; ++i) slot_of[i] = -1;
+            const size_t first = vdict.size();
+            int count = 0;
+            bool ok = true;
+            for (int32_t q = tl.nnz_begin; q < tl.nnz_end; ++q) {
+                uint64_t bits;
+                memcpy(&bits, &data[q], sizeof bits);
+                uint32_t hsh = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 56);   // 8 bits
+                while (slot_of[hsh] >= 0 && keys[hsh] != bits) hsh = (hsh + 1) & (kHash - 1);
+                if (slot_of[hsh] < 0) {
+                    if (count == kDictMax) { ok = false; break; }
+                    keys[hsh] = bits;
+                    slot_of[hsh] = (int16_t)count++;
+                    vdict.push_back(data[q]);
+                }
+                vidx[q] = (uint8_t)slot_of[hsh];
+            }
+            if (!ok) {
+                vdict.resize(first);
+                if (interior) vd_int = false; else vd_bnd = false;
+                continue;
+            }
+            vdesc[2 * ti] = (int32_t)first;
+            vdesc[2 * ti + 1] = count;
+        }
+        if (vdict.size() >= (size_t)INT32_MAX) vd_int = vd_bnd = false;
+    }
+    h->vd_int = vd_int;
+    h->vd_bnd = vd_bnd && !t1.empty();
+
     // --- upload (arrays padded so the 16-byte stream loads never leave the allocation) ---
     const size_t pad = 8;
     HIPCHK(h, h->indptr.alloc(((size_t)n_rows + 1 + pad) * sizeof(int32_t)));
@@ -943,9 +1000,19 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         HIPCHK(h, hipMemcpy(h->col16.p, c16.data(), c16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(h, h->col8.alloc(c8.empty() ? 16 : c8.size()));
     if (!c8.empty()) HIPCHK(h, hipMemcpy(h->col8.p, c8.data(), c8.size(), hipMemcpyHostToDevice));
+    const bool any_vd = h->vd_int || h->vd_bnd;
+    HIPCHK(h, h->vidx8.alloc(any_vd ? vidx.size() : 16));
+    HIPCHK(h, h->vdict.alloc(any_vd ? (vdict.size() + kDictMax) * sizeof(double) : 16));
+    HIPCHK(h, h->vdesc.alloc(any_vd ? vdesc.size() * sizeof(int32_t) : 16));
+    if (any_vd) {
+        HIPCHK(h, hipMemcpy(h->vidx8.p, vidx.data(), vidx.size(), hipMemcpyHostToDevice));
+        if (!vdict.empty())
+            HIPCHK(h, hipMemcpy(h->vdict.p, vdict.data(), vdict.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->vdesc.p, vdesc.data(), vdesc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
     h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
-    HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost) * sizeof(double)));
+    HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost + kGatherPad) * sizeof(double)));
     HIPCHK(h, h->t1.alloc((size_t)2 * n_rows * sizeof(double)));
     HIPCHK(h, h->partA.alloc((size_t)8192 * kPartialStride * sizeof(double)));
     HIPCHK(h, h->partB.alloc((size_t)8192 * kPartialStride * sizeof(double)));
@@ -1047,7 +1114,10 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
           "prcg_solve_begin: error histories need x_true");
     CHECK(h, h->g == 0 || (h->multi() && h->have_halo), "ghost columns need a communicator and a halo plan");
     HIPCHK(h, hipSetDevice(h->dev));
-    const int64_t n = h->n, ne = h->n + h->g;
+    // every vector that feeds a matrix product has ghost room AND kGatherPad spare entries: the
+    // narrow column encodings decode a few out-of-tile bytes per tile against the tile's own base
+    // (products nobody reads); the pad keeps those gathers inside the allocation without a test
+    const int64_t n = h->n, ne = h->n + h->g + kGatherPad;
     const size_t D = sizeof(double);
     h->in_session = false;
     h->variant = variant;
@@ -1265,7 +1335,8 @@ int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
     return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
-           (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8);
+           (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
+           (h->vd_int ? PRCG_SCHED_VALDICT : 0) | (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0));
 }
 
 int prcg_set_iteration(prcg_t* h, int k) {

@@ -41,7 +41,19 @@ struct CsrDev {
     const unsigned short* col16;
     const unsigned char* col8;  // the same with 1 byte, when every tile spans < 256 columns (narrow bands)
     const int* tile_base;      // per tile, same indexing as the tile table
+    // Device-internal re-encoding of the VALUES ("value dictionary", built at prcg_set_csr when
+    // every streamed tile holds at most kDictMax distinct bit patterns -- stencils, constant
+    // off-diagonals): vidx8[q] = index of val[q] in the tile's dictionary vdict[vd[t].x ..+vd[t].y).
+    // 1 byte instead of 8 on the HBM stream; the dictionary entries ARE the original doubles, so
+    // every product is bit-identical.  Null when not built.
+    const unsigned char* vidx8;
+    const double* vdict;
+    const int2* vd;            // per tile (same indexing as the tile table): {first entry, count}
 };
+constexpr int kDictMax = 64;   // one dictionary entry per lane
+// spare entries behind every gather-source vector: the largest tile-relative column offset (16 bit)
+// added to a valid column of the tile never leaves the allocation
+constexpr int kGatherPad = 65536;
 
 // y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
 // partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.

@@ -266,22 +266,34 @@ __device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename Ve
 //              loads, each wave-instruction one contiguous 256 / 512 bytes).  Neighbouring
 //              lanes then gather NEIGHBOURING columns, so one gather instruction touches
 //              ~4x fewer cache lines, and the product stores into LDS are conflict-free.
-template <int STEPS, bool LS>
+// VD = true: the values arrive as 1-byte dictionary indices (4 per lane and step, one 32-bit
+// load) plus ONE dictionary entry per lane and tile
+template <int STEPS, bool LS, bool VD>
 struct MatRegs {
     int4 cc[STEPS];
     double2 va[STEPS], vb[STEPS];
 };
+template <int STEPS, bool LS>
+struct MatRegs<STEPS, LS, true> {
+    int4 cc[STEPS];
+    unsigned vi[STEPS];
+    double dv;
+};
 
-struct TileDesc { int rb, re, lo, hi, base; };
+struct TileDesc { int rb, re, lo, hi, base, vo, vc; };
 
-template <int C16>
-__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const int* __restrict__ tile_base, int t) {
+template <int C16, bool VD>
+__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const CsrDev& A, int t) {
     const int4 d = T4[t];
     TileDesc o;
     o.rb = __builtin_amdgcn_readfirstlane(d.x); o.re = __builtin_amdgcn_readfirstlane(d.y);
     o.lo = __builtin_amdgcn_readfirstlane(d.z); o.hi = __builtin_amdgcn_readfirstlane(d.w);
-    o.base = 0;
-    if constexpr (C16 != 0) o.base = __builtin_amdgcn_readfirstlane(tile_base[t]);
+    o.base = 0; o.vo = 0; o.vc = 0;
+    if constexpr (C16 != 0) o.base = __builtin_amdgcn_readfirstlane(A.tile_base[t]);
+    if constexpr (VD) {
+        const int2 v = A.vd[t];
+        o.vo = __builtin_amdgcn_readfirstlane(v.x); o.vc = __builtin_amdgcn_readfirstlane(v.y);
+    }
     return o;
 }
 
@@ -289,9 +301,10 @@ __device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const
 // lies past the tile re-reads the tile's first chunk (one hot line); its products land in
 // LDS slots nobody reads.
 // C16: width of the streamed column encoding: 0 = the int32 given, 16 / 8 = tile-relative offsets
-template <int STEPS, bool LS, int C16>
-__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS>& m) {
+template <int STEPS, bool LS, int C16, bool VD>
+__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS, VD>& m) {
     const int alo = d.lo & ~3;
+    if constexpr (VD) m.dv = lane < d.vc ? A.vdict[d.vo + lane] : 0.0;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         if constexpr (LS) {
@@ -317,28 +330,28 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
 #else
             if constexpr (C16 == 8) {
                 // 4 column indices in 4 bytes
+                // (entries of the 16-byte chunk that belong to a neighbouring tile were encoded
+                //  against ANOTHER base; decoded against this one they still land inside the
+                //  vector's kGatherPad spare entries, and their products are never read)
                 const uchar4 c = *reinterpret_cast<const uchar4*>(A.col8 + lb);
                 const int b = d.base;
-                m.cc[st] = make_int4((lb >= d.lo && lb < d.hi) ? b + (int)c.x : b,
-                                     (lb + 1 >= d.lo && lb + 1 < d.hi) ? b + (int)c.y : b,
-                                     (lb + 2 >= d.lo && lb + 2 < d.hi) ? b + (int)c.z : b,
-                                     (lb + 3 >= d.lo && lb + 3 < d.hi) ? b + (int)c.w : b);
+                m.cc[st] = make_int4(b + (int)c.x, b + (int)c.y, b + (int)c.z, b + (int)c.w);
             } else if constexpr (C16 == 16) {
                 // 4 column indices in 8 bytes, relative to the tile's smallest column
-                // (entries of the 16-byte chunk that belong to a neighbouring tile were encoded
-                //  against ANOTHER base: they must not be decoded into an address -- they get the
-                //  tile's own base column, a valid index, and their products are never read)
                 const ushort4 c = *reinterpret_cast<const ushort4*>(A.col16 + lb);
                 const int b = d.base;
-                m.cc[st] = make_int4((lb >= d.lo && lb < d.hi) ? b + (int)c.x : b,
-                                     (lb + 1 >= d.lo && lb + 1 < d.hi) ? b + (int)c.y : b,
-                                     (lb + 2 >= d.lo && lb + 2 < d.hi) ? b + (int)c.z : b,
-                                     (lb + 3 >= d.lo && lb + 3 < d.hi) ? b + (int)c.w : b);
+                m.cc[st] = make_int4(b + (int)c.x, b + (int)c.y, b + (int)c.z, b + (int)c.w);
             } else {
                 m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
             }
-            m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-            m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+            if constexpr (VD) {
+                // 4 dictionary indices in 4 bytes (bytes of a neighbouring tile index ITS dictionary;
+                // the lookup masks them into range and those products are never read)
+                m.vi[st] = *reinterpret_cast<const unsigned*>(A.vidx8 + lb);
+            } else {
+                m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+                m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
+            }
 #endif
         }
     }
@@ -346,10 +359,10 @@ __device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc
 
 // One tile: gather x[col], products -> this wave's LDS slice, then one lane per row sums
 // its row left to right.  `cur` holds the tile's val/col stream (loaded one tile ago).
-template <int NV, int EPI, int STEPS, bool LS>
+template <int NV, int EPI, int STEPS, bool LS, bool VD>
 __device__ __forceinline__ void process_tile(
-    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS>& cur,
-    typename VecT<NV>::type* my, const typename VecT<NV>::type* __restrict__ X,
+    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS, VD>& cur,
+    typename VecT<NV>::type* my, double* dict, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
     const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
 {
@@ -379,21 +392,33 @@ __device__ __forceinline__ void process_tile(
         xp0 = XPc[row0 < re ? row0 : rb];
         xp1 = XPc[row1 < re ? row1 : rb];
     }
+    if constexpr (VD) {
+        // the tile's dictionary: one entry per lane into this wave's LDS slot
+        dict[lane] = cur.dv;
+        wave_lds_sync();
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
+        double a0, a1, a2, a3;
+        if constexpr (VD) {
+            const unsigned v = cur.vi[st];
+            a0 = dict[v & 63u]; a1 = dict[(v >> 8) & 63u]; a2 = dict[(v >> 16) & 63u]; a3 = dict[(v >> 24) & 63u];   // & 63: in range whatever the byte
+        } else {
+            a0 = cur.va[st].x; a1 = cur.va[st].y; a2 = cur.vb[st].x; a3 = cur.vb[st].y;
+        }
         if constexpr (LS) {
             const int o = st * 256 + lane;
-            my[o] = vmul(cur.va[st].x, g0);
-            my[o + 64] = vmul(cur.va[st].y, g1);
-            my[o + 128] = vmul(cur.vb[st].x, g2);
-            my[o + 192] = vmul(cur.vb[st].y, g3);
+            my[o] = vmul(a0, g0);
+            my[o + 64] = vmul(a1, g1);
+            my[o + 128] = vmul(a2, g2);
+            my[o + 192] = vmul(a3, g3);
         } else {
             const int o = st * 256 + lane * 4;
-            my[o + 0] = vmul(cur.va[st].x, g0);
-            my[o + 1] = vmul(cur.va[st].y, g1);
-            my[o + 2] = vmul(cur.vb[st].x, g2);
-            my[o + 3] = vmul(cur.vb[st].y, g3);
+            my[o + 0] = vmul(a0, g0);
+            my[o + 1] = vmul(a1, g1);
+            my[o + 2] = vmul(a2, g2);
+            my[o + 3] = vmul(a3, g3);
         }
     }
     wave_lds_sync();
@@ -411,7 +436,7 @@ __device__ __forceinline__ void process_tile(
 // stream of tile t+W is already in flight (second register image) and the descriptor of
 // tile t+2W is being fetched.  The dependent chain per tile is then just
 // gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
-template <int NV, int EPI, int STEPS, bool LS, int C16>
+template <int NV, int EPI, int STEPS, bool LS, int C16, bool VD>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     CsrDev A, const Tile* __restrict__ tiles, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -423,12 +448,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     constexpr int kSlots = 256 * STEPS;
     constexpr int kCap = kSlots - 3;
     __shared__ V prod[kWaves][kSlots];
+    __shared__ double dict_lds[VD ? kWaves : 1][VD ? kDictMax : 1];
 
     const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
     const int4* __restrict__ T4 = reinterpret_cast<const int4*>(tiles);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     V* my = prod[wv];
+    double* dict = dict_lds[VD ? wv : 0];
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
@@ -486,12 +513,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         t = slot; tend = ntiles; step = W;
     }
 
-    MatRegs<STEPS, LS> m0, m1;
-    TileDesc d0 = {0, 0, 0, 0, 0}, d1 = {0, 0, 0, 0, 0};
+    MatRegs<STEPS, LS, VD> m0, m1;
+    TileDesc d0 = {0, 0, 0, 0, 0, 0, 0}, d1 = {0, 0, 0, 0, 0, 0, 0};
     if (t < tend) {
-        d0 = read_desc<C16>(T4, A.tile_base, t);
-        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS, C16>(A, d0, lane, m0);
-        if (t + step < tend) d1 = read_desc<C16>(T4, A.tile_base, t + step);
+        d0 = read_desc<C16, VD>(T4, A, t);
+        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS, C16, VD>(A, d0, lane, m0);
+        if (t + step < tend) d1 = read_desc<C16, VD>(T4, A, t + step);
     }
 
     while (t < tend) {
@@ -499,9 +526,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         {
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc<C16>(T4, A.tile_base, t2 < tend ? t2 : t);
-            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS, C16>(A, d1, lane, m1);
-            process_tile<NV, EPI, STEPS, LS>(A, d0, lane, m0, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
+            const TileDesc d2 = read_desc<C16, VD>(T4, A, t2 < tend ? t2 : t);
+            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS, C16, VD>(A, d1, lane, m1);
+            process_tile<NV, EPI, STEPS, LS, VD>(A, d0, lane, m0, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d0 = d2;
             t += step;
         }
@@ -510,9 +537,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         {
             const bool has_next = t + step < tend;
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc<C16>(T4, A.tile_base, t2 < tend ? t2 : t);
-            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS, C16>(A, d0, lane, m0);
-            process_tile<NV, EPI, STEPS, LS>(A, d1, lane, m1, my, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
+            const TileDesc d2 = read_desc<C16, VD>(T4, A, t2 < tend ? t2 : t);
+            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS, C16, VD>(A, d0, lane, m0);
+            process_tile<NV, EPI, STEPS, LS, VD>(A, d1, lane, m1, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             d1 = d2;
             t += step;
         }
@@ -1093,7 +1120,9 @@ int tile_grid(K kernel, int ntiles) {
             // TAG = NV*1000 + EPI*100 + STEPS*10 + (column bytes on the stream: 0 = int32, 1, 2);
             // with the narrower column stream one more resident block pays (S3: 2394 vs 2317 it/s)
             const int steps_ = (TAG / 10) % 10, narrow_ = TAG % 10;
-            const int tuned = steps_ == 4 ? 2 : ((steps_ == 2 && narrow_ != 0) ? 4 : 3);
+            // (codes 4..6: value dictionary beside int32 / 8-bit / 16-bit columns -- lighter stream, fewer
+            //  registers: 4 blocks also at 256-slot tiles, S2 4103 vs 3666 it/s, S1 36.6 k vs 35.4 k)
+            const int tuned = steps_ == 4 ? 2 : (((steps_ == 2 && narrow_ != 0) || narrow_ >= 4) ? 4 : 3);
             if (occ > tuned) occ = tuned;
         }
         // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
@@ -1126,13 +1155,15 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 {
     const bool ls = lane_strided();
     const int cw = (ls || A.tile_base == nullptr) ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
-    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, 0>
-                : (cw == 8 ? k_spmv_tiles<NV, EPI, STEPS, false, 8>
-                           : (cw == 16 ? k_spmv_tiles<NV, EPI, STEPS, false, 16> : k_spmv_tiles<NV, EPI, STEPS, false, 0>));
+    const bool vd = !ls && A.vidx8 != nullptr;   // value dictionary
+    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, 0, false>
+                : (cw == 8 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 8, true> : k_spmv_tiles<NV, EPI, STEPS, false, 8, false>)
+                           : (cw == 16 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 16, true> : k_spmv_tiles<NV, EPI, STEPS, false, 16, false>)
+                                       : (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 0, true> : k_spmv_tiles<NV, EPI, STEPS, false, 0, false>)));
     int grid;
-    if (cw == 8) grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles);
-    else if (cw == 16) grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles);
-    else grid = tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles);
+    if (cw == 8) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 5>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles);
+    else if (cw == 16) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 6>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles);
+    else grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 4>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,

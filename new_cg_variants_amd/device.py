@@ -157,7 +157,8 @@ class DeviceCSR:
         """Flags of the schedule the current session runs (prcg.h PRCG_SCHED_*)."""
         s = self._lib.prcg_schedule(self._h)
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
-                'dual_comm': bool(s & 16), 'tile_steps': (s >> 8) & 15}
+                'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
+                'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15}
 
     def set_iteration(self, k):
         self._check(self._lib.prcg_set_iteration(self._h, int(k)))

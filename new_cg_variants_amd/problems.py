@@ -115,7 +115,8 @@ def fem_like_3d(m, dof=3, rows=None):
     J = np.stack(cols, axis=1)
     valid = np.stack(valid, axis=1)
     # symmetric values: a function of the unordered pair {row, col}
-    V = -(1.0 + ((I[:, None] + J) % 7) / 16.0) / (27.0 * dof)
+    # (practically all distinct, as in an assembled FEM matrix: nothing for a value dictionary to find)
+    V = -(1.0 + (((I[:, None] + J) * (np.abs(I[:, None] - J) + 1)) % 1000003) / 1000003.0) / (27.0 * dof)
     V[J == I[:, None]] = 2.0
     return _assemble(I[:, None], J, V, valid, hi - lo, n)
 

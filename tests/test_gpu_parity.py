@@ -141,6 +141,57 @@ def test_spmv_column_encodings_agree(amd):
         assert np.array_equal(outs[0][1][:, 0], ref) and np.array_equal(outs[0][1][:, 1], A @ (0.5 * x)), name
 
 
+def test_spmv_value_dictionary_is_lossless(amd):
+    """Where every tile holds <= 64 distinct values (stencils, constant off-diagonals) the device
+    streams 1-byte dictionary indices instead of the doubles; the dictionary entries ARE the
+    doubles, so products must be bit-identical to SciPy and to the plain stream.  Covers: the
+    ex2b band (8-bit columns + dictionary), a 5-point stencil (16-bit columns + dictionary),
+    quantised random values, one tile with too many distinct values (whole class falls back)
+    and signed zeros (distinct bit patterns)."""
+    rng = np.random.default_rng(10)
+    P = amd['problems']
+    n = 120_000
+    lens = rng.integers(1, 12, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    near = (np.repeat(np.arange(n), lens) + rng.integers(-50, 50, size=int(indptr[-1]))).clip(0, n - 1).astype(np.int32)
+    quant = rng.integers(-3, 4, size=near.size) / 8.0
+    quant[::7] = -0.0
+    spoiled = quant.copy()
+    spoiled[indptr[n // 3]:indptr[n // 3] + 200] = rng.standard_normal(200)      # > 64 distinct values in one tile
+    cases = {'banded': (P.banded_ex2b(300_000, 7), True, 1), 'stencil': (P.laplace_2d(400, 300), True, 2),
+             'quantised': (sp.csr_matrix((quant, near, indptr), shape=(n, n)), True, 1),
+             'spoiled': (sp.csr_matrix((spoiled, near, indptr), shape=(n, n)), False, 1)}
+    for name, (A, expect, col_bytes) in cases.items():
+        x = rng.standard_normal(A.shape[0])
+        ref = A @ x
+        outs = []
+        for knobs in (None, {'PRCG_VALDICT': '0'}):
+            op = amd['device'].DeviceCSR(A, knobs=knobs)
+            sched = op.schedule()
+            assert sched['value_dict'] == (expect and knobs is None), (name, knobs, sched)
+            assert sched['col_bytes'] == col_bytes, (name, sched)
+            y, _ = op.matvec(x)
+            WU, _ = op.matmat2(np.stack([x, -3.0 * x], axis=1))
+            outs.append((y, WU))
+            op.close()
+        assert np.array_equal(outs[0][0], ref), name
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), name
+        assert np.array_equal(outs[0][1][:, 0], ref) and np.array_equal(outs[0][1][:, 1], A @ (-3.0 * x)), name
+    # whole solves: same bits with and without the dictionary
+    A = P.banded_ex2b(200_000, 7)
+    b, x0, _ = P.reference_rhs(A, A.shape[0])
+    hist = []
+    for knobs in (None, {'PRCG_VALDICT': '0'}):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        for variant in (amd['L'].PIPE_PR, amd['L'].HS):
+            op.begin(variant, b, x0, 60, hist_mask=amd['L'].HIST_BITS['updated_residual_2_norm'])
+            op.iterate(59)
+            op.sync()
+            hist.append(op.history()['updated_residual_2_norm'])
+        op.close()
+    assert np.array_equal(hist[0], hist[2]) and np.array_equal(hist[1], hist[3])
+
+
 def test_spmv_full_size_properties(amd):
     """S1 at full size (n=1e6): bit-exact vs SciPy, plus size-independent properties:
     A*1 = row sums, symmetry x'(Ay) = y'(Ax), linearity."""
