@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for s in $steps; do for g in $grids; do
   if [ $g = 0 ]; then unset PRCG_GRID_PER_CU; else export PRCG_GRID_PER_CU=$g; fi
   if [ $s = 0 ]; then unset PRCG_TILE_STEPS; else export PRCG_TILE_STEPS=$s; fi
-  timeout -k 10 200 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/sw.json 2>/dev/null
+  timeout -k 10 200 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --no-plain-values > gpurun_out/sw.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/sw.json"))
