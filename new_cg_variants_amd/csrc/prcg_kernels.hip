@@ -17,10 +17,6 @@
 
 #include "prcg_kernels.h"
 
-#ifndef PRCG_XP_PREFETCH
-#define PRCG_XP_PREFETCH 0   // measured slower on S3 (1.99-2.02k vs 2.07-2.10k it/s): more registers live across the gather
-#endif
-
 namespace prcg {
 namespace {
 
@@ -180,8 +176,7 @@ template <int NV, int EPI>
 __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
                                            int write_mask, const typename VecT<NV>::type* __restrict__ X,
                                            const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf,
-                                           const double2* pre_xp = nullptr)
+                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
 {
     if constexpr (NV == 1) {
         double* Y = reinterpret_cast<double*>(yout_);
@@ -204,7 +199,7 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
         // the OLD pair array X (other rows still gather from it) and written to the NEW one.
         double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
         double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
-        const double2 xp = pre_xp ? *pre_xp : XP[row];
+        const double2 xp = XP[row];
         const double2 rs = X[row];
         const double xn = xp.x + cf.al * xp.y;               // x += a p
         const double rn = rs.x - cf.al * rs.y;               // r -= a s
@@ -260,108 +255,98 @@ __device__ __forceinline__ typename VecT<NV>::type lds_row_sum(const typename Ve
 }
 
 // ---- register image of one tile's val/col stream ------------------------------------
-// LS = false: each lane holds 4 CONSECUTIVE nonzeros per step (one 16-byte load of 4
-//              column indices, two of the values);
-// LS = true : lane l holds nonzeros l, l+64, l+128, l+192 of the step (4-byte / 8-byte
-//              loads, each wave-instruction one contiguous 256 / 512 bytes).  Neighbouring
-//              lanes then gather NEIGHBOURING columns, so one gather instruction touches
-//              ~4x fewer cache lines, and the product stores into LDS are conflict-free.
+// Each lane holds 4 CONSECUTIVE nonzeros per step.  The image keeps the words AS LOADED
+// (column words of the encoding in use, values or dictionary indices); they are decoded only
+// when the tile is processed, one loop phase after the loads were issued -- a decode next to
+// the load would make the compiler wait for the load right there and serialise the pipeline.
+template <int C16> struct ColWord;
+template <> struct ColWord<0> { int4 w; };          // the int32 indices given
+template <> struct ColWord<16> { uint2 w; };        // 4 x 16-bit offsets from the tile's smallest column
+template <> struct ColWord<8> { unsigned w; };      // 4 x 8-bit offsets
+
+__device__ __forceinline__ int4 decode_cols(const ColWord<0>& c, int) { return c.w; }
+// (entries of the chunk that belong to a neighbouring tile were encoded against ANOTHER base;
+//  decoded against this one they still land inside the vector's kGatherPad spare entries, and
+//  their products are never read)
+__device__ __forceinline__ int4 decode_cols(const ColWord<16>& c, int b) {
+    return make_int4(b + (int)(c.w.x & 0xffffu), b + (int)(c.w.x >> 16), b + (int)(c.w.y & 0xffffu), b + (int)(c.w.y >> 16));
+}
+__device__ __forceinline__ int4 decode_cols(const ColWord<8>& c, int b) {
+    return make_int4(b + (int)(c.w & 255u), b + (int)((c.w >> 8) & 255u), b + (int)((c.w >> 16) & 255u), b + (int)(c.w >> 24));
+}
+
 // VD = true: the values arrive as 1-byte dictionary indices (4 per lane and step, one 32-bit
 // load) plus ONE dictionary entry per lane and tile
-template <int STEPS, bool LS, bool VD>
+template <int STEPS, int C16, bool VD>
 struct MatRegs {
-    int4 cc[STEPS];
+    ColWord<C16> c[STEPS];
     double2 va[STEPS], vb[STEPS];
 };
-template <int STEPS, bool LS>
-struct MatRegs<STEPS, LS, true> {
-    int4 cc[STEPS];
+template <int STEPS, int C16>
+struct MatRegs<STEPS, C16, true> {
+    ColWord<C16> c[STEPS];
     unsigned vi[STEPS];
     double dv;
 };
 
+// Tile descriptor: RawDesc = the words as loaded (two tiles ahead), TileDesc = the same made
+// wave-uniform -- again one loop phase later, so that nobody waits for the load where it is issued.
+struct RawDesc { int4 d; int base; int2 v; };
 struct TileDesc { int rb, re, lo, hi, base, vo, vc; };
 
+// (the three tables are separate __restrict__ const kernel arguments: wave-uniform loads from
+//  them become scalar loads, which retire on their own counter instead of queueing behind the
+//  vector loads and stores of the tile before)
 template <int C16, bool VD>
-__device__ __forceinline__ TileDesc read_desc(const int4* __restrict__ T4, const CsrDev& A, int t) {
-    const int4 d = T4[t];
+__device__ __forceinline__ RawDesc read_raw(const int4* __restrict__ T4, const int* __restrict__ tbase,
+                                            const int2* __restrict__ vdp, int t) {
+    RawDesc r;
+    r.d = T4[t];
+    r.base = 0; r.v = make_int2(0, 0);
+    if constexpr (C16 != 0) r.base = tbase[t];
+    if constexpr (VD) r.v = vdp[t];
+    return r;
+}
+__device__ __forceinline__ TileDesc cook(const RawDesc& r) {
     TileDesc o;
-    o.rb = __builtin_amdgcn_readfirstlane(d.x); o.re = __builtin_amdgcn_readfirstlane(d.y);
-    o.lo = __builtin_amdgcn_readfirstlane(d.z); o.hi = __builtin_amdgcn_readfirstlane(d.w);
-    o.base = 0; o.vo = 0; o.vc = 0;
-    if constexpr (C16 != 0) o.base = __builtin_amdgcn_readfirstlane(A.tile_base[t]);
-    if constexpr (VD) {
-        const int2 v = A.vd[t];
-        o.vo = __builtin_amdgcn_readfirstlane(v.x); o.vc = __builtin_amdgcn_readfirstlane(v.y);
-    }
+    o.rb = __builtin_amdgcn_readfirstlane(r.d.x); o.re = __builtin_amdgcn_readfirstlane(r.d.y);
+    o.lo = __builtin_amdgcn_readfirstlane(r.d.z); o.hi = __builtin_amdgcn_readfirstlane(r.d.w);
+    o.base = __builtin_amdgcn_readfirstlane(r.base);
+    o.vo = __builtin_amdgcn_readfirstlane(r.v.x); o.vc = __builtin_amdgcn_readfirstlane(r.v.y);
     return o;
 }
 
-// Branch-free 16-byte loads of the tile's column indices and values: a lane whose chunk
-// lies past the tile re-reads the tile's first chunk (one hot line); its products land in
-// LDS slots nobody reads.
+// Branch-free 16-byte (4-byte, 8-byte) loads of the tile's column words and values: a lane
+// whose chunk lies past the tile re-reads the tile's first chunk (one hot line); its products
+// land in LDS slots nobody reads.
 // C16: width of the streamed column encoding: 0 = the int32 given, 16 / 8 = tile-relative offsets
-template <int STEPS, bool LS, int C16, bool VD>
-__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, LS, VD>& m) {
+template <int STEPS, int C16, bool VD>
+__device__ __forceinline__ void load_tile_stream(const CsrDev& A, const TileDesc& d, int lane, MatRegs<STEPS, C16, VD>& m) {
     const int alo = d.lo & ~3;
     if constexpr (VD) m.dv = lane < d.vc ? A.vdict[d.vo + lane] : 0.0;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        if constexpr (LS) {
-            const int b0 = alo + st * 256 + lane;
-            const int i0 = b0 < d.hi ? b0 : alo, i1 = b0 + 64 < d.hi ? b0 + 64 : alo;
-            const int i2 = b0 + 128 < d.hi ? b0 + 128 : alo, i3 = b0 + 192 < d.hi ? b0 + 192 : alo;
-            m.cc[st] = make_int4(A.col[i0], A.col[i1], A.col[i2], A.col[i3]);
-            m.va[st] = make_double2(A.val[i0], A.val[i1]);
-            m.vb[st] = make_double2(A.val[i2], A.val[i3]);
+        const int base = alo + st * 256 + lane * 4;
+        const int lb = base < d.hi ? base : alo;
+        if constexpr (C16 == 8) m.c[st].w = *reinterpret_cast<const unsigned*>(A.col8 + lb);
+        else if constexpr (C16 == 16) m.c[st].w = *reinterpret_cast<const uint2*>(A.col16 + lb);
+        else m.c[st].w = *reinterpret_cast<const int4*>(A.col + lb);
+        if constexpr (VD) {
+            // 4 dictionary indices in 4 bytes (bytes of a neighbouring tile index ITS dictionary;
+            // the lookup masks them into range and those products are never read)
+            m.vi[st] = *reinterpret_cast<const unsigned*>(A.vidx8 + lb);
         } else {
-            const int base = alo + st * 256 + lane * 4;
-            const int lb = base < d.hi ? base : alo;
-#ifdef PRCG_NT_STREAM
-            // the matrix is read exactly once per product: keep it from displacing x in L2
-            typedef int v4i_t __attribute__((ext_vector_type(4)));
-            typedef double v2d_t __attribute__((ext_vector_type(2)));
-            const v4i_t c4 = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(A.col + lb));
-            const v2d_t a2 = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(A.val + lb));
-            const v2d_t b2 = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(A.val + lb + 2));
-            m.cc[st] = make_int4(c4.x, c4.y, c4.z, c4.w);
-            m.va[st] = make_double2(a2.x, a2.y);
-            m.vb[st] = make_double2(b2.x, b2.y);
-#else
-            if constexpr (C16 == 8) {
-                // 4 column indices in 4 bytes
-                // (entries of the 16-byte chunk that belong to a neighbouring tile were encoded
-                //  against ANOTHER base; decoded against this one they still land inside the
-                //  vector's kGatherPad spare entries, and their products are never read)
-                const uchar4 c = *reinterpret_cast<const uchar4*>(A.col8 + lb);
-                const int b = d.base;
-                m.cc[st] = make_int4(b + (int)c.x, b + (int)c.y, b + (int)c.z, b + (int)c.w);
-            } else if constexpr (C16 == 16) {
-                // 4 column indices in 8 bytes, relative to the tile's smallest column
-                const ushort4 c = *reinterpret_cast<const ushort4*>(A.col16 + lb);
-                const int b = d.base;
-                m.cc[st] = make_int4(b + (int)c.x, b + (int)c.y, b + (int)c.z, b + (int)c.w);
-            } else {
-                m.cc[st] = *reinterpret_cast<const int4*>(A.col + lb);
-            }
-            if constexpr (VD) {
-                // 4 dictionary indices in 4 bytes (bytes of a neighbouring tile index ITS dictionary;
-                // the lookup masks them into range and those products are never read)
-                m.vi[st] = *reinterpret_cast<const unsigned*>(A.vidx8 + lb);
-            } else {
-                m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
-                m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
-            }
-#endif
+            m.va[st] = *reinterpret_cast<const double2*>(A.val + lb);
+            m.vb[st] = *reinterpret_cast<const double2*>(A.val + lb + 2);
         }
     }
 }
 
 // One tile: gather x[col], products -> this wave's LDS slice, then one lane per row sums
 // its row left to right.  `cur` holds the tile's val/col stream (loaded one tile ago).
-template <int NV, int EPI, int STEPS, bool LS, bool VD>
+template <int NV, int EPI, int STEPS, int C16, bool VD>
 __device__ __forceinline__ void process_tile(
-    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, LS, VD>& cur,
+    const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, C16, VD>& cur,
     typename VecT<NV>::type* my, double* dict, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
     const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
@@ -384,14 +369,6 @@ __device__ __forceinline__ void process_tile(
     const int* ip0 = A.indptr + (row0 < re ? row0 : rb);
     const int* ip1 = A.indptr + (row1 < re ? row1 : rb);
     const int s0r = ip0[0], e0r = ip0[1], s1r = ip1[0], e1r = ip1[1];
-    double2 xp0 = make_double2(0.0, 0.0), xp1 = xp0;
-    if constexpr (PRCG_XP_PREFETCH && EPI == kEpiPipeFused) {
-        // the rows' (x,p) pairs for the fused update: issued with the row pointers, used
-        // after the row sums
-        const double2* XPc = reinterpret_cast<const double2*>(yout_);
-        xp0 = XPc[row0 < re ? row0 : rb];
-        xp1 = XPc[row1 < re ? row1 : rb];
-    }
     if constexpr (VD) {
         // the tile's dictionary: one entry per lane into this wave's LDS slot
         dict[lane] = cur.dv;
@@ -399,7 +376,8 @@ __device__ __forceinline__ void process_tile(
     }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        const V g0 = X[cur.cc[st].x], g1 = X[cur.cc[st].y], g2 = X[cur.cc[st].z], g3 = X[cur.cc[st].w];
+        const int4 cc = decode_cols(cur.c[st], d.base);
+        const V g0 = X[cc.x], g1 = X[cc.y], g2 = X[cc.z], g3 = X[cc.w];
         double a0, a1, a2, a3;
         if constexpr (VD) {
             const unsigned v = cur.vi[st];
@@ -407,23 +385,15 @@ __device__ __forceinline__ void process_tile(
         } else {
             a0 = cur.va[st].x; a1 = cur.va[st].y; a2 = cur.vb[st].x; a3 = cur.vb[st].y;
         }
-        if constexpr (LS) {
-            const int o = st * 256 + lane;
-            my[o] = vmul(a0, g0);
-            my[o + 64] = vmul(a1, g1);
-            my[o + 128] = vmul(a2, g2);
-            my[o + 192] = vmul(a3, g3);
-        } else {
-            const int o = st * 256 + lane * 4;
-            my[o + 0] = vmul(a0, g0);
-            my[o + 1] = vmul(a1, g1);
-            my[o + 2] = vmul(a2, g2);
-            my[o + 3] = vmul(a3, g3);
-        }
+        const int o = st * 256 + lane * 4;
+        my[o + 0] = vmul(a0, g0);
+        my[o + 1] = vmul(a1, g1);
+        my[o + 2] = vmul(a2, g2);
+        my[o + 3] = vmul(a3, g3);
     }
     wave_lds_sync();
-    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, PRCG_XP_PREFETCH && EPI == kEpiPipeFused ? &xp0 : nullptr);
-    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, PRCG_XP_PREFETCH && EPI == kEpiPipeFused ? &xp1 : nullptr);
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
     for (int row = rb + 128 + lane; row < re; row += 64) {
         const int s = A.indptr[row] - alo;
         const int e = A.indptr[row + 1] - alo;
@@ -436,9 +406,10 @@ __device__ __forceinline__ void process_tile(
 // stream of tile t+W is already in flight (second register image) and the descriptor of
 // tile t+2W is being fetched.  The dependent chain per tile is then just
 // gather -> LDS -> row sums, and every wave keeps HBM loads outstanding all the time.
-template <int NV, int EPI, int STEPS, bool LS, int C16, bool VD>
+// Everything loaded ahead stays RAW until the phase that needs it (see MatRegs / RawDesc).
+template <int NV, int EPI, int STEPS, int C16, bool VD>
 __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
-    CsrDev A, const Tile* __restrict__ tiles, int ntiles,
+    CsrDev A, const Tile* __restrict__ tiles, const int* __restrict__ tbase, const int2* __restrict__ vdp, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d,
     double* __restrict__ ep_st, double* __restrict__ partials, int chunked, double* __restrict__ aux,
@@ -513,34 +484,37 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
         t = slot; tend = ntiles; step = W;
     }
 
-    MatRegs<STEPS, LS, VD> m0, m1;
+    MatRegs<STEPS, C16, VD> m0, m1;
     TileDesc d0 = {0, 0, 0, 0, 0, 0, 0}, d1 = {0, 0, 0, 0, 0, 0, 0};
+    RawDesc rn = {make_int4(0, 0, 0, 0), 0, make_int2(0, 0)};     // raw descriptor of the tile after the current one
     if (t < tend) {
-        d0 = read_desc<C16, VD>(T4, A, t);
-        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, LS, C16, VD>(A, d0, lane, m0);
-        if (t + step < tend) d1 = read_desc<C16, VD>(T4, A, t + step);
+        d0 = cook(read_raw<C16, VD>(T4, tbase, vdp, t));
+        if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, C16, VD>(A, d0, lane, m0);
+        if (t + step < tend) rn = read_raw<C16, VD>(T4, tbase, vdp, t + step);
     }
 
     while (t < tend) {
-        // ---- even phase: tile t lives in m0 / d0 ----
+        // ---- even phase: tile t lives in m0 / d0; rn = raw descriptor of tile t+step (loaded a phase ago) ----
         {
-            const bool has_next = t + step < tend;
+            if (t + step < tend) {
+                d1 = cook(rn);
+                if (d1.hi - d1.lo <= kCap) load_tile_stream<STEPS, C16, VD>(A, d1, lane, m1);
+            }
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc<C16, VD>(T4, A, t2 < tend ? t2 : t);
-            if (has_next && (d1.hi - d1.lo <= kCap)) load_tile_stream<STEPS, LS, C16, VD>(A, d1, lane, m1);
-            process_tile<NV, EPI, STEPS, LS, VD>(A, d0, lane, m0, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
-            d0 = d2;
+            rn = read_raw<C16, VD>(T4, tbase, vdp, t2 < tend ? t2 : t);
+            process_tile<NV, EPI, STEPS, C16, VD>(A, d0, lane, m0, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             t += step;
         }
         if (t >= tend) break;
         // ---- odd phase: tile t lives in m1 / d1 ----
         {
-            const bool has_next = t + step < tend;
+            if (t + step < tend) {
+                d0 = cook(rn);
+                if (d0.hi - d0.lo <= kCap) load_tile_stream<STEPS, C16, VD>(A, d0, lane, m0);
+            }
             const int t2 = t + 2 * step;
-            const TileDesc d2 = read_desc<C16, VD>(T4, A, t2 < tend ? t2 : t);
-            if (has_next && (d0.hi - d0.lo <= kCap)) load_tile_stream<STEPS, LS, C16, VD>(A, d0, lane, m0);
-            process_tile<NV, EPI, STEPS, LS, VD>(A, d1, lane, m1, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
-            d1 = d2;
+            rn = read_raw<C16, VD>(T4, tbase, vdp, t2 < tend ? t2 : t);
+            process_tile<NV, EPI, STEPS, C16, VD>(A, d1, lane, m1, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
             t += step;
         }
     }
@@ -1140,33 +1114,23 @@ int tile_grid(K kernel, int ntiles) {
 // ---- launch wrappers -------------------------------------------------------------------
 #define PRCG_LAUNCH_OK() (hipGetLastError() == hipSuccess)
 
-// experiment knob: PRCG_LANE_STRIDED=1 selects the lane-strided layout (measured equal or
-// slightly slower than 4 consecutive nonzeros per lane with 16-byte loads)
-bool lane_strided() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PRCG_LANE_STRIDED"); v = e ? (atoi(e) != 0) : 0; }
-    return v != 0;
-}
-
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
                  double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
-    const bool ls = lane_strided();
-    const int cw = (ls || A.tile_base == nullptr) ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
-    const bool vd = !ls && A.vidx8 != nullptr;   // value dictionary
-    auto k = ls ? k_spmv_tiles<NV, EPI, STEPS, true, 0, false>
-                : (cw == 8 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 8, true> : k_spmv_tiles<NV, EPI, STEPS, false, 8, false>)
-                           : (cw == 16 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 16, true> : k_spmv_tiles<NV, EPI, STEPS, false, 16, false>)
-                                       : (vd ? k_spmv_tiles<NV, EPI, STEPS, false, 0, true> : k_spmv_tiles<NV, EPI, STEPS, false, 0, false>)));
+    const int cw = A.tile_base == nullptr ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
+    const bool vd = A.vidx8 != nullptr;   // value dictionary
+    auto k = cw == 8 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, 8, true> : k_spmv_tiles<NV, EPI, STEPS, 8, false>)
+                     : (cw == 16 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, 16, true> : k_spmv_tiles<NV, EPI, STEPS, 16, false>)
+                                 : (vd ? k_spmv_tiles<NV, EPI, STEPS, 0, true> : k_spmv_tiles<NV, EPI, STEPS, 0, false>));
     int grid;
     if (cw == 8) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 5>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles);
     else if (cw == 16) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 6>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles);
     else grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 4>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles);
     static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, A.tile_base, A.vd, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
                        partials, chunked, aux, fz);
     return PRCG_LAUNCH_OK() ? grid : -1;
 }
