@@ -210,6 +210,8 @@ def main():
         if os.path.exists(tfile):
             try:
                 key = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
+                if fused and not sched['value_dict']:
+                    key += ':plain_values'
                 traffic = json.load(open(tfile)).get(key)
             except Exception:
                 traffic = None
