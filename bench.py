@@ -124,6 +124,7 @@ def main():
     nnz_local = int(A_rows.nnz)
     nnz_total = sum(comm.allgather_obj(nnz_local))
 
+    t_setup = time.perf_counter()
     if world == 1 and args.force_comm:
         from new_cg_variants_amd.device import DeviceCSR
         uid = np.zeros((2, 128), dtype=np.uint8)
@@ -134,6 +135,7 @@ def main():
     else:
         op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
         dev = op.dev
+    t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
     variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR}[args.variant]
 
     # ---- standalone SpMV rate (north_star: effective SpMV HBM GB/s vs roofline) -----------
@@ -222,7 +224,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
                        'partition': f'row blocks x{world}', 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
-                       'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6},
+                       'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6,
+                       'operator_setup_s': t_setup},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': kname,
                          'algorithmic_bytes_per_launch': kbytes, 'avg_launch_ms': tim['spmv_ms'],

@@ -209,6 +209,16 @@ int prcg_solve(prcg_t* h, int variant, const double* b, const double* x0, int ma
 int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
                         int cap_nnz, int cap_rows, int32_t* tiles_out, int64_t capacity,
                         int64_t* n_class0);
+/* Merged exchange of the multi-GPU pipelined loop (small halos ride on the one all-gather per
+ * iteration): where in the gathered buffer do this rank's ghost rows lie?  `tables`: every rank's
+ * send table, doubles_per_table doubles each: [n_peers, (peer, first row of its list, rows)...];
+ * slot_doubles = 8 + 2 * (largest send list of any rank).  ghost_src[j] = index, in 16-byte pairs,
+ * of ghost j (ghosts ordered as prcg_set_halo's receive segments).  Returns 0, 1+q if peer q's
+ * table holds no list of the expected length for this rank, -1 on a bad argument.  What
+ * prcg_solve_begin computes internally after all-gathering the tables; exported for the CPU tests. */
+int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int n_peers,
+                     const int32_t* peer_rank, const int64_t* recv_ptr, int64_t slot_doubles,
+                     int32_t* ghost_src);
 /* the tile caps the device kernels were compiled for */
 void prcg_tile_caps(int* cap_nnz, int* cap_rows);
 

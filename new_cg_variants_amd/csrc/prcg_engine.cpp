@@ -299,19 +299,9 @@ int plan_gather(prcg_t* h) {
     HIPCHK(h, hipStreamSynchronize(h->sc));
     // (c) ghost j  <-  pair index into the gathered buffer
     std::vector<int32_t> src((size_t)h->g + 1, 0);
-    for (int q = 0; q < np; ++q) {
-        const int64_t want = h->recv_ptr[q + 1] - h->recv_ptr[q];
-        if (want == 0) continue;
-        const int pr = h->peer_rank[q];
-        const double* pt = tab.data() + (size_t)pr * T;
-        int64_t off = -1;
-        for (int e = 0; e < (int)pt[0]; ++e)
-            if ((int)pt[1 + 3 * e] == h->rank && (int64_t)pt[3 + 3 * e] == want) { off = (int64_t)pt[2 + 3 * e]; break; }
-        CHECK(h, off >= 0, "halo plans disagree: rank %d sends no list of %lld rows to rank %d", pr, (long long)want, h->rank);
-        const int64_t first = ((int64_t)pr * slot + 8) / 2 + off;
-        CHECK(h, first + want < (int64_t)INT32_MAX, "merged exchange: index overflow");
-        for (int64_t i = 0; i < want; ++i) src[(size_t)(h->recv_ptr[q] + i)] = (int32_t)(first + i);
-    }
+    const int bad = plan_gather_sources(h->rank, T, tab.data(), np, h->peer_rank.data(), h->recv_ptr.data(), slot, src.data());
+    CHECK(h, bad == 0, "halo plans disagree: rank %d sends no list of the expected length to rank %d (or index overflow)",
+          bad > 0 ? h->peer_rank[bad - 1] : -1, h->rank);
     HIPCHK(h, h->ghost_src.alloc(src.size() * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->ghost_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(h, h->gbuf.alloc((size_t)R * slot * sizeof(double)));
@@ -1497,6 +1487,13 @@ int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_cla
     for (const auto& t : t0) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
     for (const auto& t : t1) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
     return total;
+}
+
+int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int n_peers, const int32_t* peer_rank,
+                     const int64_t* recv_ptr, int64_t slot_doubles, int32_t* ghost_src) {
+    if (rank < 0 || doubles_per_table < 1 || !tables || n_peers < 0 || slot_doubles < 8 || (slot_doubles & 1)) return -1;
+    if (n_peers > 0 && (!peer_rank || !recv_ptr || !ghost_src)) return -1;
+    return plan_gather_sources(rank, doubles_per_table, tables, n_peers, peer_rank, recv_ptr, slot_doubles, ghost_src);
 }
 
 void prcg_tile_caps(int* cap_nnz, int* cap_rows) {

@@ -43,4 +43,22 @@ void plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
     }
 }
 
+int plan_gather_sources(int rank, int T, const double* tab, int n_peers, const int32_t* peer_rank,
+                        const int64_t* recv_ptr, int64_t slot, int32_t* src) {
+    for (int q = 0; q < n_peers; ++q) {
+        const int64_t want = recv_ptr[q + 1] - recv_ptr[q];
+        if (want == 0) continue;
+        const int pr = peer_rank[q];
+        const double* pt = tab + (size_t)pr * T;
+        int64_t off = -1;
+        for (int e = 0; e < (int)pt[0]; ++e)
+            if ((int)pt[1 + 3 * e] == rank && (int64_t)pt[3 + 3 * e] == want) { off = (int64_t)pt[2 + 3 * e]; break; }
+        if (off < 0) return 1 + q;
+        const int64_t first = ((int64_t)pr * slot + 8) / 2 + off;
+        if (first + want >= (int64_t)INT32_MAX) return 1 + q;
+        for (int64_t i = 0; i < want; ++i) src[(size_t)(recv_ptr[q] + i)] = (int32_t)(first + i);
+    }
+    return 0;
+}
+
 }  // namespace prcg

@@ -121,3 +121,55 @@ def test_generators_match_their_stated_sizes():
     # ex2b.c:93: diag = 1 + (i/(n-1)) (kappa-1) rho^(n-1-i); last row has the full kappa
     assert B[4999, 4999] == 1.0 + (1e6 - 1.0)
     assert B[0, 0] == 1.0 and B[10, 11] == 1e-4
+
+
+@pytest.mark.parametrize('workload,nranks', [('s3_small', 2), ('s3_small', 5), ('s1_small', 3), ('s1_small', 4)])
+def test_merged_exchange_plan_moves_the_right_rows(workload, nranks):
+    """The multi-GPU pipelined loop moves a small halo inside the one all-gather per iteration
+    (DESIGN.md section 5).  Each rank learns from the others' send tables where its ghost rows lie
+    in the gathered buffer (prcg_plan_gather = the host code prcg_solve_begin runs after
+    all-gathering the tables).  Simulate all ranks in one process: pack as k_gather_pack does,
+    concatenate the slots as ncclAllGather does, pick as k_gather_unpack does -- every rank must
+    end up with exactly the (r,s) rows of its ghost columns."""
+    from new_cg_variants_amd import partition
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    offsets, parts = partition.split_serial(A, nranks)
+    rng = np.random.default_rng(4)
+    RS = rng.standard_normal((n, 2))                      # global (r,s) pairs
+    max_send = max(int(p[2]['send_ptr'][-1]) for p in parts)
+    max_peers = max(len(p[2]['peers']) for p in parts)
+    slot = 8 + 2 * max_send
+    T = 1 + 3 * max_peers
+    tables = np.zeros((nranks, T))
+    gbuf = np.zeros((nranks, slot))
+    for r, (A_loc, ghost_ids, halo) in enumerate(parts):
+        tables[r, 0] = len(halo['peers'])
+        for q, peer in enumerate(halo['peers']):
+            tables[r, 1 + 3 * q:4 + 3 * q] = (peer, halo['send_ptr'][q], halo['send_ptr'][q + 1] - halo['send_ptr'][q])
+        lo = offsets[r]
+        gbuf[r, :5] = r + 1.0                                                    # stand-in for the partial sums
+        rows = RS[lo + halo['send_idx']]                                         # k_gather_pack: rows[j] = rs[send_idx[j]]
+        gbuf[r, 8:8 + 2 * rows.shape[0]] = rows.ravel()
+    pairs = gbuf.reshape(-1, 2)                                                  # the gathered buffer, viewed as 16-byte pairs
+    moved = 0
+    for r, (A_loc, ghost_ids, halo) in enumerate(parts):
+        g = ghost_ids.size
+        src = np.full(g + 1, -1, dtype=np.int32)
+        peers = np.ascontiguousarray(halo['peers'], dtype=np.int32)
+        recv_ptr = np.ascontiguousarray(halo['recv_ptr'], dtype=np.int64)
+        rc = L.lib().prcg_plan_gather(r, T, L.ptr(tables), len(peers), L.ptr(peers), L.ptr(recv_ptr), slot, L.ptr(src))
+        assert rc == 0
+        got = pairs[src[:g]]                                                     # k_gather_unpack: rs_ghost[j] = g2[ghost_src[j]]
+        assert np.array_equal(got, RS[ghost_ids]), (workload, nranks, r)
+        moved += g
+        assert np.array_equal(gbuf[:, :5].sum(axis=0), np.full(5, nranks * (nranks + 1) / 2))
+    assert moved > 0
+    # a table that does not match (a peer "forgets" its list for rank 0) is reported, not mis-indexed
+    A_loc, ghost_ids, halo = parts[0]
+    broken = tables.copy()
+    broken[int(halo['peers'][0]), 0] = 0
+    src = np.zeros(ghost_ids.size + 1, dtype=np.int32)
+    peers = np.ascontiguousarray(halo['peers'], dtype=np.int32)
+    recv_ptr = np.ascontiguousarray(halo['recv_ptr'], dtype=np.int64)
+    assert L.lib().prcg_plan_gather(0, T, L.ptr(broken), len(peers), L.ptr(peers), L.ptr(recv_ptr), slot, L.ptr(src)) == 1
