@@ -75,7 +75,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--workload', default='s3', choices=['s1', 's2', 's3', 's4', 's4b', 's3_8th', 's1_small', 's3_small'])
+    ap.add_argument('--workload', default='s3',
+                    help='s1 s2 s3 s4 s4b s3_8th s1_small s3_small; queen if QUEEN_4147_MTX names the MatrixMarket file')
     ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-comm', action='store_true',

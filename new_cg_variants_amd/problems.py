@@ -162,3 +162,28 @@ WORKLOADS = {
     's3_small': dict(desc='ex2b banded n=20000 k=7', n=20000,
                      make=lambda rows=None: banded_ex2b(20000, 7, rows=rows)),
 }
+
+
+def _register_queen():
+    """S4 is SuiteSparse Queen_4147 itself when QUEEN_4147_MTX points to the
+    MatrixMarket file (it cannot be fetched in the build environment).  Read once per process."""
+    import os
+    path = os.environ.get('QUEEN_4147_MTX')
+    if not path or not os.path.exists(path):
+        return
+    cache = {}
+
+    def make(rows=None):
+        if 'A' not in cache:
+            import scipy.io
+            cache['A'] = sp.csr_matrix(scipy.io.mmread(path)).astype(np.float64)
+            cache['A'].sort_indices()
+        return _row_slice(cache['A'], rows)
+
+    import scipy.io
+    n = int(scipy.io.mminfo(path)[0])
+    WORKLOADS['queen'] = dict(desc=f'SuiteSparse Queen_4147 from {os.path.basename(path)} (n={n})', n=n, make=make)
+
+
+_register_queen()
+
