@@ -58,8 +58,8 @@ constexpr int kGatherPad = 65536;
 // y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
 // partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.
 // returns the grid size used (needed to reduce the partials), <0 on launch failure.
-// (tile_first: index of tiles[0] in the full tile table = index into A.tile_base;
-//  use16: stream the 16-bit column encoding -- only if all tiles of the range qualified)
+// (A.tile_base / A.vd are indexed like `tiles`: the caller offsets all three together; the
+//  narrow encodings are non-null in A only if every tile of the range qualified)
 int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
                 const double* ep_r, const double* ep_d, double* ep_st,

@@ -1,7 +1,7 @@
 """Distributed CG variants with the call shape of the reference's mpi4py experiment:
 
     sol, times = variant(comm, A, b, max_iter)
-    (scaling_experiments_mpi4py/scaling_tests.py:71; cg_variants/pipe_pr_cg.py:7, hs_cg.py:7)
+    (scaling_experiments_mpi4py/scaling_tests.py:71; cg_variants/{pipe_pr_cg,hs_cg,cg_cg,gv_cg,pr_cg}.py:7)
 
 one process per GPU.  ``comm`` is a communicator-like object (``TorchComm`` wraps
 torch.distributed; anything with Get_rank/Get_size/Barrier/allgather_obj/bcast_obj
@@ -163,4 +163,16 @@ def pr_cg(comm, A, b, max_iter):
     return _timed(comm, _as_operator(comm, A), L.PR, b, max_iter)
 
 
-__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'pipe_p_cg', 'hs_cg', 'pr_cg']
+def cg_cg(comm, A, b, max_iter):
+    """Chronopoulos-Gear CG (cg_variants/cg_cg.py:7): one reduction {nu, eta} per iteration, after the
+    product it depends on -- nothing to overlap it with."""
+    return _timed(comm, _as_operator(comm, A), L.CG_CG, b, max_iter)
+
+
+def gv_cg(comm, A, b, max_iter):
+    """Ghysels-Vanroose pipelined CG (cg_variants/gv_cg.py:7): the reduction {nu, eta} is issued before
+    the product t = A w and overlaps it on the communication stream."""
+    return _timed(comm, _as_operator(comm, A), L.GV, b, max_iter)
+
+
+__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'pipe_p_cg', 'hs_cg', 'pr_cg', 'cg_cg', 'gv_cg']

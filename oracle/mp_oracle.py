@@ -4,6 +4,7 @@ CPU restatement of the reference's mpi4py scaling variants:
 
 * ``pipe_pr_cg(comm, A, b, max_iter)``  MP/cg_variants/pipe_pr_cg.py:7-89
 * ``hs_cg(comm, A, b, max_iter)``       MP/cg_variants/hs_cg.py:7-66
+* ``cg_cg``, ``gv_cg``, ``pr_cg``        MP/cg_variants/{cg_cg,gv_cg,pr_cg}.py
 
 MP/ = /root/reference/predict_and_recompute/scaling_experiments_mpi4py/.
 
@@ -118,6 +119,113 @@ def hs_cg(comm, A, b, max_iter, dot=np.dot):
             x += alpha * p                                     # :59
             r -= alpha * s                                     # :60
     comm.Barrier()                                             # :62
+    if rank == 0:
+        times['tot'] = time.perf_counter() - t0
+    return x, times
+
+
+def _scalar_allreduce(comm, *vals):
+    """The reference keeps its scalars in 1-element arrays (views of the reduction buffers);
+    arithmetic on those is what this restatement is pinned against (e.g. ``alpha**2`` on a
+    1-element array is an exact square, on a NumPy scalar it is libm pow)."""
+    out = comm.allreduce_sum(np.array([float(v) for v in vals]))
+    return [out[i:i + 1].copy() for i in range(len(vals))]
+
+
+def cg_cg(comm, A, b, max_iter, dot=np.dot):
+    """Chronopoulos-Gear CG, MP/cg_variants/cg_cg.py:7-71 (two reductions per iteration: the
+    product w = A r -- a data reduction in the reference's column-block layout -- and {nu, eta})."""
+    rank = comm.Get_rank()
+    times = {'tot': 0.} if rank == 0 else None                 # cg_cg.py:13-16
+    alpha = np.zeros(1)                                        # :19
+    nu = np.ones(1)                                            # :22
+    x = np.zeros_like(b)                                       # :33
+    r = np.array(b, copy=True)                                 # :34
+    p = np.zeros_like(b)                                       # :35
+    s = np.zeros_like(b)                                       # :36
+    comm.Barrier()                                             # :42
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        for k in range(max_iter):                              # :46
+            w = A.matvec_local(r)                              # :48-50
+            nu_ = nu.copy()                                    # :52
+            nu, eta = _scalar_allreduce(comm, dot(r, r), dot(r, w))   # :53-56
+            beta = nu / nu_                                    # :58
+            p *= beta                                          # :60
+            p += r                                             # :61
+            s *= beta                                          # :62
+            s += w                                             # :63
+            mu = eta - (beta / alpha) * nu if k > 0 else eta   # :65
+            alpha = nu / mu                                    # :66
+            x += alpha * p                                     # :68
+            r -= alpha * s                                     # :69
+    comm.Barrier()                                             # :71
+    if rank == 0:
+        times['tot'] = time.perf_counter() - t0
+    return x, times
+
+
+def gv_cg(comm, A, b, max_iter, dot=np.dot):
+    """Ghysels-Vanroose pipelined CG, MP/cg_variants/gv_cg.py:7-88 (ONE reduction per iteration,
+    carrying t = A w together with nu and eta)."""
+    rank = comm.Get_rank()
+    times = {'tot': 0.} if rank == 0 else None                 # gv_cg.py:13-16
+    alpha = np.zeros(1)                                        # :19
+    nu = np.ones(1)                                            # :29 (the reduction buffer starts as ones)
+    x = np.zeros_like(b)                                       # :23
+    r = np.array(b, copy=True)                                 # :24
+    p = np.zeros_like(b)                                       # :25
+    s = np.zeros_like(b)                                       # :26
+    u = np.zeros_like(b)                                       # :28
+    w = np.array(A.matvec_local(r), copy=True)                 # :43-45  (w = A b, before the clock)
+    comm.Barrier()                                             # :48
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        for k in range(max_iter):                              # :52
+            nu_ = nu.copy()                                    # :54
+            part = (dot(r, r), dot(r, w))                      # :56-57
+            t = A.matvec_local(w)                              # :58-60 (same reduction as the scalars)
+            nu, eta = _scalar_allreduce(comm, *part)
+            beta = nu / nu_                                    # :62
+            p *= beta                                          # :64
+            p += r                                             # :65
+            s *= beta                                          # :66
+            s += w                                             # :67
+            u *= beta                                          # :68
+            u += t                                             # :69
+            mu = eta - (beta / alpha) * nu if k > 0 else eta   # :71
+            alpha = nu / mu                                    # :72
+            x += alpha * p                                     # :74
+            r -= alpha * s                                     # :75
+            w -= alpha * u                                     # :76
+    comm.Barrier()                                             # :78
+    if rank == 0:
+        times['tot'] = time.perf_counter() - t0
+    return x, times
+
+
+def pr_cg(comm, A, b, max_iter, dot=np.dot):
+    """Predict-and-recompute CG (not pipelined), MP/cg_variants/pr_cg.py:7-77."""
+    rank = comm.Get_rank()
+    times = {'tot': 0.} if rank == 0 else None                 # pr_cg.py:13-16
+    x = np.zeros_like(b)                                       # :23
+    r = np.array(b, copy=True)                                 # :24
+    p = np.array(b, copy=True)                                 # :25
+    comm.Barrier()                                             # :46
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        for _ in range(max_iter):                              # :50
+            s = A.matvec_local(p)                              # :52-53
+            mu, delta, gamma, nup = _scalar_allreduce(comm, dot(p, s), dot(r, s), dot(s, s), dot(r, r))   # :55-60
+            nu_ = nup.copy()                                   # :62
+            alpha = nu_ / mu                                   # :64
+            x += alpha * p                                     # :66
+            r -= alpha * s                                     # :67
+            nu = nu_ - 2 * alpha * delta + alpha**2 * gamma    # :69
+            beta = nu / nu_                                    # :70
+            p *= beta                                          # :72
+            p += r                                             # :73
+    comm.Barrier()                                             # :75
     if rank == 0:
         times['tot'] = time.perf_counter() - t0
     return x, times

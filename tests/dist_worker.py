@@ -98,7 +98,7 @@ def main(mode, workload, iters, outdir):
         def matvec_local(self, V):
             return A_full @ V
     results = {}
-    for name in ('pipe_pr_cg', 'hs_cg'):
+    for name in ('pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'):      # all five files of MP/cg_variants/
         x_ref, _ = getattr(mp_oracle, name)(mp_oracle.SingleRankComm(), Whole(), b_full.copy(), iters)
         if mode == 'cpu':
             A_local, ghost_ids = partition.localize(A_rows, lo, hi)

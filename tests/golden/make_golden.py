@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden.py          # everything
     python tests/golden/make_golden.py table    # only the published convergence table + its matrices
+    python tests/golden/make_golden.py mp       # only the mpi4py-variant fixtures
 
 What it does
   1. imports the reference (read-only mount at /root/reference) -- the serial
@@ -173,7 +174,9 @@ def mp_goldens():
     for n, iters in ((1024, 40), (1024, 400), (12288, 1500)):
         lam = mporc.model_problem_eigs(n)                    # MP/scaling_tests.py:31-36
         b = lam / np.sqrt(n)                                 # :57 (after the diagonal fill)
-        for vname in ('pipe_pr_cg', 'hs_cg'):
+        for vname in ('pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'):
+            if n == 12288 and vname not in ('pipe_pr_cg', 'hs_cg'):
+                continue        # the two variants of SURVEY row a8 get the full-size run; the others n=1024
             if n == 12288:
                 # the reference's dense n x n operator (1.2 GB) is affordable once
                 A = np.zeros((n, n)); A[np.arange(n), np.arange(n)] = lam
@@ -258,6 +261,9 @@ def main():
     print('numpy', np.__version__, 'scipy', scipy.__version__)
     if sys.argv[1:] == ['table']:
         paper_table()
+        return
+    if sys.argv[1:] == ['mp']:
+        mp_goldens()
         return
     mats = {m: load_matrix(m) for m in ('bcsstk03', 'nos7', 'nos4', '494_bus', 'bcsstk14', 'bcsstm22', 'model_48_8_3')}
     for m, A in mats.items():

@@ -58,7 +58,7 @@ def test_row_block_halo_plan_over_gloo(tmp_path, world, workload):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     for r in range(world):
         res = np.load(tmp_path / f'result_cpu_{r}.npy', allow_pickle=True).item()
-        assert res['pipe_pr_cg'] <= 1e-11 and res['hs_cg'] <= 1e-11, res
+        assert set(res) == {'pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'} and all(v <= 1e-11 for v in res.values()), res
 
 
 def test_halo_plan_is_consistent_between_ranks():
@@ -96,7 +96,7 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
     uid, path = rccl_ids(1)
     plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})     # same two-kernel schedule as with a communicator
     comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
-    for variant in (L.PIPE_PR, L.HS, L.PR):
+    for variant in (L.PIPE_PR, L.HS, L.PR, L.CG_CG, L.GV, L.PIPE_P):
         outs = []
         for op in (plain, comm):
             op.begin(variant, z['b'], np.zeros(n), 400, x_true=z['x_true'], hist_mask=15)
@@ -205,4 +205,4 @@ def test_two_ranks_through_rccl_when_the_box_allows_it(tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     for r in range(2):
         res = np.load(tmp_path / f'result_gpu_{r}.npy', allow_pickle=True).item()
-        assert res['pipe_pr_cg'] <= 1e-11 and res['hs_cg'] <= 1e-11, res
+        assert set(res) == {'pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'} and all(v <= 1e-11 for v in res.values()), res

@@ -19,6 +19,7 @@ import scipy.sparse as sp
 
 from conftest import all_runs, golden_state, load_run
 from device_order import device_dot
+from oracle import mp_oracle
 from oracle import ne_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -580,3 +581,25 @@ def test_ex2b_driver_matches_the_published_petsc_errors(amd, capfd):
         err = float(out.split()[3])
         assert abs(np.log10(err) - np.log10(err_pub)) < 1.0, (flags, err, err_pub)
         print(f'ex2b {flags}: {out}   (PETSc run published {err_pub:g})')
+
+
+@pytest.mark.parametrize('name', ['pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'])
+def test_scaling_mirror_against_mp_oracle(amd, name):
+    """`sol, t = variant(comm, A, b, max_iter)` (MP/scaling_tests.py:71) for all five files of
+    MP/cg_variants/, on one rank: the device result vs the MP oracle (pinned bitwise against the
+    reference) on the same sparse operator -- x after 25 iterations, to 1e-11 relative (the inner
+    products are summed in a different order; 25 iterations of this well-conditioned problem do
+    not amplify that), and the reference's timing dict."""
+    from new_cg_variants_amd import scaling
+    A = amd['problems'].laplace_2d(48, 40)
+    n = A.shape[0]
+    b = A @ (np.ones(n) / np.sqrt(n))
+
+    class Whole:
+        def matvec_local(self, V):
+            return A @ V
+    comm = mp_oracle.SingleRankComm()
+    x_ref, _ = getattr(mp_oracle, name)(comm, Whole(), b.copy(), 25)
+    x, t = getattr(scaling, name)(scaling.SelfComm(), A, b.copy(), 25)
+    assert set(t) >= {'tot'} and t['tot'] > 0
+    assert rel(x, x_ref) <= 1e-11, (name, rel(x, x_ref))

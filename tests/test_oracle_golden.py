@@ -136,7 +136,7 @@ def test_mp_oracle_against_reference_fixture():
     b = lam / np.sqrt(n)
     comm = mp_oracle.SingleRankComm()
     A = mp_oracle.DenseColumnBlock(comm, np.diag(lam))
-    for name in ('pipe_pr_cg', 'hs_cg'):
+    for name in ('pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'):
         x, t = getattr(mp_oracle, name)(comm, A, b.copy(), 40)
         assert set(t) == {'tot'} and t['tot'] >= 0
         assert rel(x, z[f'{name}_n1024_it40_x']) <= 1e-12
