@@ -5,8 +5,9 @@
 
 one process per GPU.  ``comm`` is a communicator-like object (``TorchComm`` wraps
 torch.distributed; anything with Get_rank/Get_size/Barrier/allgather_obj/bcast_obj
-works); ``A`` is the rank's CSR row block with GLOBAL column ids (shape n_local x n) --
-or a ``RowBlockOperator`` already resident on the GPU; ``b`` the rank's slice of the
+works); ``A`` is the rank's CSR row block with GLOBAL column ids (shape n_local x n), a
+``RowBlockOperator`` already resident on the GPU, or -- exactly what the reference's driver
+passes -- the rank's dense n x (n/size) column block of a symmetric operator; ``b`` the rank's slice of the
 right-hand side.  As in the reference x0 = 0, r0 = p0 = b, the loop body runs
 ``max_iter`` times, the return value is the local slice of x and ``{'tot': seconds}`` on
 rank 0 (``None`` elsewhere), and the clock starts/stops between barriers
@@ -121,7 +122,19 @@ class RowBlockOperator:
 
 
 def _as_operator(comm, A):
-    return A if isinstance(A, RowBlockOperator) else RowBlockOperator(comm, A)
+    if isinstance(A, RowBlockOperator):
+        return A
+    if isinstance(A, np.ndarray) and A.ndim == 2:
+        # The reference hands each rank the dense n x (n/size) COLUMN block of the operator
+        # (scaling_tests.py:51-54) and completes the product with an all-reduce of the n-vector.
+        # CG requires a symmetric operator, so column block j is the transpose of row block j:
+        # that row block, in CSR, is what the device wants (the model problem is diagonal).
+        import scipy.sparse as sp
+        m = A.shape[1]
+        if A.shape[0] != m * comm.Get_size():
+            raise ValueError(f'dense operator block of shape {A.shape}: expected (n, n/size) as in the reference')
+        A = sp.csr_matrix(np.ascontiguousarray(A.T))
+    return RowBlockOperator(comm, A)
 
 
 def _timed(comm, op, variant, b, max_iter):

@@ -607,3 +607,30 @@ def test_scaling_mirror_against_mp_oracle(amd, name):
     x, t = getattr(scaling, name)(scaling.SelfComm(), A, b.copy(), 25)
     assert set(t) >= {'tot'} and t['tot'] > 0
     assert rel(x, x_ref) <= 1e-11, (name, rel(x, x_ref))
+
+
+def test_scaling_mirror_takes_the_reference_drivers_dense_column_block(amd):
+    """MP/scaling_tests.py:31-57 builds the diagonal model problem as a dense n x (n/size) column
+    block and calls `variant(comm, A, b, max_iter)` with it.  The same call, same arguments, on one
+    rank: x after 40 iterations against the fixture written from the reference itself."""
+    import os
+    from conftest import GOLDEN
+    from new_cg_variants_amd import scaling
+    z = np.load(os.path.join(GOLDEN, 'mp_model_problem.npz'))
+    n = 1024
+    lam = mp_oracle.model_problem_eigs(n)
+    A = np.zeros((n, n))
+    A[np.arange(n), np.arange(n)] = lam                  # scaling_tests.py:51-54 with size = 1
+    b = lam / np.sqrt(n)                                 # :57
+    comm = mp_oracle.SingleRankComm()
+    op = mp_oracle.DenseColumnBlock(comm, A)
+    for name in ('pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'):
+        # 5 iterations: nothing has been amplified yet
+        x5, _ = getattr(scaling, name)(scaling.SelfComm(), A, b.copy(), 5)
+        want5, _ = getattr(mp_oracle, name)(comm, op, b.copy(), 5)
+        assert rel(x5, want5) <= 1e-11, (name, rel(x5, want5))
+        # 40 iterations against the reference's own output.  This model problem (kappa = 1e6) amplifies
+        # ANY change of summation order: permuting the order of the reference's ddot moves x by 2e-4
+        # (pipe_pr_cg) / 9e-5 (hs_cg) at iteration 40, one iteration more or less by 1e-2.
+        x, t = getattr(scaling, name)(scaling.SelfComm(), A, b.copy(), 40)
+        assert rel(x, z[f'{name}_n1024_it40_x']) <= 1e-3, (name, rel(x, z[f'{name}_n1024_it40_x']))
