@@ -634,3 +634,24 @@ def test_scaling_mirror_takes_the_reference_drivers_dense_column_block(amd):
         # (pipe_pr_cg) / 9e-5 (hs_cg) at iteration 40, one iteration more or less by 1e-2.
         x, t = getattr(scaling, name)(scaling.SelfComm(), A, b.copy(), 40)
         assert rel(x, z[f'{name}_n1024_it40_x']) <= 1e-3, (name, rel(x, z[f'{name}_n1024_it40_x']))
+
+
+def test_scaling_tests_driver_matches_the_published_errors(amd, tmp_path, monkeypatch, capfd):
+    """The reference's own run of `scaling_tests.py 12288 1500` (scaling_experiments_mpi4py/data/,
+    BASELINE.md / SURVEY.md section 6) ended with errors hs 1.10e-7, cg_cg 2.08e-6, gv 5.74e-5,
+    pr 2.26e-7, pipe_pr 4.01e-7.  The same command line through the device must land in the same
+    decade (the attained accuracy of each variant is the experiment's second result), print the same
+    lines and save the same dicts."""
+    from new_cg_variants_amd.experiments import scaling_tests
+    monkeypatch.chdir(tmp_path)
+    res = scaling_tests.main(['12288', '1500', 'unit'])
+    out = capfd.readouterr().out
+    published = {'hs_cg': 1.10e-7, 'cg_cg': 2.08e-6, 'gv_cg': 5.74e-5, 'pr_cg': 2.26e-7, 'pipe_pr_cg': 4.01e-7}
+    for name, err_pub in published.items():
+        assert f'{name} error: ' in out
+        saved = np.load(tmp_path / 'data' / '12288' / f'{name}_unit.npy', allow_pickle=True).item()
+        assert set(saved) == {'error', 'timings'} and saved['timings']['tot'] > 0
+        assert abs(np.log10(saved['error']) - np.log10(err_pub)) < 1.0, (name, saved['error'], err_pub)
+        print(f'scaling_tests {name}: error {saved["error"]:.3e} (published {err_pub:.2e}), '
+              f'{1500 / saved["timings"]["tot"]:.0f} it/s')
+    assert res.keys() == published.keys()
