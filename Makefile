@@ -7,11 +7,14 @@ OUT := new_cg_variants_amd/libprcg.so
 # -ffp-contract=off: the reference's arithmetic is "multiply, round, add, round"
 # (NumPy ufuncs, scipy csr_matvec); an FMA would change the bits.
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
-OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
+OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
 
 all: $(OUT)
 
-$(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h
+$(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_win.o: $(CSRC)/prcg_win.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h

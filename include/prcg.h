@@ -102,6 +102,11 @@ const char* prcg_last_error(const prcg_t* h);
 /* ABI version of this header */
 int  prcg_version(void);
 
+/* Experiment switches (the PRCG_* names of INTEGRATION.md, e.g. "PRCG_FUSED" = "0"): prcg_create
+ * takes their defaults from the environment, this call sets one for ONE handle -- before
+ * prcg_set_csr, which fixes the operator's encodings.  No counterpart in the reference. */
+int prcg_set_option(prcg_t* h, const char* key, const char* value);
+
 /* ---- multi-GPU: one RCCL communicator per handle --------------------------------
  * replaces comm = MPI.COMM_WORLD (scaling_tests.py:21) for the data path.
  * rccl_path: path of the librccl.so to dlopen (NULL -> "librccl.so.1").  Rank 0
@@ -137,6 +142,11 @@ int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank,
  * n_ghost > 0).  ms_avg (nullable) = mean device time per launch by HIP events.
  * Replaces `A @ v` -> scipy _sparsetools.csr_matvec (hs_cg.py:23,26,59). */
 int prcg_spmv(prcg_t* h, const double* x, double* y, int reps, double* ms_avg);
+/* y = A_local [x_own ; x_ghost]: the row block's product with the ghost entries supplied by the
+ * caller (n_rows + n_ghost host doubles) instead of by a halo exchange -- no communicator needed.
+ * Runs the interior launch and the boundary launch of the overlapped schedule.  What one rank of
+ * `A @ v` computes once its halo has arrived (scaling_experiments_mpi4py/cg_variants/hs_cg.py:49-51). */
+int prcg_spmv_ext(prcg_t* h, const double* x_ext, double* y);
 /* [w u] = A [r s], the fused two-vector product of the pipelined loop
  * (pipe_pr_cg.py:69-70; mpi4py pipe_pr_cg.py:65).  rs, wu: n_rows x 2 row-major. */
 int prcg_spmm2(prcg_t* h, const double* rs, double* wu, int reps, double* ms_avg);
@@ -171,6 +181,8 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_VALDICT 32   /* interior tiles stream 1-byte value-dictionary indices (lossless) */
 #define PRCG_SCHED_COL8 64      /* ... and 1-byte tile-relative column offsets */
 #define PRCG_SCHED_COL16 128    /* ... 2-byte */
+#define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
+                                   LDS-staged window of the input vector */
 int prcg_schedule(const prcg_t* h);
 /* teacher forcing: declare that the state now loaded (prcg_set_vector / prcg_set_scalars
  * for iteration k) IS iteration k; the next prcg_iterate(h,1) produces k+1 */

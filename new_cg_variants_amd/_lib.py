@@ -49,11 +49,13 @@ _SIGNATURES = {
     'prcg_create': (C.c_int, [C.POINTER(_P), C.c_int]),
     'prcg_destroy': (None, [_P]),
     'prcg_last_error': (C.c_char_p, [_P]),
+    'prcg_set_option': (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     'prcg_comm_unique_id': (C.c_int, [C.c_char_p, _P]),
     'prcg_comm_init': (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, _P, C.c_int]),
     'prcg_set_csr': (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     'prcg_set_halo': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     'prcg_spmv': (C.c_int, [_P, _P, _P, C.c_int, _dp]),
+    'prcg_spmv_ext': (C.c_int, [_P, _P, _P]),
     'prcg_spmm2': (C.c_int, [_P, _P, _P, C.c_int, _dp]),
     'prcg_solve_begin': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_uint32]),
     'prcg_iterate': (C.c_int, [_P, C.c_int]),

@@ -1,0 +1,204 @@
+// Device-side helpers shared by the kernel translation units of libprcg.so (gfx950 only).
+// Included by prcg_kernels.hip (CSR-adaptive tile kernels, vector updates) and prcg_win.hip
+// (row-per-lane window kernels).  Everything here is internal linkage on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "prcg_kernels.h"
+
+namespace prcg {
+namespace {
+
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kElemsPerTrip = kBlock * 2;   // update kernels: 2 elements per thread per trip
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a contiguous
+// range of work items so neighbouring tiles (which gather overlapping x entries) meet
+// in the same 4 MiB L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// LDS traffic of ONE wave is processed in issue order; only the compiler has to be
+// kept from moving the row reads above the product writes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NV> struct VecT;
+template <> struct VecT<1> { using type = double; };
+template <> struct VecT<2> { using type = double2; };
+
+__device__ __forceinline__ double vmul(double a, double g) { return a * g; }
+__device__ __forceinline__ double2 vmul(double a, double2 g) { return make_double2(a * g.x, a * g.y); }
+__device__ __forceinline__ void vacc(double& s, double p) { s += p; }
+__device__ __forceinline__ void vacc(double2& s, double2 p) { s.x += p.x; s.y += p.y; }
+__device__ __forceinline__ void vzero(double& s) { s = 0.0; }
+__device__ __forceinline__ void vzero(double2& s) { s.x = 0.0; s.y = 0.0; }
+__device__ __forceinline__ double vwave_sum(double v) { return wave_sum(v); }
+__device__ __forceinline__ double2 vwave_sum(double2 v) { return make_double2(wave_sum(v.x), wave_sum(v.y)); }
+
+// block-level combine of per-lane accumulators -> partials[block][slot0 + q]
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NQ], double* partials, int slot0) {
+    __shared__ double red[kWaves][NQ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + slot0 + threadIdx.x] = v;
+    }
+}
+
+// Same, plus: the block that finishes LAST sums all block partials in a fixed order and
+// writes the final values -- no separate reduction launch.  Which block is last varies
+// from run to run, the order of the summation does not, so the result is reproducible.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, counter form): every block
+// publishes its partials with plain stores -> s_waitcnt vmcnt(0) -> barrier -> one lane:
+// agent-scope release fence, wait, relaxed agent-scope ticket; the block that draws the
+// last ticket: agent-scope acquire fence, wait, barrier, plain loads.  Nobody spins.
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], double* partials, unsigned* ticket,
+                                                         double* __restrict__ final_out) {
+    __shared__ double red[kWaves][NQ];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (tk == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last block: thread t sums partials t, t+256, ...; butterfly; waves in order ----
+    double tot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+    const int nparts = gridDim.x;
+    for (int j = threadIdx.x; j < nparts; j += kBlock) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tot[q] += partials[(size_t)j * kPartialStride + q];
+    }
+    __syncthreads();   // red[] is reused
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(tot[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
+        final_out[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch (kernel boundary orders it)
+}
+
+struct Coefs { double al, bt, nup; };
+
+__device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {
+    // a_k1 = nu/mu; nu_k = nu - 2 a dl + a^2 gm (or Meurant's -nu + a^2 gm); b_k = nu_k/nu
+    // (numerical_experiments/cg_variants/pipe_pr_cg.py:64-66,75; Python evaluates
+    //  ((nu - (2a)dl) + (a^2)gm) left to right)
+    const double mu = dp[0], dl = dp[1], gm = dp[2], nu = dp[3];
+    Coefs c;
+    c.al = nu / mu;
+    const double a2 = c.al * c.al;
+    c.nup = meurant ? (-nu + a2 * gm) : ((nu - (2 * c.al) * dl) + a2 * gm);
+    c.bt = c.nup / nu;
+    return c;
+}
+
+// per-row epilogue: store y (and the fused extras)
+template <int NV, int EPI>
+__device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
+                                           int write_mask, const typename VecT<NV>::type* __restrict__ X,
+                                           const double* __restrict__ ep_r, const double* __restrict__ ep_d,
+                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
+{
+    if constexpr (NV == 1) {
+        double* Y = reinterpret_cast<double*>(yout_);
+        Y[row] = sum;
+        if constexpr (EPI == kEpiDotXY) acc[0] += X[row] * sum;
+        if constexpr (EPI == kEpiPR) {
+            const double stv = ep_d ? ep_d[row] * sum : sum;
+            if (ep_st) ep_st[row] = stv;
+            acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
+        }
+        if constexpr (EPI == kEpiCG) {
+            // Chronopoulos-Gear: w = A r~ with nu = r.r~, eta = w.r~ (cg_cg.py:61-63), r.r for the history
+            // (stored in the scalar-slot layout: eta -> 1, nu -> 3, r.r -> 4)
+            const double rv = ep_r[row], zv = X[row];
+            acc[3] += rv * zv; acc[1] += sum * zv; acc[4] += rv * rv;
+        }
+    } else if constexpr (EPI == kEpiPipeFused) {
+        // The NEXT iteration's vector update, row by row, while (w_i,u_i) = sum is still in
+        // registers (pipe_pr_cg.py:61-74): w and u never touch memory.  r,s are read from
+        // the OLD pair array X (other rows still gather from it) and written to the NEW one.
+        double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
+        double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
+        const double2 xp = XP[row];
+        const double2 rs = X[row];
+        const double xn = xp.x + cf.al * xp.y;               // x += a p
+        const double rn = rs.x - cf.al * rs.y;               // r -= a s
+        const double wn = sum.x - cf.al * sum.y;             // w -= a u      (w = A r, u = A s: just computed)
+        const double pn = rn + cf.bt * xp.y;                 // p = r + b p
+        const double sn = wn + cf.bt * rs.y;                 // s = w + b s
+        XP[row] = make_double2(xn, pn);
+        RSN[row] = make_double2(rn, sn);
+        acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+    } else {
+        if (write_mask == 3) {
+            reinterpret_cast<double2*>(yout_)[row] = sum;
+        } else {
+            double* Y = reinterpret_cast<double*>(yout_);
+            if (write_mask & 1) Y[2 * (size_t)row] = sum.x;
+            if (write_mask & 2) Y[2 * (size_t)row + 1] = sum.y;
+        }
+    }
+}
+
+
+}  // namespace
+}  // namespace prcg

@@ -36,26 +36,42 @@ namespace {
 std::string g_last_error;   // errors with no handle to hang them on
 
 constexpr int kNS = PRCG_NUM_SCALARS;
+static_assert(kPartialStride == PRCG_NUM_SCALARS, "the small-system kernel indexes the scalar history with kPartialStride");
 constexpr int kCoefStride = 4;
 constexpr int kMaxProfSamples = 512;
 
 struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;      // size asked for
+    size_t cap = 0;        // size of the allocation
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; cap = 0; } }
     hipError_t alloc(size_t nbytes, bool zero = true) {
         release();
         if (nbytes == 0) nbytes = 16;
         hipError_t e = hipMalloc(&p, nbytes);
         if (e != hipSuccess) { p = nullptr; return e; }
-        bytes = nbytes;
+        bytes = cap = nbytes;
         if (zero) {
             // the null stream does not order with our non-blocking streams: wait here
             e = hipMemset(p, 0, nbytes);
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         }
         return e;
+    }
+    // Session state: keep the allocation of the previous solve when it is large enough (a sweep of
+    // solves on one operator -- figure_gen.py:343-363 runs nine variants per matrix -- then allocates
+    // once) and clear it on the stream the session works on: no hipMalloc, no host synchronisation.
+    hipError_t ensure(size_t nbytes, hipStream_t st) {
+        if (nbytes == 0) nbytes = 16;
+        if (!p || cap < nbytes || cap > 2 * nbytes + (1u << 20)) {
+            release();
+            hipError_t e = hipMalloc(&p, nbytes);
+            if (e != hipSuccess) { p = nullptr; return e; }
+            cap = nbytes;
+        }
+        bytes = nbytes;
+        return hipMemsetAsync(p, 0, nbytes, st);
     }
     double* d() const { return static_cast<double*>(p); }
     int* i() const { return static_cast<int*>(p); }
@@ -93,6 +109,17 @@ struct prcg_handle {
     bool want_vdict = true;              // PRCG_VALDICT=0 turns it off
     int nt_int = 0, nt_bnd = 0;          // interior tiles first, then boundary tiles
     int steps = kDefaultTileSteps;       // tile size the table was planned for
+    TileKnobs kn;                        // PRCG_GRID_PER_CU, PRCG_TILE_ORDER
+    int steps_override = 0;              // PRCG_TILE_STEPS
+    // ---- window tiles (row-per-lane kernels, prcg_win.hip): all tiles of the operator or none ----
+    bool want_win = true;                // PRCG_WIN=0 turns them off
+    int win_per_cu = 0;                  // PRCG_WIN_GRID_PER_CU
+    int win_max_mean = 24;               // PRCG_WIN_MAX_MEAN: longest mean row the window form is tried for
+    bool win = false;
+    int win_geom = 0, win_rows = 0;
+    bool win_vd = false;
+    int nwt_int = 0, nwt_bnd = 0;
+    DevBuf wtiles, wcw, wvidx, wvdict;
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
                                          // measured slower than in-order (cross-stream event waits ~15 us/iter)
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
@@ -164,6 +191,14 @@ struct prcg_handle {
                       okv ? static_cast<const int2*>(vdesc.p) + first : nullptr};
     }
     const Tile* tile_ptr(int first = 0) const { return static_cast<const Tile*>(tiles.p) + first; }
+    WinDev wdev() const {
+        const bool b16 = win_geom >= 2;
+        return WinDev{indptr.i(), val.d(), b16 ? nullptr : static_cast<const unsigned char*>(wcw.p),
+                      b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
+                      win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
+                      win_vd ? static_cast<const double*>(wvdict.p) : nullptr};
+    }
+    const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
     bool multi() const { return comm != nullptr; }
 };
@@ -208,17 +243,48 @@ int fail(prcg_t* h, int code, const char* fmt, ...) {
 // with 256-slot tiles -- more rows per lane would otherwise serialise the reduce phase
 // (measured: S1 34.3 k vs 31.3 k it/s, S2 3236 vs 3013) -- longer rows with 512-slot tiles
 // (S3, 15 per row: 2115 vs 1885 it/s).  PRCG_TILE_STEPS = 1 | 2 | 4 overrides.
-int env_tile_steps(int64_t n = 0, int64_t nnz = 0) {
-    const char* e = getenv("PRCG_TILE_STEPS");
-    if (e) {
-        const int s = atoi(e);
-        if (s == 1 || s == 2 || s == 4) return s;
-    }
+int pick_tile_steps(int override_, int64_t n = 0, int64_t nnz = 0) {
+    if (override_ == 1 || override_ == 2 || override_ == 4) return override_;
     if (n > 0 && nnz < 10 * n) return 1;
     // medium rows (FEM-like, ~50+ nonzeros): the lane-per-row sums are a serial chain per row, so
     // bigger tiles (more rows summed side by side per wave) win (s4b: 2983 vs 2740 it/s)
     if (n > 0 && nnz >= 48 * n) return 4;
     return kDefaultTileSteps;
+}
+
+// The matrix products of the engine: window kernels when the operator qualified, else the
+// CSR-adaptive tile kernels.  which: 0 = every tile, 1 = interior tiles, 2 = tiles touching ghosts.
+int eng_spmv(prcg_t* h, hipStream_t st, int which, const double* x, double* y, SpmvEpilogue epi, const double* ep_r,
+             const double* ep_d, double* ep_st, double* partials) {
+    if (h->win) {
+        const int first = which == 2 ? h->nwt_int : 0;
+        const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
+        return launch_win_spmv(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, x, y, epi, ep_r, ep_d, ep_st, partials,
+                               h->win_per_cu);
+    }
+    const int first = which == 2 ? h->nt_int : 0;
+    const int nt = which == 0 ? h->nt_int + h->nt_bnd : (which == 1 ? h->nt_int : h->nt_bnd);
+    const CsrDev A = which == 0 ? h->csr() : (which == 1 ? h->csr(0, h->nt_bnd == 0) : h->csr(h->nt_int, false));
+    return launch_spmv(st, A, h->tile_ptr(first), nt, h->steps, x, y, epi, ep_r, ep_d, ep_st, partials, h->kn);
+}
+int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu, int mask) {
+    if (h->win) {
+        const int first = which == 2 ? h->nwt_int : 0;
+        const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
+        return launch_win_spmm2(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, rs, wu, mask, h->win_per_cu);
+    }
+    const int first = which == 2 ? h->nt_int : 0;
+    const int nt = which == 0 ? h->nt_int + h->nt_bnd : (which == 1 ? h->nt_int : h->nt_bnd);
+    const CsrDev A = which == 0 ? h->csr() : (which == 1 ? h->csr(0, h->nt_bnd == 0) : h->csr(h->nt_int, false));
+    return launch_spmm2(st, A, h->tile_ptr(first), nt, h->steps, rs, wu, mask, h->kn);
+}
+int eng_fused(prcg_t* h, hipStream_t st, const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
+              double* coef_out, double* partials, int meur, FusedPrev prev) {
+    if (h->win)
+        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(), h->nwt_int + h->nwt_bnd, h->win_geom, rs_old, rs_new,
+                                     xp, dots_prev, coef_out, partials, meur, prev, h->win_per_cu);
+    return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, rs_old, rs_new, xp, dots_prev,
+                             coef_out, partials, meur, prev, h->kn);
 }
 
 bool is_pipe(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_P || v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M; }
@@ -239,17 +305,19 @@ int exchange(prcg_t* h, double* vec_ext, int nc, hipStream_t st) {
     const int64_t nsend = h->send_ptr[h->n_peers];
     launch_pack(st, h->send_buf.d(), vec_ext, h->send_idx.i(), nsend, nc);
     NCCLCHK(h, h->rccl->GroupStart());
-    for (int q = 0; q < h->n_peers; ++q) {
+    ncclResult_t bad = ncclSuccess;
+    for (int q = 0; q < h->n_peers && bad == ncclSuccess; ++q) {
         const int64_t ns = h->send_ptr[q + 1] - h->send_ptr[q];
         const int64_t nr = h->recv_ptr[q + 1] - h->recv_ptr[q];
         if (ns > 0)
-            NCCLCHK(h, h->rccl->Send(h->send_buf.d() + h->send_ptr[q] * nc, (size_t)(ns * nc), ncclDouble,
-                                     h->peer_rank[q], cm, st));
-        if (nr > 0)
-            NCCLCHK(h, h->rccl->Recv(vec_ext + (h->n + h->recv_ptr[q]) * nc, (size_t)(nr * nc), ncclDouble,
-                                     h->peer_rank[q], cm, st));
+            bad = h->rccl->Send(h->send_buf.d() + h->send_ptr[q] * nc, (size_t)(ns * nc), ncclDouble, h->peer_rank[q], cm, st);
+        if (nr > 0 && bad == ncclSuccess)
+            bad = h->rccl->Recv(vec_ext + (h->n + h->recv_ptr[q]) * nc, (size_t)(nr * nc), ncclDouble, h->peer_rank[q], cm, st);
     }
-    NCCLCHK(h, h->rccl->GroupEnd());
+    // never leave the group open: a failed send/recv still gets its GroupEnd before the error is reported
+    const ncclResult_t fin = h->rccl->GroupEnd();
+    if (bad != ncclSuccess) return fail(h, PRCG_ERCCL, "ncclSend/ncclRecv failed: %s", h->rccl->GetErrorString(bad));
+    NCCLCHK(h, fin);
     return PRCG_OK;
 }
 
@@ -318,9 +386,7 @@ int dist_spmv(prcg_t* h, double* x_ext, double* y, SpmvEpilogue epi, const doubl
               const double* ep_d, double* ep_st, int* grid_out) {
     int rc = exchange(h, x_ext, 1, h->sc);
     if (rc) return rc;
-    const int nt = h->nt_int + h->nt_bnd;
-    const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
-                                 h->partB.d());
+    const int grid = eng_spmv(h, h->sc, 0, x_ext, y, epi, ep_r, ep_d, ep_st, h->partB.d());
     LAUNCHCHK(h, grid);
     if (grid_out) *grid_out = grid;
     return PRCG_OK;
@@ -395,7 +461,7 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
         // everything in order on one stream
         if (!h->fused_final) launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), 0, 0, 5);
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+        LAUNCHCHK(h, eng_spmm2(h, h->sc, 0, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         return PRCG_OK;
     }
@@ -413,11 +479,10 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
                              h->ghost_src.i(), (int)h->g);
         HIPCHK(h, hipEventRecord(h->e_red, h->sm));
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
+        LAUNCHCHK(h, eng_spmm2(h, h->sc, 1, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
-        if (h->nt_bnd > 0)
-            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+        if (h->nt_bnd > 0) LAUNCHCHK(h, eng_spmm2(h, h->sc, 2, in_ext, h->wu.d(), mask));
         return PRCG_OK;
     }
     const bool halo = h->multi() && h->have_halo && h->n_peers > 0;
@@ -439,11 +504,11 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
     HIPCHK(h, hipEventRecord(h->e_red, h->sm));
 
     if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, in_ext, h->wu.d(), mask));
+    LAUNCHCHK(h, eng_spmm2(h, h->sc, 1, in_ext, h->wu.d(), mask));
     if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     if (halo) {
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-        LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, in_ext, h->wu.d(), mask));
+        LAUNCHCHK(h, eng_spmm2(h, h->sc, 2, in_ext, h->wu.d(), mask));
     }
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
     return PRCG_OK;
@@ -456,8 +521,7 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
     bool on = false;
     if (!h->multi()) {
         prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-        const int grid = launch_spmv(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, x_ext, y, epi, ep_r,
-                                     ep_d, ep_st, h->partB.d());
+        const int grid = eng_spmv(h, h->sc, 0, x_ext, y, epi, ep_r, ep_d, ep_st, h->partB.d());
         LAUNCHCHK(h, grid);
         prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
         *nparts = grid;
@@ -470,13 +534,11 @@ int overlapped_spmv(prcg_t* h, int k, double* x_ext, double* y, SpmvEpilogue epi
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(h->e_halo, hs));
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int g1 = launch_spmv(h->sc, h->csr(0, h->nt_bnd == 0), h->tile_ptr(), h->nt_int, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
-                               h->partB.d());
+    const int g1 = eng_spmv(h, h->sc, 1, x_ext, y, epi, ep_r, ep_d, ep_st, h->partB.d());
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_halo, 0));
-    const int g2 = launch_spmv(h->sc, h->csr(h->nt_int, false), h->tile_ptr(h->nt_int), h->nt_bnd, h->steps, x_ext, y, epi, ep_r, ep_d, ep_st,
-                               h->partB.d() + (size_t)g1 * kPartialStride);
+    const int g2 = eng_spmv(h, h->sc, 2, x_ext, y, epi, ep_r, ep_d, ep_st, h->partB.d() + (size_t)g1 * kPartialStride);
     LAUNCHCHK(h, g2);
     *nparts = g1 + g2;
     return PRCG_OK;
@@ -525,8 +587,8 @@ int iterate_pipe_fused(prcg_t* h, int k) {
     double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int grid = launch_pipe_fused(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, rs_old, rs_new,
-                                       h->xp.d(), dots_at(h, k - 1), coef_at(h, k), part_out, meurant(h->variant), prev);
+    const int grid = eng_fused(h, h->sc, rs_old, rs_new, h->xp.d(), dots_at(h, k - 1), coef_at(h, k), part_out,
+                               meurant(h->variant), prev);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
@@ -673,6 +735,34 @@ int iterate_gv(prcg_t* h, int k) {
     return PRCG_OK;
 }
 
+// One place for every PRCG_* switch: prcg_create reads the environment through it, prcg_set_option
+// sets them per handle.  Returns false for an unknown key.
+bool apply_option(prcg_t* h, const char* key, const char* val) {
+    if (!key || !val) return false;
+    const std::string k(key);
+    const long v = atol(val);
+    if (k == "PRCG_SIDE_STREAM") h->side_stream = v != 0;
+    else if (k == "PRCG_FUSED_FINAL") h->fused_final = v != 0;
+    else if (k == "PRCG_FUSED") h->want_fused = v != 0;
+    else if (k == "PRCG_SMALL") h->want_small = v != 0;
+    else if (k == "PRCG_COL16") h->want_c16 = v != 0;
+    else if (k == "PRCG_COL8") h->want_c8 = v != 0;
+    else if (k == "PRCG_VALDICT") h->want_vdict = v != 0;
+    else if (k == "PRCG_GATHER") h->want_gather = v != 0;
+    else if (k == "PRCG_GATHER_MAX_BYTES") { if (v >= 64) h->gather_max_bytes = v; }
+    else if (k == "PRCG_GRID_PER_CU") h->kn.per_cu = (v >= 1 && v <= 16) ? (int)v : 0;
+    else if (k == "PRCG_TILE_ORDER") h->kn.chunked = (val[0] == 'c') ? 1 : 0;
+    else if (k == "PRCG_TILE_STEPS") h->steps_override = (v == 1 || v == 2 || v == 4) ? (int)v : 0;
+    else if (k == "PRCG_WIN") h->want_win = v != 0;
+    else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
+    else if (k == "PRCG_WIN_MAX_MEAN") { if (v >= 1) h->win_max_mean = (int)v; }
+    else return false;
+    return true;
+}
+const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
+                                   "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
+                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN"};
+
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
     HIPCHK(h, hipStreamSynchronize(h->sc));
@@ -757,15 +847,9 @@ int prcg_create(prcg_t** out, int device_id) {
     prcg_t* h = new (std::nothrow) prcg_handle();
     if (!h) return fail(nullptr, PRCG_ENOMEM, "out of host memory");
     h->dev = device_id;
-    if (const char* e = getenv("PRCG_SIDE_STREAM")) h->side_stream = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_FUSED_FINAL")) h->fused_final = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_FUSED")) h->want_fused = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_SMALL")) h->want_small = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_COL16")) h->want_c16 = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_COL8")) h->want_c8 = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_VALDICT")) h->want_vdict = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_GATHER")) h->want_gather = atoi(e) != 0;
-    if (const char* e = getenv("PRCG_GATHER_MAX_BYTES")) { const long v = atol(e); if (v >= 64) h->gather_max_bytes = v; }
+    // every switch lives in the handle from here on (no lazily read environment anywhere else)
+    for (const char* key : kOptionKeys)
+        if (const char* e = getenv(key)) (void)apply_option(h, key, e);
     // the communication stream outranks the compute stream: its small kernels (halo pack,
     // partial reduction, RCCL) must get CU slots while the matrix product floods the chip
     int prio_lo = 0, prio_hi = 0;
@@ -798,6 +882,14 @@ void prcg_destroy(prcg_t* h) {
     if (h->sm) (void)hipStreamDestroy(h->sm);
     if (h->sh) (void)hipStreamDestroy(h->sh);
     delete h;
+}
+
+int prcg_set_option(prcg_t* h, const char* key, const char* value) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, key && value, "prcg_set_option: null key or value");
+    CHECK(h, !h->have_csr, "prcg_set_option: options are fixed once the operator is set (call it before prcg_set_csr)");
+    CHECK(h, apply_option(h, key, value), "prcg_set_option: unknown option '%s'", key);
+    return PRCG_OK;
 }
 
 int prcg_comm_unique_id(const char* rccl_path, void* id128) {
@@ -870,18 +962,44 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     h->max_row_len = max_len;
     std::vector<Tile> t0, t1;
-    h->steps = env_tile_steps(n_rows, nnz);
+    h->steps = pick_tile_steps(h->steps_override, n_rows, nnz);
     plan_tiles(n_rows, ip.data(), n_ghost > 0 ? cls.data() : nullptr, tile_cap_nnz(h->steps), kTileCapRows, t0, t1);
     std::vector<Tile> all(t0);
     all.insert(all.end(), t1.begin(), t1.end());
+
+    // --- window tiles (row-per-lane kernels): tried first; when every tile of the operator qualifies the
+    // narrow encodings of the CSR-adaptive kernels below are not built at all ---
+    h->win = false; h->win_vd = false; h->nwt_int = h->nwt_bnd = 0;
+    WinPlan wp;
+    std::vector<WTile> wall;
+    std::vector<uint8_t> wvidx;
+    std::vector<double> wvdict;
+    if (h->want_win && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)h->win_max_mean * n_rows) {
+        const int rows = nnz < 10 * n_rows ? 128 : 64;
+        plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, rows, kWinCapNnz,
+                          win_max_pages(rows), wp);
+        const int most = wp.pages0 > wp.pages1 ? wp.pages0 : wp.pages1;
+        const int geom = win_geometry(rows, most);
+        if (wp.ok0 && wp.ok1 && geom >= 0 && wp.t0.size() + wp.t1.size() < (size_t)(1 << 26)) {
+            h->win = true; h->win_geom = geom; h->win_rows = rows;
+            wall = wp.t0;
+            wall.insert(wall.end(), wp.t1.begin(), wp.t1.end());
+            if (h->want_vdict) {
+                wvidx.assign((size_t)nnz + 32, 0);
+                h->win_vd = plan_window_dict(wall, data, kWinDictMax, wvidx, wvdict);
+                if (!h->win_vd) { for (auto& t : wall) t.vd_first = t.vd_count = 0; }
+            }
+        }
+    }
+    const bool classic_enc = !h->win;      // column / value re-encodings of the CSR-adaptive kernels
 
     // --- 16-bit tile-relative column encoding (host, once) ---
     std::vector<int32_t> tbase(all.size() + 1, 0);
     std::vector<uint16_t> c16;
     std::vector<uint8_t> c8;
-    bool fit_int = h->want_c16 && !all.empty(), fit_bnd = h->want_c16;
+    bool fit_int = classic_enc && h->want_c16 && !all.empty(), fit_bnd = classic_enc && h->want_c16;
     bool fit8_int = fit_int && h->want_c8, fit8_bnd = fit_bnd && h->want_c8;
-    if (h->want_c16) {
+    if (classic_enc && h->want_c16) {
         const int cap = tile_cap_nnz(h->steps);
         for (size_t ti = 0; ti < all.size(); ++ti) {
             const Tile& tl = all[ti];
@@ -926,7 +1044,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     std::vector<uint8_t> vidx;
     std::vector<double> vdict;
     std::vector<int32_t> vdesc;     // {first entry, count} per tile
-    bool vd_int = h->want_vdict && !t0.empty(), vd_bnd = h->want_vdict && !t1.empty();
+    bool vd_int = classic_enc && h->want_vdict && !t0.empty(), vd_bnd = classic_enc && h->want_vdict && !t1.empty();
     if (vd_int || vd_bnd) {
         const int cap = tile_cap_nnz(h->steps);
         vidx.assign((size_t)nnz + 8, 0);
@@ -971,7 +1089,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     h->vd_bnd = vd_bnd && !t1.empty();
 
     // --- upload (arrays padded so the 16-byte stream loads never leave the allocation) ---
-    const size_t pad = 8;
+    const size_t pad = 32;
     HIPCHK(h, h->indptr.alloc(((size_t)n_rows + 1 + pad) * sizeof(int32_t)));
     HIPCHK(h, h->col.alloc(((size_t)nnz + pad) * sizeof(int32_t)));
     HIPCHK(h, h->val.alloc(((size_t)nnz + pad) * sizeof(double)));
@@ -999,6 +1117,27 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         if (!vdict.empty())
             HIPCHK(h, hipMemcpy(h->vdict.p, vdict.data(), vdict.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->vdesc.p, vdesc.data(), vdesc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (h->win) {
+        h->nwt_int = (int)wp.t0.size(); h->nwt_bnd = (int)wp.t1.size();
+        HIPCHK(h, h->wtiles.alloc((wall.size() + 1) * sizeof(WTile)));
+        HIPCHK(h, hipMemcpy(h->wtiles.p, wall.data(), wall.size() * sizeof(WTile), hipMemcpyHostToDevice));
+        if (h->win_geom >= 2) {
+            HIPCHK(h, h->wcw.alloc(wp.cw.size() * sizeof(uint16_t)));
+            HIPCHK(h, hipMemcpy(h->wcw.p, wp.cw.data(), wp.cw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        } else {
+            std::vector<uint8_t> c8w(wp.cw.size());
+            for (size_t q = 0; q < wp.cw.size(); ++q) c8w[q] = (uint8_t)wp.cw[q];
+            HIPCHK(h, h->wcw.alloc(c8w.size()));
+            HIPCHK(h, hipMemcpy(h->wcw.p, c8w.data(), c8w.size(), hipMemcpyHostToDevice));
+        }
+        if (h->win_vd) {
+            HIPCHK(h, h->wvidx.alloc(wvidx.size()));
+            HIPCHK(h, hipMemcpy(h->wvidx.p, wvidx.data(), wvidx.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, h->wvdict.alloc((wvdict.size() + kWinDictMax) * sizeof(double)));
+            if (!wvdict.empty())
+                HIPCHK(h, hipMemcpy(h->wvdict.p, wvdict.data(), wvdict.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
     h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
@@ -1062,14 +1201,12 @@ static int timed_product(prcg_t* h, int nc, const double* in, double* out, int r
     HIPCHK(h, hipEventCreate(&a));
     HIPCHK(h, hipEventCreate(&b));
     double total = 0.0;
-    const int nt = h->nt_int + h->nt_bnd;
     for (int i = 0; i < reps; ++i) {
         HIPCHK(h, hipEventRecord(a, h->sc));
         if (nc == 1)
-            LAUNCHCHK(h, launch_spmv(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr,
-                                     nullptr, nullptr, nullptr));
+            LAUNCHCHK(h, eng_spmv(h, h->sc, 0, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr));
         else
-            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), nt, h->steps, h->tmp_ext.d(), h->t1.d(), 3));
+            LAUNCHCHK(h, eng_spmm2(h, h->sc, 0, h->tmp_ext.d(), h->t1.d(), 3));
         HIPCHK(h, hipEventRecord(b, h->sc));
         HIPCHK(h, hipEventSynchronize(b));
         float ms = 0.f;
@@ -1085,6 +1222,19 @@ static int timed_product(prcg_t* h, int nc, const double* in, double* out, int r
 int prcg_spmv(prcg_t* h, const double* x, double* y, int reps, double* ms_avg) {
     if (!h) return PRCG_EINVAL;
     return timed_product(h, 1, x, y, reps, ms_avg);
+}
+
+int prcg_spmv_ext(prcg_t* h, const double* x_ext, double* y) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->have_csr, "no matrix: call prcg_set_csr first");
+    CHECK(h, x_ext && y, "bad argument");
+    HIPCHK(h, hipSetDevice(h->dev));
+    int rc = h2d(h, h->tmp_ext.d(), x_ext, h->n + h->g);
+    if (rc) return rc;
+    // interior tiles, then the tiles that touch ghost columns: the two launches of the overlapped schedule
+    LAUNCHCHK(h, eng_spmv(h, h->sc, 1, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr));
+    LAUNCHCHK(h, eng_spmv(h, h->sc, 2, h->tmp_ext.d(), h->t1.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr));
+    return d2h(h, y, h->t1.d(), h->n);
 }
 
 int prcg_spmm2(prcg_t* h, const double* rs, double* wu, int reps, double* ms_avg) {
@@ -1121,13 +1271,13 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->k = 0;
     h->n_ev_spmv = h->n_ev_upd = 0;
 
-    HIPCHK(h, h->x.alloc((size_t)n * D));
-    HIPCHK(h, h->b.alloc((size_t)n * D));
-    HIPCHK(h, h->xt.alloc((size_t)n * D));
-    HIPCHK(h, h->e_ext.alloc((size_t)ne * D));
-    HIPCHK(h, h->dinv.alloc((size_t)n * D));
-    HIPCHK(h, h->dots.alloc((size_t)(max_iter + 1) * kNS * D));
-    HIPCHK(h, h->coef.alloc((size_t)(max_iter + 1) * kCoefStride * D));
+    HIPCHK(h, h->x.ensure((size_t)n * D, h->sc));
+    HIPCHK(h, h->b.ensure((size_t)n * D, h->sc));
+    HIPCHK(h, h->xt.ensure((size_t)n * D, h->sc));
+    HIPCHK(h, h->e_ext.ensure((size_t)ne * D, h->sc));
+    HIPCHK(h, h->dinv.ensure((size_t)n * D, h->sc));
+    HIPCHK(h, h->dots.ensure((size_t)(max_iter + 1) * kNS * D, h->sc));
+    HIPCHK(h, h->coef.ensure((size_t)(max_iter + 1) * kCoefStride * D, h->sc));
     int rc;
     if ((rc = h2d(h, h->x.d(), x0, n))) return rc;
     if ((rc = h2d(h, h->b.d(), b, n))) return rc;
@@ -1144,19 +1294,19 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     if (is_pipe(variant)) {
         h->fused = h->want_fused && !h->multi() && !h->prec && pipe_recompute(variant) && h->g == 0;
         if ((rc = plan_gather(h))) return rc;
-        HIPCHK(h, h->xp.alloc((size_t)2 * n * D));
-        HIPCHK(h, h->rs.alloc((size_t)2 * (h->prec ? n : ne) * D));
-        HIPCHK(h, h->rs2.alloc(h->fused ? (size_t)2 * ne * D : 16));
-        HIPCHK(h, h->partC.alloc(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16));
+        HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
+        HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
+        HIPCHK(h, h->rs2.ensure(h->fused ? (size_t)2 * ne * D : 16, h->sc));
+        HIPCHK(h, h->partC.ensure(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         h->rs_cur = h->rs.d();
         // one-workgroup solver: only when nothing but the recurrence residual is recorded
         h->small = h->fused && h->want_small &&
                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
                    small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
-        HIPCHK(h, h->rst.alloc(h->prec ? (size_t)2 * ne * D : 16));
-        HIPCHK(h, h->wu.alloc((size_t)2 * n * D));
-        HIPCHK(h, h->wt.alloc(h->prec ? (size_t)n * D : 16));
+        HIPCHK(h, h->rst.ensure(h->prec ? (size_t)2 * ne * D : 16, h->sc));
+        HIPCHK(h, h->wu.ensure((size_t)2 * n * D, h->sc));
+        HIPCHK(h, h->wt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
         double* RS = h->rs.d();
         double* WU = h->wu.d();
         double* XP = h->xp.d();
@@ -1192,15 +1342,15 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
     } else if (is_cg_family(variant)) {
         // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
-        HIPCHK(h, h->p.alloc((size_t)ne * D));
-        HIPCHK(h, h->r.alloc((size_t)ne * D));
-        HIPCHK(h, h->rt.alloc(h->prec ? (size_t)ne * D : 16));
-        HIPCHK(h, h->w.alloc((size_t)ne * D));
-        HIPCHK(h, h->wt.alloc(h->prec ? (size_t)ne * D : 16));
-        HIPCHK(h, h->s.alloc((size_t)n * D));
-        HIPCHK(h, h->st.alloc(h->prec ? (size_t)n * D : 16));
-        HIPCHK(h, h->u.alloc((size_t)n * D));
-        HIPCHK(h, h->tvec.alloc((size_t)n * D));
+        HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
+        HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
+        HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->w.ensure((size_t)ne * D, h->sc));
+        HIPCHK(h, h->wt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
+        HIPCHK(h, h->u.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->tvec.ensure((size_t)n * D, h->sc));
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x      cg_cg.py:23
         if (h->prec) launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r   :89
         double* z = h->prec ? h->rt.d() : h->r.d();
@@ -1233,11 +1383,11 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         }
     } else {
         // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)
-        HIPCHK(h, h->p.alloc((size_t)ne * D));
-        HIPCHK(h, h->r.alloc((size_t)n * D));
-        HIPCHK(h, h->s.alloc((size_t)n * D));
-        HIPCHK(h, h->rt.alloc(h->prec ? (size_t)n * D : 16));
-        HIPCHK(h, h->st.alloc(h->prec ? (size_t)n * D : 16));
+        HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
+        HIPCHK(h, h->r.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->rt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
+        HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
         if (h->prec) {
             launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r
@@ -1326,7 +1476,9 @@ int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
     return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
-           (h->vd_int ? PRCG_SCHED_VALDICT : 0) | (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0));
+           ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
+           (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW
+                   : (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0)));
 }
 
 int prcg_set_iteration(prcg_t* h, int k) {
@@ -1347,8 +1499,7 @@ int prcg_get_vector(prcg_t* h, int which, double* out) {
     if (!locate(h, which, &base, &stride)) {
         // fused schedule: w = A r and u = A s are never stored -- recompute on request
         if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U)) {
-            LAUNCHCHK(h, launch_spmm2(h->sc, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, h->rs_cur,
-                                      h->wu.d(), 3));
+            LAUNCHCHK(h, eng_spmm2(h, h->sc, 0, h->rs_cur, h->wu.d(), 3));
             launch_copy(h->sc, h->t1.d(), 1, h->wu.d() + (which == PRCG_VEC_U ? 1 : 0), 2, n);
             return d2h(h, out, h->t1.d(), n);
         }
@@ -1497,7 +1648,8 @@ int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int 
 }
 
 void prcg_tile_caps(int* cap_nnz, int* cap_rows) {
-    if (cap_nnz) *cap_nnz = tile_cap_nnz(env_tile_steps());
+    const char* e = getenv("PRCG_TILE_STEPS");
+    if (cap_nnz) *cap_nnz = tile_cap_nnz(pick_tile_steps(e ? atoi(e) : 0));
     if (cap_rows) *cap_rows = kTileCapRows;
 }
 

@@ -21,6 +21,9 @@ constexpr int kPartialStride = 8;                   // doubles per block in a pa
 struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 #endif
 
+// partial inner products of the previous one-launch iteration (see launch_pipe_fused)
+struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; };
+
 // epilogues fused into the single-vector SpMV
 enum SpmvEpilogue {
     kEpiNone = 0,
@@ -55,6 +58,9 @@ constexpr int kDictMax = 64;   // one dictionary entry per lane
 // added to a valid column of the tile never leaves the allocation
 constexpr int kGatherPad = 65536;
 
+// experiment knobs of the tile kernels, owned by the handle (read once in prcg_create / prcg_set_option)
+struct TileKnobs { int per_cu = 0; int chunked = 0; };
+
 // y = A x over tiles[0..ntiles).  x has ghost room; y has n_rows entries.
 // partials: [grid][kPartialStride] doubles (slots 0..2 used by the epilogues) or null.
 // returns the grid size used (needed to reduce the partials), <0 on launch failure.
@@ -63,11 +69,11 @@ constexpr int kGatherPad = 65536;
 int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
                 const double* ep_r, const double* ep_d, double* ep_st,
-                double* partials);
+                double* partials, TileKnobs kn = TileKnobs{});
 
 // [w u] = A [r s] on interleaved pairs.  write_mask: 1 = first, 2 = second, 3 = both.
 int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
-                 const double* rs, double* wu, int write_mask);
+                 const double* rs, double* wu, int write_mask, TileKnobs kn = TileKnobs{});
 
 // One launch per iteration of pipe_pr_cg / pipe_pr_m_cg on ONE GPU: [w u] = A [r s] with the
 // vector update of the following iteration applied to each row as soon as its (w_i,u_i)
@@ -77,10 +83,53 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 // partials (prev.prev_partials[nprev][kPartialStride]); every block sums them itself in the
 // fixed order and block 0 stores the result to prev.dots_prev_out -- no reduction launch
 // between iterations.  Otherwise the reduced values are read from dots_prev.
-struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; };
 int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                       const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant, FusedPrev prev);
+                      double* coef_out, double* partials, int meurant, FusedPrev prev, TileKnobs kn = TileKnobs{});
+
+// ---- window tiles: row-per-lane kernels for bands and stencils (prcg_win.hip) ---------------
+// Planned on the host by plan_window_tiles (prcg_plan.cpp).  The CSR arrays are the caller's;
+// device-internal, lossless re-encodings: cw8 / cw16[q] = index of col[q] in the tile's staged
+// window of the input vector (page * 64 + offset); vidx8 / vdict = per-tile value dictionary
+// (<= kWinDictMax distinct bit patterns per tile; entries ARE the caller's doubles).
+constexpr int kWinSlots = 1024;                 // nonzeros of one window tile that fit the wave's LDS slice
+constexpr int kWinCapNnz = kWinSlots - 15;      // the stream starts at a multiple of 16 nonzeros
+constexpr int kWinDictMax = 256;
+#ifndef PRCG_WTILE_DEFINED
+#define PRCG_WTILE_DEFINED
+constexpr int kWinMaxPages = 12;
+struct alignas(16) WTile {
+    int rb, re, lo, hi;
+    int geo, maxlen, vd_first, vd_count;
+    int page_col[kWinMaxPages];
+};
+#endif
+static_assert(sizeof(WTile) == 80, "the kernels read a window tile descriptor as five int4");
+struct WinDev {
+    const int* indptr;
+    const double* val;
+    const unsigned char* cw8;      // geometry 0, 1
+    const unsigned short* cw16;    // geometry 2, 3
+    const unsigned char* vidx8;    // null: plain values
+    const double* vdict;
+};
+// geometry id of a class planned with rows_per_tile (64 | 128) whose tiles need at most most_pages
+// pages: 0 = 64 rows / 2 pages / 8-bit indices, 1 = 64 / 4 / 8-bit, 2 = 128 / 8 / 16-bit, 3 = 128 / 12 / 16-bit
+inline int win_geometry(int rows_per_tile, int most_pages) {
+    if (rows_per_tile == 64) return most_pages <= 2 ? 0 : (most_pages <= 4 ? 1 : -1);
+    if (rows_per_tile == 128) return most_pages <= 8 ? 2 : (most_pages <= 12 ? 3 : -1);
+    return -1;
+}
+inline int win_max_pages(int rows_per_tile) { return rows_per_tile == 64 ? 4 : 12; }
+// same contracts as launch_spmv / launch_spmm2 / launch_pipe_fused below; per_cu > 0 overrides the
+// number of workgroups launched per CU (experiments)
+int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* x, double* y,
+                    SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu);
+int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,
+                     int write_mask, int per_cu);
+int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs_old,
+                          double* rs_new, double* xp, const double* dots_prev, double* coef_out, double* partials,
+                          int meurant, FusedPrev prev, int per_cu);
 
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {

@@ -16,134 +16,10 @@
 #include <cstdlib>
 
 #include "prcg_kernels.h"
+#include "prcg_device.hpp"
 
 namespace prcg {
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
-constexpr int kElemsPerTrip = kBlock * 2;   // update kernels: 2 elements per thread per trip
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a contiguous
-// range of work items so neighbouring tiles (which gather overlapping x entries) meet
-// in the same 4 MiB L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-    const int xcd = b & 7, idx = b >> 3;
-    const int q = nb >> 3, r = nb & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
-// LDS traffic of ONE wave is processed in issue order; only the compiler has to be
-// kept from moving the row reads above the product writes.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int NV> struct VecT;
-template <> struct VecT<1> { using type = double; };
-template <> struct VecT<2> { using type = double2; };
-
-__device__ __forceinline__ double vmul(double a, double g) { return a * g; }
-__device__ __forceinline__ double2 vmul(double a, double2 g) { return make_double2(a * g.x, a * g.y); }
-__device__ __forceinline__ void vacc(double& s, double p) { s += p; }
-__device__ __forceinline__ void vacc(double2& s, double2 p) { s.x += p.x; s.y += p.y; }
-__device__ __forceinline__ void vzero(double& s) { s = 0.0; }
-__device__ __forceinline__ void vzero(double2& s) { s.x = 0.0; s.y = 0.0; }
-__device__ __forceinline__ double vwave_sum(double v) { return wave_sum(v); }
-__device__ __forceinline__ double2 vwave_sum(double2 v) { return make_double2(wave_sum(v.x), wave_sum(v.y)); }
-
-// block-level combine of per-lane accumulators -> partials[block][slot0 + q]
-template <int NQ>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NQ], double* partials, int slot0) {
-    __shared__ double red[kWaves][NQ];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double v = wave_sum(acc[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NQ) {
-        double v = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kPartialStride + slot0 + threadIdx.x] = v;
-    }
-}
-
-// Same, plus: the block that finishes LAST sums all block partials in a fixed order and
-// writes the final values -- no separate reduction launch.  Which block is last varies
-// from run to run, the order of the summation does not, so the result is reproducible.
-// Hand-off protocol (cdna_hip_programming.md Guideline 16, counter form): every block
-// publishes its partials with plain stores -> s_waitcnt vmcnt(0) -> barrier -> one lane:
-// agent-scope release fence, wait, relaxed agent-scope ticket; the block that draws the
-// last ticket: agent-scope acquire fence, wait, barrier, plain loads.  Nobody spins.
-template <int NQ>
-__device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], double* partials, unsigned* ticket,
-                                                         double* __restrict__ final_out) {
-    __shared__ double red[kWaves][NQ];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double v = wave_sum(acc[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NQ) {
-        double v = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (tk == gridDim.x - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- last block: thread t sums partials t, t+256, ...; butterfly; waves in order ----
-    double tot[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
-    const int nparts = gridDim.x;
-    for (int j = threadIdx.x; j < nparts; j += kBlock) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) tot[q] += partials[(size_t)j * kPartialStride + q];
-    }
-    __syncthreads();   // red[] is reused
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double v = wave_sum(tot[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NQ) {
-        double v = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) v += red[w][threadIdx.x];
-        final_out[threadIdx.x] = v;
-    }
-    if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch (kernel boundary orders it)
-}
 
 // ======================================================================================
 // CSR-adaptive SpMV / two-vector SpMM.
@@ -156,70 +32,6 @@ __device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], doub
 //   reduce phase : lane i sums row i of the tile sequentially from LDS and stores it.
 // A row longer than a tile is summed by the whole wave (partial sums + butterfly).
 // ======================================================================================
-struct Coefs { double al, bt, nup; };
-
-__device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {
-    // a_k1 = nu/mu; nu_k = nu - 2 a dl + a^2 gm (or Meurant's -nu + a^2 gm); b_k = nu_k/nu
-    // (numerical_experiments/cg_variants/pipe_pr_cg.py:64-66,75; Python evaluates
-    //  ((nu - (2a)dl) + (a^2)gm) left to right)
-    const double mu = dp[0], dl = dp[1], gm = dp[2], nu = dp[3];
-    Coefs c;
-    c.al = nu / mu;
-    const double a2 = c.al * c.al;
-    c.nup = meurant ? (-nu + a2 * gm) : ((nu - (2 * c.al) * dl) + a2 * gm);
-    c.bt = c.nup / nu;
-    return c;
-}
-
-// per-row epilogue: store y (and the fused extras)
-template <int NV, int EPI>
-__device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
-                                           int write_mask, const typename VecT<NV>::type* __restrict__ X,
-                                           const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
-{
-    if constexpr (NV == 1) {
-        double* Y = reinterpret_cast<double*>(yout_);
-        Y[row] = sum;
-        if constexpr (EPI == kEpiDotXY) acc[0] += X[row] * sum;
-        if constexpr (EPI == kEpiPR) {
-            const double stv = ep_d ? ep_d[row] * sum : sum;
-            if (ep_st) ep_st[row] = stv;
-            acc[0] += X[row] * sum; acc[1] += ep_r[row] * stv; acc[2] += stv * sum;
-        }
-        if constexpr (EPI == kEpiCG) {
-            // Chronopoulos-Gear: w = A r~ with nu = r.r~, eta = w.r~ (cg_cg.py:61-63), r.r for the history
-            // (stored in the scalar-slot layout: eta -> 1, nu -> 3, r.r -> 4)
-            const double rv = ep_r[row], zv = X[row];
-            acc[3] += rv * zv; acc[1] += sum * zv; acc[4] += rv * rv;
-        }
-    } else if constexpr (EPI == kEpiPipeFused) {
-        // The NEXT iteration's vector update, row by row, while (w_i,u_i) = sum is still in
-        // registers (pipe_pr_cg.py:61-74): w and u never touch memory.  r,s are read from
-        // the OLD pair array X (other rows still gather from it) and written to the NEW one.
-        double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
-        double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
-        const double2 xp = XP[row];
-        const double2 rs = X[row];
-        const double xn = xp.x + cf.al * xp.y;               // x += a p
-        const double rn = rs.x - cf.al * rs.y;               // r -= a s
-        const double wn = sum.x - cf.al * sum.y;             // w -= a u      (w = A r, u = A s: just computed)
-        const double pn = rn + cf.bt * xp.y;                 // p = r + b p
-        const double sn = wn + cf.bt * rs.y;                 // s = w + b s
-        XP[row] = make_double2(xn, pn);
-        RSN[row] = make_double2(rn, sn);
-        acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
-    } else {
-        if (write_mask == 3) {
-            reinterpret_cast<double2*>(yout_)[row] = sum;
-        } else {
-            double* Y = reinterpret_cast<double*>(yout_);
-            if (write_mask & 1) Y[2 * (size_t)row] = sum.x;
-            if (write_mask & 2) Y[2 * (size_t)row + 1] = sum.y;
-        }
-    }
-}
-
 #ifndef PRCG_ROWSUM_UNROLL
 #define PRCG_ROWSUM_UNROLL 8
 #endif
@@ -794,6 +606,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+static_assert(kPartialStride == 8, "k_small_pipe_pr indexes the scalar history (PRCG_NUM_SCALARS doubles per iteration) with kPartialStride");
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallRows = 4;                    // rows per thread -> n <= 4096
 constexpr int kSmallMaxN = kSmallThreads * kSmallRows;
@@ -1073,8 +886,11 @@ int util_grid(int64_t n) {
 // CU is handed out per half (80 KiB each), so residency = 2 * floor(80 KiB / block LDS),
 // further capped by the API and by 8 blocks (32 waves) per CU.
 template <int TAG, typename K>
-int tile_grid(K kernel, int ntiles) {
-    static int cap = 0;   // per TAG (the kernels share one function-pointer type)
+int tile_grid(K kernel, int ntiles, int per_cu_override) {
+    static int caps[16] = {};   // per TAG (the kernels share one function-pointer type) and device
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    int& cap = caps[devid & 15];
     if (cap == 0) {
         int dev = 0, cus = 256, occ = 4;
         if (hipGetDevice(&dev) == hipSuccess) {
@@ -1099,12 +915,16 @@ int tile_grid(K kernel, int ntiles) {
             const int tuned = steps_ == 4 ? 2 : (((steps_ == 2 && narrow_ != 0) || narrow_ >= 4) ? 4 : 3);
             if (occ > tuned) occ = tuned;
         }
-        // experiment knob: PRCG_GRID_PER_CU overrides the residency estimate
-        if (const char* e = getenv("PRCG_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) occ = v; }
         cap = occ * cus;
     }
     int g = (ntiles + kWaves - 1) / kWaves;
-    if (g > cap) g = cap;
+    int lim = cap;
+    if (per_cu_override >= 1 && per_cu_override <= 16) {      // experiment knob PRCG_GRID_PER_CU (read into the handle)
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid);
+        lim = per_cu_override * cus;
+    }
+    if (g > lim) g = lim;
     if (g < 1) g = 1;
     return g;
 }
@@ -1117,7 +937,7 @@ int tile_grid(K kernel, int ntiles) {
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
-                 double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
+                 TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
     const int cw = A.tile_base == nullptr ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
     const bool vd = A.vidx8 != nullptr;   // value dictionary
@@ -1125,11 +945,10 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
                      : (cw == 16 ? (vd ? k_spmv_tiles<NV, EPI, STEPS, 16, true> : k_spmv_tiles<NV, EPI, STEPS, 16, false>)
                                  : (vd ? k_spmv_tiles<NV, EPI, STEPS, 0, true> : k_spmv_tiles<NV, EPI, STEPS, 0, false>));
     int grid;
-    if (cw == 8) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 5>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles);
-    else if (cw == 16) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 6>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles);
-    else grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 4>(k, ntiles) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles);
-    static int chunked = -1;   // experiment knob: PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
-    if (chunked < 0) { const char* e = getenv("PRCG_TILE_ORDER"); chunked = (e && e[0] == 'c') ? 1 : 0; }
+    if (cw == 8) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 5>(k, ntiles, kn.per_cu) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 1>(k, ntiles, kn.per_cu);
+    else if (cw == 16) grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 6>(k, ntiles, kn.per_cu) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 2>(k, ntiles, kn.per_cu);
+    else grid = vd ? tile_grid<NV * 1000 + EPI * 100 + STEPS * 10 + 4>(k, ntiles, kn.per_cu) : tile_grid<NV * 1000 + EPI * 100 + STEPS * 10>(k, ntiles, kn.per_cu);
+    const int chunked = kn.chunked;   // experiment knob PRCG_TILE_ORDER=chunk (measured slower: 4.2-4.7 vs 4.6-4.9 TB/s)
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, tiles, A.tile_base, A.vd, ntiles, x, y, write_mask, ep_r, ep_d, ep_st,
                        partials, chunked, aux, fz);
     return PRCG_LAUNCH_OK() ? grid : -1;
@@ -1138,46 +957,46 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 template <int NV, int EPI>
 int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
                        void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
-                       double* partials, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
+                       double* partials, TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
 {
     switch (steps) {
-    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
-    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
-    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, kn, aux, fz);
+    case 2: return launch_tiles<NV, EPI, 2>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, kn, aux, fz);
+    case 4: return launch_tiles<NV, EPI, 4>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, kn, aux, fz);
     default: return -1;
     }
 }
 
 int launch_spmv(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                 const double* x, double* y, SpmvEpilogue epi,
-                const double* ep_r, const double* ep_d, double* ep_st, double* partials)
+                const double* ep_r, const double* ep_d, double* ep_st, double* partials, TileKnobs kn)
 {
     if (ntiles <= 0) return 0;
     switch (epi) {
-    case kEpiNone: return launch_tiles_steps<1, kEpiNone>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-    case kEpiDotXY: return launch_tiles_steps<1, kEpiDotXY>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-    case kEpiPR: return launch_tiles_steps<1, kEpiPR>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
-    case kEpiCG: return launch_tiles_steps<1, kEpiCG>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials);
+    case kEpiNone: return launch_tiles_steps<1, kEpiNone>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, kn);
+    case kEpiDotXY: return launch_tiles_steps<1, kEpiDotXY>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, kn);
+    case kEpiPR: return launch_tiles_steps<1, kEpiPR>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, kn);
+    case kEpiCG: return launch_tiles_steps<1, kEpiCG>(steps, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, kn);
     default: break;
     }
     return -1;
 }
 
 int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
-                 const double* rs, double* wu, int write_mask)
+                 const double* rs, double* wu, int write_mask, TileKnobs kn)
 {
     if (ntiles <= 0) return 0;
     return launch_tiles_steps<2, kEpiNone>(steps, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr,
-                                           nullptr);
+                                           nullptr, kn);
 }
 
 int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
                       const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant, FusedPrev prev)
+                      double* coef_out, double* partials, int meurant, FusedPrev prev, TileKnobs kn)
 {
     if (ntiles <= 0) return 0;
     return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0),
-                                                dots_prev, nullptr, rs_new, partials, coef_out, prev);
+                                                dots_prev, nullptr, rs_new, partials, kn, coef_out, prev);
 }
 
 size_t small_lds_bytes(int n, int nnz, int mode) {

@@ -2,6 +2,10 @@
 // so the CPU test-suite can exercise it through the C-ABI (prcg_plan_tiles).
 #include "prcg_plan.h"
 
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
 namespace prcg {
 
 // Greedy packing of consecutive rows of one class into wave tiles.
@@ -41,6 +45,150 @@ void plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
             r = e;
         }
     }
+}
+
+namespace {
+
+// pages + column encoding of tiles [first, last) of `tiles`; returns the most pages a tile needed,
+// or -1 if one needed more than max_pages
+int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n_cols, const int32_t* indptr,
+                 const int32_t* indices, int max_pages, uint16_t* cw) {
+    std::vector<int32_t> cols;
+    int most = 0;
+    for (size_t ti = first; ti < last; ++ti) {
+        WTile& t = tiles[ti];
+        cols.assign(indices + t.lo, indices + t.hi);
+        std::sort(cols.begin(), cols.end());
+        cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+        // greedy cover of {needed columns} U [rb, re) by pages of 64 consecutive columns; a page
+        // opened inside the tile's own rows continues the previous one, so that the own rows are
+        // contiguous in the window (the fused epilogues read (r,s) of their row from it)
+        int np = 0;
+        int32_t page[kWinMaxPages];
+        size_t ci = 0;
+        int32_t own = t.rb;                   // next own row still to be covered
+        int maxlen = 0;
+        for (int r = t.rb; r < t.re; ++r) maxlen = std::max(maxlen, indptr[r + 1] - indptr[r]);
+        bool fail = false;
+        for (;;) {
+            // smallest uncovered column among the needed ones and the own rows
+            while (ci < cols.size() && np > 0 && cols[ci] < page[np - 1] + 64) ++ci;
+            if (np > 0 && own < page[np - 1] + 64) own = std::max(own, page[np - 1] + 64);
+            int32_t c;
+            const bool have_col = ci < cols.size(), have_own = own < t.re;
+            if (!have_col && !have_own) break;
+            if (have_col && have_own) c = std::min(cols[ci], own);
+            else c = have_col ? cols[ci] : own;
+            if (np == max_pages || np == kWinMaxPages) { fail = true; break; }
+            // keep the page inside the vector (its 64 entries are loaded unconditionally)
+            if ((int64_t)c + 64 > n_cols) c = (int32_t)std::max<int64_t>(n_cols - 64, 0);
+            if (np > 0 && c < page[np - 1] + 64) c = page[np - 1] + 64;   // pages never overlap
+            page[np++] = c;
+        }
+        if (fail) return -1;
+        {
+            const int p = (int)(std::upper_bound(page, page + np, (int32_t)t.rb) - page) - 1;
+            t.geo = np | ((p * 64 + (t.rb - page[p])) << 8);
+        }
+        t.maxlen = maxlen;
+        for (int p = 0; p < kWinMaxPages; ++p) t.page_col[p] = p < np ? page[p] : 0;
+        most = std::max(most, np);
+        for (int32_t q = t.lo; q < t.hi; ++q) {
+            const int32_t col = indices[q];
+            int p = (int)(std::upper_bound(page, page + np, col) - page) - 1;
+            cw[q] = (uint16_t)(p * 64 + (col - page[p]));
+        }
+    }
+    return most;
+}
+
+bool window_class(std::vector<WTile>& tiles, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+                  int max_pages, uint16_t* cw, int* most_pages) {
+    if (tiles.empty()) { *most_pages = 0; return true; }
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+    if (tiles.size() < 4096) nt = 1;
+    std::vector<int> res(nt, 0);
+    std::vector<std::thread> th;
+    const size_t per = (tiles.size() + nt - 1) / nt;
+    for (unsigned i = 0; i < nt; ++i) {
+        const size_t a = std::min(tiles.size(), i * per), b = std::min(tiles.size(), a + per);
+        if (nt == 1) res[0] = window_pages(tiles, a, b, n_cols, indptr, indices, max_pages, cw);
+        else th.emplace_back([&, a, b, i] { res[i] = window_pages(tiles, a, b, n_cols, indptr, indices, max_pages, cw); });
+    }
+    for (auto& t : th) t.join();
+    int most = 0;
+    for (int r : res) { if (r < 0) return false; most = std::max(most, r); }
+    *most_pages = most;
+    return true;
+}
+
+}  // namespace
+
+void plan_window_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+                       const uint8_t* row_class, int rows_per_tile, int cap_nnz, int max_pages, WinPlan& out) {
+    out.t0.clear(); out.t1.clear();
+    out.ok0 = out.ok1 = true;
+    out.pages0 = out.pages1 = 0;
+    out.cw.assign((size_t)indptr[n] + 32, 0);
+    int64_t r = 0;
+    while (r < n) {
+        const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
+        std::vector<WTile>& dst = cls ? out.t1 : out.t0;
+        int64_t run_end = n;
+        if (row_class) { run_end = r + 1; while (run_end < n && ((row_class[run_end] != 0) == cls)) ++run_end; }
+        while (r < run_end) {
+            int64_t e = r, nn = 0;
+            while (e < run_end && (e - r) < rows_per_tile) {
+                const int64_t len = (int64_t)indptr[e + 1] - indptr[e];
+                if (nn + len > cap_nnz) break;
+                nn += len;
+                ++e;
+            }
+            if (e == r) {                 // one row longer than a tile: not a window operator
+                (cls ? out.ok1 : out.ok0) = false;
+                e = r + 1;
+            }
+            WTile t{};
+            t.rb = (int)r; t.re = (int)e; t.lo = indptr[r]; t.hi = indptr[e];
+            dst.push_back(t);
+            r = e;
+        }
+    }
+    if (n_cols < 64) out.ok0 = out.ok1 = false;     // a page must fit inside the vector
+    if (out.ok0) out.ok0 = window_class(out.t0, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages0);
+    if (out.ok1) out.ok1 = window_class(out.t1, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages1);
+}
+
+bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_max,
+                      std::vector<uint8_t>& vidx, std::vector<double>& vdict) {
+    constexpr int kHash = 1024;           // open addressing, <= 256 live keys
+    uint64_t keys[kHash];
+    int16_t slot_of[kHash];
+    for (auto& t : tiles) {
+        if (vdict.size() & 1) vdict.push_back(0.0);            // 16-byte aligned table start
+        for (int i = 0; i < kHash; ++i) slot_of[i] = -1;
+        const size_t first = vdict.size();
+        int count = 0;
+        for (int32_t q = t.lo; q < t.hi; ++q) {
+            uint64_t bits;
+            memcpy(&bits, &data[q], sizeof bits);
+            uint32_t hsh = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);   // 10 bits
+            while (slot_of[hsh] >= 0 && keys[hsh] != bits) hsh = (hsh + 1) & (kHash - 1);
+            if (slot_of[hsh] < 0) {
+                if (count == dict_max) return false;
+                keys[hsh] = bits;
+                slot_of[hsh] = (int16_t)count++;
+                vdict.push_back(data[q]);
+            }
+            vidx[q] = (uint8_t)slot_of[hsh];
+        }
+        t.vd_first = (int)first;
+        t.vd_count = count;
+        if (vdict.size() >= (size_t)INT32_MAX - 1024) return false;
+    }
+    return true;
 }
 
 int plan_gather_sources(int rank, int T, const double* tab, int n_peers, const int32_t* peer_rank,

@@ -14,6 +14,39 @@ void plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
                 int cap_nnz, int cap_rows,
                 std::vector<Tile>& class0, std::vector<Tile>& class1);
 
+// ---- window tiles (row-per-lane kernels, prcg_win.hip) -----------------------------------
+// A window tile is a run of at most rows_per_tile consecutive rows of one class with at most
+// cap_nnz nonzeros whose columns (plus the tile's own rows) are covered by at most max_pages
+// PAGES of 64 consecutive columns.  The kernel stages the pages of the input vector in LDS once
+// per tile and each lane walks its own row; the column of a nonzero is streamed as its index into
+// that staged window (page * 64 + offset) -- 1 byte when max_pages <= 4, else 2.
+#ifndef PRCG_WTILE_DEFINED
+#define PRCG_WTILE_DEFINED
+constexpr int kWinMaxPages = 12;
+struct alignas(16) WTile {
+    int rb, re, lo, hi;                  // rows [rb,re), nonzeros [lo,hi)
+    int geo, maxlen, vd_first, vd_count;      // geo = pages in use | (window index of row rb) << 8; longest row;
+                                         // value dictionary {first entry, count}
+    int page_col[kWinMaxPages];          // first column of each page
+};
+#endif
+struct WinPlan {
+    std::vector<WTile> t0, t1;           // interior tiles, tiles touching ghost columns
+    std::vector<uint16_t> cw;            // per nonzero: index into its tile's staged window
+    bool ok0 = false, ok1 = false;       // every tile of the class qualified
+    int pages0 = 0, pages1 = 0;          // most pages any tile of the class needs
+};
+// n_cols: owned + ghost columns.  Tiles of a class that does not qualify are still listed (their
+// cw entries are unspecified); the caller then keeps the CSR-adaptive kernels for that class.
+void plan_window_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+                       const uint8_t* row_class, int rows_per_tile, int cap_nnz, int max_pages,
+                       WinPlan& out);
+// Per-tile value dictionaries (at most dict_max distinct bit patterns per tile, each tile's table
+// starting at an even entry): vidx[q] = index of data[q] in its tile's table.  Returns false (and
+// leaves the tiles' vd_* zero) if some tile needs more entries.
+bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_max,
+                      std::vector<uint8_t>& vidx, std::vector<double>& vdict);
+
 // Merged exchange (small halos ride on the one all-gather per iteration):
 // every rank contributes a slot of `slot` doubles = 8 (partial sums) + 2 x its packed send rows;
 // `tab` holds every rank's send table, `T` doubles per rank: [n_peers, (peer, first row of the

@@ -1,0 +1,414 @@
+// gfx950 (MI355X / CDNA4): row-per-lane "window" kernels for operators whose tiles touch few
+// column ranges (bands, stencils).  Same products and the same left-to-right row sums as the
+// CSR-adaptive tile kernels (prcg_kernels.hip) and as scipy's csr_matvec
+// (numerical_experiments/cg_variants/pipe_pr_cg.py:69-70 calls `A @ v`), different data path:
+//
+//   * the tile's val / col stream is read from HBM with 16-byte coalesced loads ONE TILE AHEAD
+//     into a register image, then parked raw in the wave's LDS slice (CSR order);
+//   * the entries of the input vector(s) the tile can touch -- at most PG pages of 64 consecutive
+//     columns, planned on the host (prcg_plan.cpp: plan_window_tiles) -- are read with coalesced
+//     loads one tile ahead as well and parked in LDS: NO per-nonzero gather from memory;
+//   * lane i then walks row i: column (1 or 2 bytes: its index into the staged window), value
+//     (or 1-byte dictionary index) and vector operand all come from LDS, products are added in
+//     row order without FMA; nothing is written back to LDS, no cross-lane step;
+//   * the row's epilogue (store, fused vector update, inner-product partials) follows in the
+//     same lane; for the one-launch pipelined iteration (x,p) of the row was requested a tile
+//     ahead and (r,s) of the row is read from the staged window.
+//
+// Every global load of the loop is issued a whole tile before its data is needed and there is
+// no dependent second round trip, which is what the latency-bound CSR-adaptive form suffered
+// from on narrow streams (profiles/r01_e_*: 70 % of wave cycles in s_waitcnt).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "prcg_device.hpp"
+#include "prcg_kernels.h"
+
+namespace prcg {
+namespace {
+
+#ifndef PRCG_WIN_UNROLL
+#define PRCG_WIN_UNROLL 8
+#endif
+constexpr int kU = PRCG_WIN_UNROLL;
+
+// wave-uniform view of one tile descriptor
+template <int PG>
+struct WDesc {
+    int rb, re, lo, hi, np, own, maxlen, vdf, vdc;
+    int pc[PG];
+};
+
+template <int PG>
+__device__ __forceinline__ WDesc<PG> read_desc(const int4* __restrict__ wt, int t) {
+    const int4 a = wt[t * 5 + 0], b = wt[t * 5 + 1];
+    WDesc<PG> d;
+    d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
+    d.lo = __builtin_amdgcn_readfirstlane(a.z); d.hi = __builtin_amdgcn_readfirstlane(a.w);
+    const int geo = __builtin_amdgcn_readfirstlane(b.x);
+    d.np = geo & 255; d.own = geo >> 8;
+    d.maxlen = __builtin_amdgcn_readfirstlane(b.y);
+    d.vdf = __builtin_amdgcn_readfirstlane(b.z); d.vdc = __builtin_amdgcn_readfirstlane(b.w);
+#pragma unroll
+    for (int q = 0; q < (PG + 3) / 4; ++q) {
+        const int4 p = wt[t * 5 + 2 + q];
+        if (4 * q + 0 < PG) d.pc[4 * q + 0] = __builtin_amdgcn_readfirstlane(p.x);
+        if (4 * q + 1 < PG) d.pc[4 * q + 1] = __builtin_amdgcn_readfirstlane(p.y);
+        if (4 * q + 2 < PG) d.pc[4 * q + 2] = __builtin_amdgcn_readfirstlane(p.z);
+        if (4 * q + 3 < PG) d.pc[4 * q + 3] = __builtin_amdgcn_readfirstlane(p.w);
+    }
+    return d;
+}
+
+// register image of one tile, as loaded
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+template <int NV> struct RegV;
+template <> struct RegV<1> { using type = double; };
+template <> struct RegV<2> { using type = d2_t; };
+template <int NV, int M, int PG, int CW, bool VD>
+struct WRegs {
+    d2_t v[VD ? 1 : kWinSlots / 128];   // plain values: nonzeros alo + st*128 + lane*2 .. +2
+    u4_t vi;                              // dictionary indices: nonzeros alo + lane*16 .. +16
+    u4_t c[CW / 8];                       // window indices: CW=8 like vi; CW=16: alo + k*512 + lane*8 .. +8
+    double dv[4];                          // dictionary entries lane, lane+64, ...
+    typename RegV<NV>::type w[PG];         // page p: column pc[p] + lane
+    int s[M], e[M];                        // row pointers of rows rb + j*64 + lane
+    d2_t xp[M];                         // fused iteration: (x,p) of those rows
+};
+
+template <int NV, int M, int PG, int CW, bool VD, bool FUSED>
+__device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
+                                            const typename VecT<NV>::type* __restrict__ X,
+                                            const double2* __restrict__ XP, WRegs<NV, M, PG, CW, VD>& R) {
+    const int alo = d.lo & ~15;
+    // branch-free: a lane whose chunk lies past the tile re-reads the tile's first chunk (hot line)
+    const int q16 = (alo + lane * 16) < d.hi ? (alo + lane * 16) : alo;
+    if constexpr (VD) {
+        R.vi = *reinterpret_cast<const u4_t*>(A.vidx8 + q16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (64 * k < d.vdc) {                               // wave-uniform
+                const int i = 64 * k + lane;
+                R.dv[k] = A.vdict[d.vdf + (i < d.vdc ? i : 0)];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < kWinSlots / 128; ++st) {
+            const int q = alo + st * 128 + lane * 2;
+            R.v[st] = *reinterpret_cast<const d2_t*>(A.val + (q < d.hi ? q : alo));
+        }
+    }
+    if constexpr (CW == 8) {
+        R.c[0] = *reinterpret_cast<const u4_t*>(A.cw8 + q16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = alo + k * 512 + lane * 8;
+            R.c[k] = *reinterpret_cast<const u4_t*>(A.cw16 + (q < d.hi ? q : alo));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PG; ++p)
+        if (p < d.np) R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];               // wave-uniform branch
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int row = d.rb + j * 64 + lane;
+        const int rr = row < d.re ? row : d.rb;
+        R.s[j] = A.indptr[rr];
+        R.e[j] = A.indptr[rr + 1];
+        if constexpr (FUSED) R.xp[j] = reinterpret_cast<const d2_t*>(XP)[rr];
+    }
+}
+
+template <int WPB, int NQ>
+__device__ __forceinline__ void win_block_reduce_store(double (&acc)[NQ], double* partials) {
+    __shared__ double red[WPB][NQ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    }
+}
+
+// One launch over window tiles.  Persistent grid, wave `slot` takes tiles slot, slot + W, ...
+// Template: NV vectors (1: SpMV, 2: the pipelined SpMM on (r,s) pairs), EPI row epilogue,
+// M rows per lane (tile = up to 64*M rows), PG pages, CW bits per window index, VD value
+// dictionary, WPB waves per workgroup (waves are independent: no workgroup barrier in the loop).
+template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_win_tiles(
+    WinDev A, const int4* __restrict__ wt, int ntiles,
+    const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
+    const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,
+    double* __restrict__ partials, double* __restrict__ aux, FusedPrev fz)
+{
+    using V = typename VecT<NV>::type;
+    constexpr bool FUSED = (EPI == kEpiPipeFused);
+    static_assert(!FUSED || NV == 2, "the fused iteration works on (r,s) pairs");
+    static_assert(PG * 64 <= (CW == 8 ? 256 : 65536), "window index does not fit");
+    __shared__ __attribute__((aligned(16))) double s_val[WPB][VD ? 2 : kWinSlots];
+    __shared__ __attribute__((aligned(16))) unsigned char s_vi[WPB][VD ? kWinSlots : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_col[WPB][kWinSlots * (CW / 8)];
+    __shared__ __attribute__((aligned(16))) double s_dict[WPB][VD ? kWinDictMax : 2];
+    __shared__ __attribute__((aligned(16))) V s_win[WPB][PG * 64];
+
+    const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
+    const double2* __restrict__ XPc = reinterpret_cast<const double2*>(yout_);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* sv = s_val[wv];
+    unsigned char* svi = s_vi[wv];
+    unsigned char* sc = s_col[wv];
+    const unsigned short* sc16 = reinterpret_cast<const unsigned short*>(s_col[wv]);
+    double* sd = s_dict[wv];
+    V* sw = s_win[wv];
+
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    Coefs cf = {0.0, 0.0, 0.0};
+    if constexpr (FUSED) {
+        // inner products of the previous iteration: still one row of partials per block of the
+        // previous launch -- every block of this launch sums them in the same fixed order
+        // (thread t: rows t, t+B, ...; butterfly; waves in order), see prcg_kernels.hip
+        if (fz.nprev > 0) {
+            __shared__ double redp[WPB][5];
+            __shared__ double dsum[5];
+            double tot[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = threadIdx.x; j < fz.nprev; j += 64 * WPB) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) tot[q] += fz.prev_partials[(size_t)j * kPartialStride + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double v = wave_sum(tot[q]);
+                if (lane == 0) redp[wv][q] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 5) {
+                double v = redp[0][threadIdx.x];
+#pragma unroll
+                for (int w = 1; w < WPB; ++w) v += redp[w][threadIdx.x];
+                dsum[threadIdx.x] = v;
+                if (blockIdx.x == 0) fz.dots_prev_out[threadIdx.x] = v;
+            }
+            __syncthreads();
+            cf = predict(dsum, (write_mask >> 2) & 1);
+        } else {
+            cf = predict(ep_r, (write_mask >> 2) & 1);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+    }
+
+    const int nblk = gridDim.x;
+    const int W = nblk * WPB;
+    int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
+
+    WRegs<NV, M, PG, CW, VD> R;
+    WDesc<PG> d = {}, dn = {};
+    if (t < ntiles) {
+        d = read_desc<PG>(wt, t);
+        issue_loads<NV, M, PG, CW, VD, FUSED>(A, d, lane, X, XPc, R);
+        if (t + W < ntiles) dn = read_desc<PG>(wt, t + W);
+    }
+
+    while (t < ntiles) {
+        const int alo = d.lo & ~15;
+        // ---- park the tile's image in LDS (this is where the wave waits for its loads) ----
+        if constexpr (VD) {
+            *reinterpret_cast<u4_t*>(svi + lane * 16) = R.vi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (64 * k < d.vdc) sd[64 * k + lane] = R.dv[k];
+        } else {
+#pragma unroll
+            for (int st = 0; st < kWinSlots / 128; ++st)
+                *reinterpret_cast<d2_t*>(sv + st * 128 + lane * 2) = R.v[st];
+        }
+        if constexpr (CW == 8) {
+            *reinterpret_cast<u4_t*>(sc + lane * 16) = R.c[0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(sc + (k * 512 + lane * 8) * 2) = R.c[k];
+        }
+#pragma unroll
+        for (int p = 0; p < PG; ++p)
+            if (p < d.np) reinterpret_cast<typename RegV<NV>::type*>(sw)[p * 64 + lane] = R.w[p];
+        int rs_[M], re_[M];
+        d2_t xp_[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) { rs_[j] = R.s[j]; re_[j] = R.e[j]; if constexpr (FUSED) xp_[j] = R.xp[j]; }
+        wave_lds_sync();
+
+        // ---- request the next tile (the image registers are free again) ----
+        const int tn = t + W;
+        const WDesc<PG> dcur = d;
+        if (tn < ntiles) {
+            d = dn;
+            issue_loads<NV, M, PG, CW, VD, FUSED>(A, d, lane, X, XPc, R);
+            if (tn + W < ntiles) dn = read_desc<PG>(wt, tn + W);
+        }
+
+        // ---- lane i walks row i (and i + 64, ...) ----
+        const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const int row = dcur.rb + j * 64 + lane;
+            const bool active = row < dcur.re;
+            if (j > 0 && dcur.rb + j * 64 >= dcur.re) break;              // wave-uniform
+            const int o = rs_[j] - alo;
+            const int len = active ? re_[j] - rs_[j] : 0;
+            V sum; vzero(sum);
+            for (int j0 = 0; j0 < dcur.maxlen; j0 += kU) {
+                int ci[kU];
+                double a[kU];
+                V g[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    int idx = o + j0 + u;
+                    idx = idx < last ? idx : last;
+                    if constexpr (CW == 8) ci[u] = sc[idx]; else ci[u] = sc16[idx];
+                    if constexpr (VD) a[u] = sd[svi[idx]]; else a[u] = sv[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) g[u] = sw[ci[u]];
+#pragma unroll
+                for (int u = 0; u < kU; ++u)
+                    if (j0 + u < len) vacc(sum, vmul(a[u], g[u]));
+            }
+            if constexpr (FUSED) {
+                // update k of the row while (w_i,u_i) = sum is in registers (pipe_pr_cg.py:61-74);
+                // (r,s)_i of the OLD pair array comes from the staged window, the new pair goes
+                // to the other array (ep_st)
+                const double2 rs = sw[active ? dcur.own + j * 64 + lane : 0];
+                if (active) {
+                    double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
+                    double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
+                    const double2 xp = make_double2(xp_[j].x, xp_[j].y);
+                    const double xn = xp.x + cf.al * xp.y;               // x += a p
+                    const double rn = rs.x - cf.al * rs.y;               // r -= a s
+                    const double wn = sum.x - cf.al * sum.y;             // w -= a u
+                    const double pn = rn + cf.bt * xp.y;                 // p = r + b p
+                    const double sn = wn + cf.bt * rs.y;                 // s = w + b s
+                    XP[row] = make_double2(xn, pn);
+                    RSN[row] = make_double2(rn, sn);
+                    acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+                }
+            } else {
+                if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+            }
+        }
+        wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
+        t = tn;
+    }
+
+    if constexpr (FUSED) { acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
+    else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
+    else if constexpr (EPI != kEpiNone) {
+        double a3[3] = {acc[0], acc[1], acc[2]};
+        win_block_reduce_store<WPB, 3>(a3, partials);
+    }
+}
+
+constexpr int kWPB = 2;   // waves per workgroup
+
+// co-resident blocks: LDS is handed out per 80 KiB half of a CU (see tile_grid in prcg_kernels.hip)
+template <typename K>
+int win_grid(K kernel, int ntiles, int per_cu_override) {
+    int dev = 0, cus = 256, occ = 4;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64 * kWPB, 0) != hipSuccess || occ < 1) occ = 4;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0) {
+            const int by_lds = 2 * (int)((80 * 1024) / fa.sharedSizeBytes);
+            if (by_lds >= 1 && by_lds < occ) occ = by_lds;
+        }
+        if (occ > 32 / kWPB) occ = 32 / kWPB;
+    }
+    if (per_cu_override >= 1 && per_cu_override <= 32) occ = per_cu_override;
+    int g = (ntiles + kWPB - 1) / kWPB;
+    if (g > occ * cus) g = occ * cus;
+    if (g < 1) g = 1;
+    return g;
+}
+
+template <int NV, int EPI, int M, int PG, int CW>
+int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
+                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
+                 int per_cu)
+{
+    const bool vd = A.vidx8 != nullptr;
+    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB>;
+    // (residency is a property of the kernel, not of the call: cached per instantiation and device)
+    static int cached_ntiles_cap[2][16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
+    if (cap == 0) cap = win_grid(k, 1 << 30, 0);
+    int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu) : cap;
+    const int need = (ntiles + kWPB - 1) / kWPB;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * kWPB), 0, st, A, reinterpret_cast<const int4*>(tiles), ntiles, x, y,
+                       write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    return hipGetLastError() == hipSuccess ? grid : -1;
+}
+
+template <int NV, int EPI>
+int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y,
+               int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux,
+               FusedPrev fz, int per_cu)
+{
+    switch (geom) {
+    case 0: return launch_win_g<NV, EPI, 1, 2, 8>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 1: return launch_win_g<NV, EPI, 1, 4, 8>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 2: return launch_win_g<NV, EPI, 2, 8, 16>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 3: return launch_win_g<NV, EPI, 2, 12, 16>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    default: return -1;
+    }
+}
+
+}  // namespace
+
+int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* x, double* y,
+                    SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    const FusedPrev none{nullptr, 0, nullptr};
+    switch (epi) {
+    case kEpiNone: return launch_win<1, kEpiNone>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiDotXY: return launch_win<1, kEpiDotXY>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiPR: return launch_win<1, kEpiPR>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiCG: return launch_win<1, kEpiCG>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    default: break;
+    }
+    return -1;
+}
+
+int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,
+                     int write_mask, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    return launch_win<2, kEpiNone>(geom, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   FusedPrev{nullptr, 0, nullptr}, per_cu);
+}
+
+int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs_old,
+                          double* rs_new, double* xp, const double* dots_prev, double* coef_out, double* partials,
+                          int meurant, FusedPrev prev, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    return launch_win<2, kEpiPipeFused>(geom, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0), dots_prev, nullptr,
+                                        rs_new, partials, coef_out, prev, per_cu);
+}
+
+}  // namespace prcg

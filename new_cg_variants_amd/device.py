@@ -38,26 +38,18 @@ class DeviceCSR:
     """
 
     def __init__(self, A, device=0, comm_init=None, halo=None, knobs=None):
-        """knobs: dict of PRCG_* experiment switches read by prcg_create (e.g.
-        {'PRCG_FUSED': '0'} keeps the two-kernel schedule on one GPU)."""
+        """knobs: dict of PRCG_* experiment switches for THIS handle (prcg_set_option), e.g.
+        {'PRCG_FUSED': '0'} keeps the two-kernel schedule on one GPU.  The process environment
+        is not touched."""
         self._h = C.c_void_p()
         self._lib = L.lib()
-        saved = {}
-        for k, v in (knobs or {}).items():
-            saved[k] = os.environ.get(k)
-            os.environ[k] = str(v)
-        try:
-            rc = self._lib.prcg_create(C.byref(self._h), int(device))
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        rc = self._lib.prcg_create(C.byref(self._h), int(device))
         if rc != L.OK:
             msg = self._lib.prcg_last_error(None)
             self._h = C.c_void_p()
             raise L.PrcgError(rc, msg.decode() if msg else '?')
+        for k, v in (knobs or {}).items():
+            self._check(self._lib.prcg_set_option(self._h, str(k).encode(), str(v).encode()))
         self.rank, self.nranks = 0, 1
         if comm_init is not None:
             rank, nranks, uid, path = comm_init      # uid: 128 or 256 bytes (one or two RCCL ids)
@@ -95,8 +87,6 @@ class DeviceCSR:
         n_ghost = n_cols - n_rows
         if n_ghost < 0:
             raise ValueError('row block must have at least n_rows columns (local numbering)')
-        if n_ghost > 0 and halo is None:
-            raise ValueError('ghost columns need a halo plan (and a communicator)')
         indptr = np.ascontiguousarray(A.indptr)
         is64 = indptr.dtype == np.int64
         if not is64:
@@ -123,6 +113,15 @@ class DeviceCSR:
         ms = C.c_double(0.0)
         self._check(self._lib.prcg_spmv(self._h, L.ptr(x), L.ptr(y), int(reps), C.byref(ms)))
         return y, ms.value
+
+    def matvec_ext(self, x_ext):
+        """y = A_local [x_own ; x_ghost] with the ghost entries supplied by the caller (no halo
+        exchange, no communicator): one rank's share of a row-block product."""
+        x_ext = L.f64(x_ext)
+        assert x_ext.shape == (self.n + self.n_ghost,)
+        y = np.empty(self.n)
+        self._check(self._lib.prcg_spmv_ext(self._h, L.ptr(x_ext), L.ptr(y)))
+        return y
 
     def matmat2(self, RS, reps=1):
         """[w u] = A [r s] for an (n,2) array; returns ((n,2) array, mean ms per launch)."""
@@ -158,7 +157,8 @@ class DeviceCSR:
         s = self._lib.prcg_schedule(self._h)
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
-                'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15}
+                'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
+                'window': bool(s & 4096)}
 
     def set_iteration(self, k):
         self._check(self._lib.prcg_set_iteration(self._h, int(k)))
