@@ -141,11 +141,123 @@ __device__ __forceinline__ void win_block_reduce_store(double (&acc)[NQ], double
     }
 }
 
+// per-wave constants of the tile loop
+template <int NV>
+struct WCtx {
+    double* sv; unsigned char* svi; unsigned char* sc; double* sd; typename VecT<NV>::type* sw;
+    const typename VecT<NV>::type* X;
+    void* yout; int write_mask;
+    const double* ep_r; const double* ep_d; double* ep_st;
+    int lane;
+};
+
+// One tile: park its image (R, requested DEPTH tiles ago) in LDS, request tile `dnext` into the
+// freed registers, then lane i walks row i (and i + 64, ...).
+template <int NV, int EPI, int M, int PG, int CW, bool VD>
+__device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<NV, M, PG, CW, VD>& R,
+                                         const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
+                                         double (&acc)[5], const Coefs& cf)
+{
+    using V = typename VecT<NV>::type;
+    using RV = typename RegV<NV>::type;
+    constexpr bool FUSED = (EPI == kEpiPipeFused);
+    const int lane = c.lane;
+    const unsigned short* sc16 = reinterpret_cast<const unsigned short*>(c.sc);
+    const int alo = dcur.lo & ~15;
+    // ---- park the tile's image in LDS (this is where the wave waits for ITS loads only: the
+    //      loads of the tiles requested after it stay in flight) ----
+    if constexpr (VD) {
+        *reinterpret_cast<u4_t*>(c.svi + lane * 16) = R.vi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (64 * k < dcur.vdc) c.sd[64 * k + lane] = R.dv[k];
+    } else {
+#pragma unroll
+        for (int st = 0; st < kWinSlots / 128; ++st)
+            *reinterpret_cast<d2_t*>(c.sv + st * 128 + lane * 2) = R.v[st];
+    }
+    if constexpr (CW == 8) {
+        *reinterpret_cast<u4_t*>(c.sc + lane * 16) = R.c[0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(c.sc + (k * 512 + lane * 8) * 2) = R.c[k];
+    }
+#pragma unroll
+    for (int p = 0; p < PG; ++p)
+        if (p < dcur.np) reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
+    int rs_[M], re_[M];
+    d2_t xp_[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { rs_[j] = R.s[j]; re_[j] = R.e[j]; if constexpr (FUSED) xp_[j] = R.xp[j]; }
+    wave_lds_sync();
+
+    // ---- request the tile DEPTH ahead (the image registers are free again) ----
+    if (have_next)
+        issue_loads<NV, M, PG, CW, VD, FUSED>(A, dnext, lane, c.X, reinterpret_cast<const double2*>(c.yout), R);
+
+    // ---- lane i walks row i (and i + 64, ...) ----
+    const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int row = dcur.rb + j * 64 + lane;
+        const bool active = row < dcur.re;
+        if (j > 0 && dcur.rb + j * 64 >= dcur.re) break;              // wave-uniform
+        const int o = rs_[j] - alo;
+        const int len = active ? re_[j] - rs_[j] : 0;
+        V sum; vzero(sum);
+        for (int j0 = 0; j0 < dcur.maxlen; j0 += kU) {
+            int ci[kU];
+            double a[kU];
+            V g[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                int idx = o + j0 + u;
+                idx = idx < last ? idx : last;
+                if constexpr (CW == 8) ci[u] = c.sc[idx]; else ci[u] = sc16[idx];
+                if constexpr (VD) a[u] = c.sd[c.svi[idx]]; else a[u] = c.sv[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) g[u] = c.sw[ci[u]];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (j0 + u < len) vacc(sum, vmul(a[u], g[u]));
+        }
+        if constexpr (FUSED) {
+            // update k of the row while (w_i,u_i) = sum is in registers (pipe_pr_cg.py:61-74);
+            // (r,s)_i of the OLD pair array comes from the staged window, the new pair goes
+            // to the other array (ep_st)
+            const double2 rs = c.sw[active ? dcur.own + j * 64 + lane : 0];
+            if (active) {
+                double2* __restrict__ XP = reinterpret_cast<double2*>(c.yout);
+                double2* __restrict__ RSN = reinterpret_cast<double2*>(c.ep_st);
+                const double2 xp = make_double2(xp_[j].x, xp_[j].y);
+                const double xn = xp.x + cf.al * xp.y;               // x += a p
+                const double rn = rs.x - cf.al * rs.y;               // r -= a s
+                const double wn = sum.x - cf.al * sum.y;             // w -= a u
+                const double pn = rn + cf.bt * xp.y;                 // p = r + b p
+                const double sn = wn + cf.bt * rs.y;                 // s = w + b s
+                XP[row] = make_double2(xn, pn);
+                RSN[row] = make_double2(rn, sn);
+                acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+            }
+        } else {
+            if (active) finish_row<NV, EPI>(row, sum, c.yout, c.write_mask, c.X, c.ep_r, c.ep_d, c.ep_st, acc, cf);
+        }
+    }
+    wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
+}
+
+#ifndef PRCG_WIN_DEPTH
+#define PRCG_WIN_DEPTH 2
+#endif
+
 // One launch over window tiles.  Persistent grid, wave `slot` takes tiles slot, slot + W, ...
 // Template: NV vectors (1: SpMV, 2: the pipelined SpMM on (r,s) pairs), EPI row epilogue,
 // M rows per lane (tile = up to 64*M rows), PG pages, CW bits per window index, VD value
-// dictionary, WPB waves per workgroup (waves are independent: no workgroup barrier in the loop).
-template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB>
+// dictionary, WPB waves per workgroup (waves are independent: no workgroup barrier in the loop),
+// DEPTH register images = tiles in flight per wave (few resident waves, each with a deep queue of
+// coalesced loads, stream better than many shallow ones: profiles/r02_sweeps.md).
+template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH>
 __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     WinDev A, const int4* __restrict__ wt, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -156,22 +268,17 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     constexpr bool FUSED = (EPI == kEpiPipeFused);
     static_assert(!FUSED || NV == 2, "the fused iteration works on (r,s) pairs");
     static_assert(PG * 64 <= (CW == 8 ? 256 : 65536), "window index does not fit");
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "one to three tiles in flight per wave");
     __shared__ __attribute__((aligned(16))) double s_val[WPB][VD ? 2 : kWinSlots];
     __shared__ __attribute__((aligned(16))) unsigned char s_vi[WPB][VD ? kWinSlots : 16];
     __shared__ __attribute__((aligned(16))) unsigned char s_col[WPB][kWinSlots * (CW / 8)];
     __shared__ __attribute__((aligned(16))) double s_dict[WPB][VD ? kWinDictMax : 2];
     __shared__ __attribute__((aligned(16))) V s_win[WPB][PG * 64];
 
-    const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
-    const double2* __restrict__ XPc = reinterpret_cast<const double2*>(yout_);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* sv = s_val[wv];
-    unsigned char* svi = s_vi[wv];
-    unsigned char* sc = s_col[wv];
-    const unsigned short* sc16 = reinterpret_cast<const unsigned short*>(s_col[wv]);
-    double* sd = s_dict[wv];
-    V* sw = s_win[wv];
+    const WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_),
+                     yout_, write_mask, ep_r, ep_d, ep_st, lane};
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
@@ -212,102 +319,33 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     const int W = nblk * WPB;
     int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
 
-    WRegs<NV, M, PG, CW, VD> R;
-    WDesc<PG> d = {}, dn = {};
-    if (t < ntiles) {
-        d = read_desc<PG>(wt, t);
-        issue_loads<NV, M, PG, CW, VD, FUSED>(A, d, lane, X, XPc, R);
-        if (t + W < ntiles) dn = read_desc<PG>(wt, t + W);
+    // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
+    WRegs<NV, M, PG, CW, VD> R[DEPTH];
+    WDesc<PG> d[DEPTH], dn = {};
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+        d[i] = WDesc<PG>{};
+        if (t + i * W < ntiles) {
+            d[i] = read_desc<PG>(wt, t + i * W);
+            issue_loads<NV, M, PG, CW, VD, FUSED>(A, d[i], lane, c.X, reinterpret_cast<const double2*>(yout_), R[i]);
+        }
     }
+    if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
 
     while (t < ntiles) {
-        const int alo = d.lo & ~15;
-        // ---- park the tile's image in LDS (this is where the wave waits for its loads) ----
-        if constexpr (VD) {
-            *reinterpret_cast<u4_t*>(svi + lane * 16) = R.vi;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (64 * k < d.vdc) sd[64 * k + lane] = R.dv[k];
-        } else {
-#pragma unroll
-            for (int st = 0; st < kWinSlots / 128; ++st)
-                *reinterpret_cast<d2_t*>(sv + st * 128 + lane * 2) = R.v[st];
-        }
-        if constexpr (CW == 8) {
-            *reinterpret_cast<u4_t*>(sc + lane * 16) = R.c[0];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(sc + (k * 512 + lane * 8) * 2) = R.c[k];
-        }
-#pragma unroll
-        for (int p = 0; p < PG; ++p)
-            if (p < d.np) reinterpret_cast<typename RegV<NV>::type*>(sw)[p * 64 + lane] = R.w[p];
-        int rs_[M], re_[M];
-        d2_t xp_[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) { rs_[j] = R.s[j]; re_[j] = R.e[j]; if constexpr (FUSED) xp_[j] = R.xp[j]; }
-        wave_lds_sync();
-
-        // ---- request the next tile (the image registers are free again) ----
-        const int tn = t + W;
-        const WDesc<PG> dcur = d;
-        if (tn < ntiles) {
-            d = dn;
-            issue_loads<NV, M, PG, CW, VD, FUSED>(A, d, lane, X, XPc, R);
-            if (tn + W < ntiles) dn = read_desc<PG>(wt, tn + W);
-        }
-
-        // ---- lane i walks row i (and i + 64, ...) ----
-        const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const int row = dcur.rb + j * 64 + lane;
-            const bool active = row < dcur.re;
-            if (j > 0 && dcur.rb + j * 64 >= dcur.re) break;              // wave-uniform
-            const int o = rs_[j] - alo;
-            const int len = active ? re_[j] - rs_[j] : 0;
-            V sum; vzero(sum);
-            for (int j0 = 0; j0 < dcur.maxlen; j0 += kU) {
-                int ci[kU];
-                double a[kU];
-                V g[kU];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    int idx = o + j0 + u;
-                    idx = idx < last ? idx : last;
-                    if constexpr (CW == 8) ci[u] = sc[idx]; else ci[u] = sc16[idx];
-                    if constexpr (VD) a[u] = sd[svi[idx]]; else a[u] = sv[idx];
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) g[u] = sw[ci[u]];
-#pragma unroll
-                for (int u = 0; u < kU; ++u)
-                    if (j0 + u < len) vacc(sum, vmul(a[u], g[u]));
-            }
-            if constexpr (FUSED) {
-                // update k of the row while (w_i,u_i) = sum is in registers (pipe_pr_cg.py:61-74);
-                // (r,s)_i of the OLD pair array comes from the staged window, the new pair goes
-                // to the other array (ep_st)
-                const double2 rs = sw[active ? dcur.own + j * 64 + lane : 0];
-                if (active) {
-                    double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
-                    double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
-                    const double2 xp = make_double2(xp_[j].x, xp_[j].y);
-                    const double xn = xp.x + cf.al * xp.y;               // x += a p
-                    const double rn = rs.x - cf.al * rs.y;               // r -= a s
-                    const double wn = sum.x - cf.al * sum.y;             // w -= a u
-                    const double pn = rn + cf.bt * xp.y;                 // p = r + b p
-                    const double sn = wn + cf.bt * rs.y;                 // s = w + b s
-                    XP[row] = make_double2(xn, pn);
-                    RSN[row] = make_double2(rn, sn);
-                    acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
-                }
-            } else {
-                if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+        for (int i = 0; i < DEPTH; ++i) {
+            if (t < ntiles) {
+                const WDesc<PG> dcur = d[i];
+                const int tnext = t + DEPTH * W;
+                const bool have_next = tnext < ntiles;
+                d[i] = dn;
+                win_step<NV, EPI, M, PG, CW, VD>(A, c, R[i], dcur, have_next, d[i], acc, cf);
+                // descriptor of the tile after that one: loaded now, looked at one step later
+                if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
+                t += W;
             }
         }
-        wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
-        t = tn;
     }
 
     if constexpr (FUSED) { acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
@@ -320,9 +358,15 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 
 constexpr int kWPB = 2;   // waves per workgroup
 
-// co-resident blocks: LDS is handed out per 80 KiB half of a CU (see tile_grid in prcg_kernels.hip)
+// Workgroups per CU.  Upper bounds: what is truly co-resident (LDS is handed out per 80 KiB half of a
+// CU; the occupancy API knows the register limit) -- a persistent strided grid with queued workgroups
+// grows a serial tail.  Below that bound FEWER waves stream better here: every wave keeps DEPTH whole
+// tiles of coalesced loads in flight, and the two-vector kernels are at the memory system's mixed
+// read/write rate from 8 waves per CU on (profiles/r02_sweeps.md: S3 4 workgroups of 2 waves per CU
+// 4.8 k it/s, 8 per CU 4.5 k, S2 5.2 k vs 3.8 k); the single-vector kernels with the dictionary stream
+// (50 bytes per row) keep gaining up to 16 waves.
 template <typename K>
-int win_grid(K kernel, int ntiles, int per_cu_override) {
+int win_grid(K kernel, int ntiles, int per_cu_override, int tuned) {
     int dev = 0, cus = 256, occ = 4;
     if (hipGetDevice(&dev) == hipSuccess) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -333,6 +377,7 @@ int win_grid(K kernel, int ntiles, int per_cu_override) {
             if (by_lds >= 1 && by_lds < occ) occ = by_lds;
         }
         if (occ > 32 / kWPB) occ = 32 / kWPB;
+        if (occ > tuned) occ = tuned;
     }
     if (per_cu_override >= 1 && per_cu_override <= 32) occ = per_cu_override;
     int g = (ntiles + kWPB - 1) / kWPB;
@@ -347,14 +392,15 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
                  int per_cu)
 {
     const bool vd = A.vidx8 != nullptr;
-    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB>;
+    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB, PRCG_WIN_DEPTH> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB, PRCG_WIN_DEPTH>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
-    if (cap == 0) cap = win_grid(k, 1 << 30, 0);
-    int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu) : cap;
+    const int tuned = (NV == 1 && vd) ? 8 : 4;
+    if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned);
+    int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned) : cap;
     const int need = (ntiles + kWPB - 1) / kWPB;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;

@@ -1,0 +1,313 @@
+"""GPU (MI355X): the BASELINE.json configurations at the sizes they are benchmarked at, and the
+row-per-lane window kernels (csrc/prcg_win.hip) against SciPy and against the CSR-adaptive kernels.
+
+Bars: every matrix product on rows that fit a tile is BIT-EXACT vs SciPy's csr_matvec (same
+left-to-right order, no FMA); rows summed by a whole wave (longer than a tile) within
+1e-14 * sum|a_ij x_j|; short pipelined runs vs the oracle with the reference's summation order
+(oracle/ne_oracle.py, BLAS ddot) to 1e-12 and vs the oracle run with the device's reduction tree
+(tests/device_order.py) as the two-kernel schedule produces it, bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN
+from device_order import device_dot
+from oracle import ne_oracle as orc
+
+FOUR_HISTS = 15
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import new_cg_variants_amd.cg_variants as cgv
+    import new_cg_variants_amd.callbacks as cbs
+    from new_cg_variants_amd import _lib, device, partition, problems
+    return dict(cgv=cgv, cbs=cbs, L=_lib, device=device, problems=problems, partition=partition)
+
+
+def products_bitexact(op, A, x, label):
+    ref = A @ x
+    y, _ = op.matvec(x)
+    assert np.array_equal(y, ref), f'{label}: SpMV differs from scipy in {np.count_nonzero(y != ref)} rows'
+    WU, _ = op.matmat2(np.stack([x, -0.5 * x], axis=1))
+    assert np.array_equal(WU[:, 0], ref) and np.array_equal(WU[:, 1], A @ (-0.5 * x)), label
+
+
+# ---------------------------------------------------------------------------------------
+# window kernels: which operators qualify, edge cases, agreement with the CSR-adaptive path
+# ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_window_kernels_selected_for_bands_and_stencils_only(amd):
+    P = amd['problems']
+    rng = np.random.default_rng(21)
+    n = 50_000
+    lens = rng.integers(1, 12, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    wide = sp.csr_matrix((rng.standard_normal(indptr[-1]), rng.integers(0, n, size=indptr[-1]).astype(np.int32), indptr),
+                         shape=(n, n))
+    expect = {'band': (P.banded_ex2b(100_000, 7), True, 1), 'lap2d': (P.laplace_2d(300, 200), True, 2),
+              'lap3d': (P.laplace_3d(40, 30, 20), True, 2), 'wide': (wide, False, 4),
+              'tiny': (P.laplace_2d(7, 8), False, 1), 'fem': (P.fem_like_3d(12, 3), False, 2)}
+    for name, (A, window, col_bytes) in expect.items():
+        op = amd['device'].DeviceCSR(A)
+        s = op.schedule()
+        assert s['window'] == window, (name, s)
+        if window:
+            assert s['col_bytes'] == col_bytes, (name, s)
+        x = rng.standard_normal(A.shape[0])
+        products_bitexact(op, A, x, name)
+        op.close()
+        off = amd['device'].DeviceCSR(A, knobs={'PRCG_WIN': '0'})
+        assert not off.schedule()['window']
+        products_bitexact(off, A, x, name + ' (PRCG_WIN=0)')
+        off.close()
+
+
+@pytest.mark.gpu
+def test_window_kernels_ragged_empty_unsorted_and_dictionary_edges(amd):
+    """Rows of 0..15 entries inside a band (row lengths differ inside a tile), runs of empty rows, unsorted
+    and duplicate column indices, signed zeros / inf / nan values, a tile with more than 256 distinct
+    values (the operator then streams plain doubles), and a row longer than a window tile (the operator
+    then falls back to the CSR-adaptive kernels)."""
+    rng = np.random.default_rng(22)
+    n = 30_000
+    lens = rng.integers(0, 16, size=n)
+    lens[500:900] = 0
+    lens[-70:] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(indptr[-1])
+    rows = np.repeat(np.arange(n), lens)
+    cols = (rows + rng.integers(-9, 10, size=nnz)).clip(0, n - 1).astype(np.int32)      # unsorted, duplicates
+    quant = rng.integers(-4, 5, size=nnz) / 16.0
+    quant[::11] = -0.0
+    A = sp.csr_matrix((quant, cols, indptr), shape=(n, n))
+    x = rng.standard_normal(n)
+    x[17] = 0.0
+    ref = A @ x
+    for knobs, want_dict in (({}, True), ({'PRCG_VALDICT': '0'}, False)):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        s = op.schedule()
+        assert s['window'] and s['value_dict'] == want_dict, s
+        products_bitexact(op, A, x, f'ragged {knobs}')
+        op.close()
+    # non-finite values: same bits as scipy wherever scipy's are defined (nan != nan: compare as bit patterns)
+    B = A.copy()
+    B.data[5] = np.inf
+    B.data[50] = np.nan
+    B.data[77] = -np.inf
+    op = amd['device'].DeviceCSR(B)
+    y, _ = op.matvec(x)
+    with np.errstate(all='ignore'):
+        refB = B @ x
+    assert np.array_equal(y, refB, equal_nan=True)
+    op.close()
+    # > 256 distinct values in one tile: dictionary refused, plain stream, same products
+    C = A.copy()
+    C.data[indptr[2000]:indptr[2000] + 700] = rng.standard_normal(700)
+    op = amd['device'].DeviceCSR(C)
+    s = op.schedule()
+    assert s['window'] and not s['value_dict'], s
+    products_bitexact(op, C, x, 'dictionary overflow')
+    op.close()
+    # one row longer than a window tile: not a window operator any more
+    lens2 = lens.copy()
+    lens2[1234] = 1500
+    indptr2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+    rows2 = np.repeat(np.arange(n), lens2)
+    cols2 = (rows2 + rng.integers(-9, 10, size=indptr2[-1])).clip(0, n - 1).astype(np.int32)
+    D = sp.csr_matrix((rng.standard_normal(indptr2[-1]), cols2, indptr2), shape=(n, n))
+    op = amd['device'].DeviceCSR(D)
+    assert not op.schedule()['window']
+    y, _ = op.matvec(x)
+    refD = D @ x
+    short = lens2 <= 500
+    assert np.array_equal(y[short], refD[short])
+    assert np.all(np.abs(y[~short] - refD[~short]) <= 1e-14 * (abs(D) @ np.abs(x))[~short])
+    op.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,parts', [('s3_small', 3), ('s1_small', 2)])
+def test_row_blocks_with_ghost_columns_reassemble_the_global_product(amd, workload, parts):
+    """Row-block partition + localisation (ghost columns behind the owned ones) on the device without a
+    communicator: prcg_spmv_ext takes the ghost entries from the caller.  Interior and boundary tiles of
+    the window kernels (and of the CSR-adaptive kernels) must give the global product bit for bit."""
+    P, part = amd['problems'], amd['partition']
+    A = P.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    x = np.random.default_rng(23).standard_normal(n)
+    ref = A @ x
+    offsets = part.even_offsets(n, parts)
+    for knobs in ({}, {'PRCG_WIN': '0'}):
+        got = np.empty(n)
+        for r in range(parts):
+            lo, hi = int(offsets[r]), int(offsets[r + 1])
+            A_local, ghost_ids = part.localize(A[lo:hi], lo, hi)
+            op = amd['device'].DeviceCSR(A_local, knobs=knobs)
+            assert op.schedule()['window'] == (not knobs)
+            got[lo:hi] = op.matvec_ext(np.concatenate([x[lo:hi], x[ghost_ids]]))
+            op.close()
+        assert np.array_equal(got, ref), (workload, knobs)
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs at bench size
+# ---------------------------------------------------------------------------------------
+def short_pipelined_run_matches_the_oracles(amd, A, iters=12):
+    n = A.shape[0]
+    b, x0, x_true = amd['problems'].reference_rhs(A, n)
+    cbs = amd['cbs']
+    # one-launch schedule (what bench.py times) vs the reference-order oracle
+    ref = orc.pipe_pr_cg(A, b, x0, iters, callbacks=['updated_residual_2_norm', 'error_2_norm'], x_true=x_true)
+    got = amd['cgv'].pipe_pr_cg(A, b, x0, iters, callbacks=[cbs.updated_residual_2_norm, cbs.error_2_norm], x_true=x_true)
+    np.testing.assert_allclose(got['updated_residual_2_norm'], ref['updated_residual_2_norm'], rtol=1e-12)
+    np.testing.assert_allclose(got['error_2_norm'], ref['error_2_norm'], rtol=1e-12)
+    # two-kernel schedule vs the oracle with the device's own reduction tree: every inner product bit for bit
+    L = amd['L']
+    want = []
+    orc.pipe_pr_cg(A, b, x0, iters, dot=device_dot, square=lambda a: a * a,
+                   tap=lambda st: want.append((st.mu, st.dl, st.gm, st.nu)))
+    op = amd['device'].DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
+    op.begin(L.PIPE_PR, b, x0, iters)
+    op.iterate(iters - 1)
+    op.sync()
+    have = np.array([op.get_scalars(k)[[L.S_MU, L.S_DELTA, L.S_GAMMA, L.S_NU]] for k in range(iters)])
+    op.close()
+    assert np.array_equal(have, np.array(want)), 'two-kernel schedule vs device-ordered oracle'
+    return got
+
+
+@pytest.mark.gpu
+def test_s3_full_size_as_benchmarked(amd):
+    """S3 = ex2b banded, n = 1e7, 149,999,944 nonzeros: exactly the operator bench.py times, with the
+    encodings it runs (window kernels, 1-byte window indices, value dictionary on and off)."""
+    P = amd['problems']
+    A = P.WORKLOADS['s3']['make']()
+    n = A.shape[0]
+    assert (n, A.nnz) == (10_000_000, 149_999_944)
+    x = np.random.default_rng(31).standard_normal(n)
+    ones = np.ones(n)
+    for knobs in ({}, {'PRCG_VALDICT': '0'}):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        s = op.schedule()
+        assert s['window'] and s['col_bytes'] == 1 and s['value_dict'] == (not knobs), s
+        y1, _ = op.matvec(ones)
+        assert np.array_equal(y1, A @ ones)                      # A*1 = row sums (sequential, as scipy)
+        products_bitexact(op, A, x, f's3 {knobs}')
+        op.close()
+    short_pipelined_run_matches_the_oracles(amd, A)
+
+
+@pytest.mark.gpu
+def test_s2_full_size(amd):
+    """S2 = 7-point Laplacian 216^3 (BASELINE.json configs[3]): far neighbours at +-46656, 12-page windows,
+    2-byte window indices."""
+    P = amd['problems']
+    A = P.WORKLOADS['s2']['make']()
+    n = A.shape[0]
+    assert (n, A.nnz) == (216 ** 3, 70_263_936)
+    x = np.random.default_rng(32).standard_normal(n)
+    ones = np.ones(n)
+    for knobs in ({}, {'PRCG_VALDICT': '0'}, {'PRCG_WIN': '0'}):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        s = op.schedule()
+        assert s['window'] == ('PRCG_WIN' not in knobs), s
+        y1, _ = op.matvec(ones)
+        assert np.array_equal(y1, A @ ones)
+        products_bitexact(op, A, x, f's2 {knobs}')
+        op.close()
+    short_pipelined_run_matches_the_oracles(amd, A)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['s4', 's4b'])
+def test_irregular_standins_at_bench_size(amd, workload):
+    """BASELINE.json configs[4] (Queen_4147, irregular degrees) cannot be fetched: its two labelled stand-ins
+    at the size bench.py --workload s4 / s4b runs them.  SpMV bit-exact on rows that fit a tile, rows summed
+    by a whole wave within 1e-14 * sum|a x|; the nnz-balanced 8-way row-block split (what 8 ranks would own)
+    reassembles the global product on the device."""
+    P, part = amd['problems'], amd['partition']
+    A = P.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    x = np.random.default_rng(33).standard_normal(n)
+    ref = A @ x
+    lens = np.diff(A.indptr)
+    op = amd['device'].DeviceCSR(A)
+    cap = 256 * op.schedule()['tile_steps'] - 3
+    y, _ = op.matvec(x)
+    fits = lens <= cap
+    assert fits.sum() >= n - 1000
+    assert np.array_equal(y[fits], ref[fits])
+    if (~fits).any():
+        scale = (abs(A[np.nonzero(~fits)[0]]) @ np.abs(x))
+        assert np.all(np.abs(y[~fits] - ref[~fits]) <= 1e-14 * scale)
+    WU, _ = op.matmat2(np.stack([x, 2.0 * x], axis=1))
+    assert np.array_equal(WU[fits, 0], ref[fits]) and np.array_equal(WU[fits, 1], (A @ (2.0 * x))[fits])
+    op.close()
+    offsets = part.nnz_balanced_offsets(A.indptr, 8)
+    nnz_of = [int(A.indptr[offsets[r + 1]] - A.indptr[offsets[r]]) for r in range(8)]
+    assert max(nnz_of) <= 1.15 * np.mean(nnz_of)
+    got = np.empty(n)
+    for r in range(8):
+        lo, hi = int(offsets[r]), int(offsets[r + 1])
+        A_local, ghost_ids = part.localize(A[lo:hi], lo, hi)
+        dev = amd['device'].DeviceCSR(A_local)
+        got[lo:hi] = dev.matvec_ext(np.concatenate([x[lo:hi], x[ghost_ids]]))
+        dev.close()
+    assert np.array_equal(got[fits], ref[fits])
+    assert np.all(np.abs(got - ref) <= 1e-14 * (abs(A) @ np.abs(x)))
+    # a short solve: HS-CG and the pipelined variant against the oracle (diagonally dominant: well conditioned)
+    b, x0, x_true = P.reference_rhs(A, n)
+    for name in ('hs_cg', 'pipe_pr_cg'):
+        want = getattr(orc, name)(A, b, x0, 8, callbacks=['updated_residual_2_norm'], x_true=x_true)
+        got_h = getattr(amd['cgv'], name)(A, b, x0, 8, callbacks=[amd['cbs'].updated_residual_2_norm], x_true=x_true)
+        # (strongly diagonally dominant: the residual falls seven decades per step by cancellation, so the
+        #  bar is absolute -- 1e-11 of the initial residual -- like the b - A x histories of test_gpu_parity)
+        np.testing.assert_allclose(got_h['updated_residual_2_norm'], want['updated_residual_2_norm'], rtol=1e-9,
+                                   atol=1e-11 * want['updated_residual_2_norm'][0])
+
+
+# ---------------------------------------------------------------------------------------
+# the Queen_4147 loader (MatrixMarket, symmetric, lower triangle stored -- the layout of the
+# reference's matrices/*.mtx, read as numerical_experiments/figure_gen.py:350 does)
+# ---------------------------------------------------------------------------------------
+def test_queen_loader_reads_a_symmetric_matrixmarket_file(monkeypatch):
+    import scipy.io
+    from new_cg_variants_amd import problems
+    path = os.path.join(GOLDEN, 'tiny_symmetric.mtx')
+    monkeypatch.setenv('QUEEN_4147_MTX', path)
+    monkeypatch.delitem(problems.WORKLOADS, 'queen', raising=False)
+    problems._register_queen()
+    wl = problems.WORKLOADS['queen']
+    A = wl['make']()
+    want = sp.csr_matrix(scipy.io.mmread(path))                  # figure_gen.py:350
+    assert wl['n'] == 40 and A.shape == (40, 40) and A.dtype == np.float64
+    assert A.nnz == want.nnz == 2 * 126 - 40                     # the stored triangle mirrored
+    assert abs(A - A.T).max() == 0 and abs(A - want).max() == 0 and A.has_sorted_indices
+    rows = wl['make'](rows=(10, 25))
+    assert rows.shape == (15, 40) and abs(rows - A[10:25]).max() == 0
+    monkeypatch.delitem(problems.WORKLOADS, 'queen', raising=False)
+
+
+@pytest.mark.gpu
+def test_queen_workload_runs_on_the_device(amd, monkeypatch):
+    problems = amd['problems']
+    monkeypatch.setenv('QUEEN_4147_MTX', os.path.join(GOLDEN, 'tiny_symmetric.mtx'))
+    monkeypatch.delitem(problems.WORKLOADS, 'queen', raising=False)
+    problems._register_queen()
+    A = problems.WORKLOADS['queen']['make']()
+    n = A.shape[0]
+    x = np.random.default_rng(34).standard_normal(n)
+    op = amd['device'].DeviceCSR(A)
+    products_bitexact(op, A, x, 'queen stand-in file')
+    op.close()
+    b, x0, x_true = problems.reference_rhs(A, n)
+    want = orc.pipe_pr_cg(A, b, x0, 30, callbacks=['updated_residual_2_norm', 'error_A_norm'], x_true=x_true)
+    got = amd['cgv'].pipe_pr_cg(A, b, x0, 30, callbacks=[amd['cbs'].updated_residual_2_norm, amd['cbs'].error_A_norm],
+                                x_true=x_true)
+    np.testing.assert_allclose(got['updated_residual_2_norm'][:12], want['updated_residual_2_norm'][:12], rtol=1e-12)
+    assert got['error_A_norm'][25] < 1e-8 * got['error_A_norm'][0]
+    monkeypatch.delitem(problems.WORKLOADS, 'queen', raising=False)
