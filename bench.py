@@ -44,6 +44,35 @@ def fused_bytes(n, nnz):    # one-launch iteration: A once, (r,s) read + written
     return 12 * nnz + 4 * (n + 1) + 64 * n
 
 
+def moved_bytes(algorithmic, nnz, sched):
+    """Bytes the launch MUST move with the operator stream the device actually reads (lossless
+    re-encodings of the caller's CSR: 1/2-byte column or window indices, 1-byte value-dictionary
+    indices; the dictionaries and tile descriptors, < 1 byte per nonzero, are not counted)."""
+    per_nnz = sched['col_bytes'] + (1 if sched['value_dict'] else 8)
+    return algorithmic - 12 * nnz + per_nnz * nnz
+
+
+def kernel_source_sha():
+    """Fingerprint of the kernel sources a PMC traffic figure was measured with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'new_cg_variants_amd', 'csrc', '*'))):
+        if f.endswith(('.hip', '.hpp', '.h', '.cpp')):
+            h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the PMC counters (tools/profile_round.sh -> profiles/traffic.json),
+    or None when the kernels have changed since they were collected."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        return t['entries'].get(key) if t.get('kernel_sha') == kernel_source_sha() else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(A, b, x0, family, seconds=15.0):
     """The CPU line: the NumPy/SciPy restatement of the reference's loop (oracle/, pinned
     bitwise against the imported reference in the build container) timed on this host."""
@@ -70,6 +99,9 @@ def cpu_baseline(A, b, x0, family, seconds=15.0):
                       f'BLAS ddot may use up to {threads} threads) on the same matrix, {os.cpu_count()} host cores visible'}
 
 
+PREWARM = 300      # untimed iterations before any clock starts: the chip's clocks are up, whatever --warmup says
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -80,10 +112,12 @@ def main():
     ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-comm', action='store_true',
-                    help='N=1 only: create a 1-rank RCCL communicator so the multi-rank schedule runs')
+                    help='N=1 only: the MAIN run uses a 1-rank RCCL communicator (multi-rank schedule)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-plain-values', action='store_true',
                     help='skip the second timed run with the value dictionary off')
+    ap.add_argument('--no-multi-rank-leg', action='store_true',
+                    help='skip the extra N=1 run of the multi-rank schedule (1-rank communicator)')
     args = ap.parse_args()
 
     # stdout is a protocol here (exactly one JSON line on rank 0): libraries that chat on
@@ -106,6 +140,7 @@ def main():
         torch.cuda.set_device(local_rank)          # torch.cuda.synchronize() below must mean THIS rank's GPU
     from new_cg_variants_amd import _lib as L
     from new_cg_variants_amd import partition, problems, scaling
+    from new_cg_variants_amd.device import DeviceCSR
 
     if world > 1:
         import torch.distributed as dist
@@ -129,39 +164,28 @@ def main():
     b, x0, x_true = problems.reference_rhs(A_rows, n)
     nnz_local = int(A_rows.nnz)
     nnz_total = sum(comm.allgather_obj(nnz_local))
+    n_local = hi - lo
 
-    t_setup = time.perf_counter()
-    if world == 1 and args.force_comm:
-        from new_cg_variants_amd.device import DeviceCSR
+    def one_rank_comm_device(knobs=None):
         uid = np.zeros((2, 128), dtype=np.uint8)
         path = L.default_rccl_path()
         for i in range(2):
             L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid[i])))
-        dev = DeviceCSR(A_rows.tocsr(), device=local_rank, comm_init=(0, 1, uid.tobytes(), path))
+        return DeviceCSR(A_rows.tocsr(), device=local_rank, comm_init=(0, 1, uid[:1].tobytes(), path), knobs=knobs)
+
+    t_setup = time.perf_counter()
+    if world == 1 and args.force_comm:
+        dev = one_rank_comm_device()
     else:
         op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
         dev = op.dev
     t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
     variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR}[args.variant]
-
-    # ---- standalone SpMV rate (north_star: effective SpMV HBM GB/s vs roofline) -----------
-    spmv = None
-    if world == 1:
-        xin = np.random.default_rng(0).standard_normal(n)
-        _, _ = dev.matvec(xin, reps=3)
-        _, ms1 = dev.matvec(xin, reps=20)
-        rs = np.stack([xin, xin[::-1]], axis=1)
-        _, ms2 = dev.matmat2(rs, reps=20)
-        spmv = {'spmv_ms': ms1, 'spmv_GBps': spmv_bytes(n, nnz_total) / ms1 * 1e-6,
-                'spmv_frac_of_peak': spmv_bytes(n, nnz_total) / ms1 * 1e-6 / HBM_PEAK_GBS,
-                'spmm2_ms': ms2, 'spmm2_GBps': spmm2_bytes(n, nnz_total) / ms2 * 1e-6}
-
-    # ---- the timed loop ----------------------------------------------------------------------
     K, W = args.steps, args.warmup
 
     def timed_run(dev):
-        dev.begin(variant, b, x0, W + K + 1)
-        dev.iterate(W)
+        dev.begin(variant, b, x0, PREWARM + W + K + 1)
+        dev.iterate(PREWARM + W)
         dev.sync()
         dev.set_profiling(max(1, K // 100))
         comm.Barrier()
@@ -177,52 +201,103 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, t_enq, dev.timings(), bool(np.isfinite(dev.get_scalars(W + K)[L.S_NU]))
+        return elapsed, t_enq, dev.timings(), bool(np.isfinite(dev.get_scalars(PREWARM + W + K)[L.S_NU]))
+
+    def product_rates(dev, sched):
+        """Standalone SpMV / two-vector SpMM of the resident operator (north_star: effective SpMV HBM GB/s)."""
+        xin = np.random.default_rng(0).standard_normal(n)
+        dev.matvec(xin, reps=30)
+        _, ms1 = dev.matvec(xin, reps=50)
+        rs = np.stack([xin, xin[::-1]], axis=1)
+        dev.matmat2(rs, reps=10)
+        _, ms2 = dev.matmat2(rs, reps=50)
+        b1, b2 = spmv_bytes(n, nnz_total), spmm2_bytes(n, nnz_total)
+        m1, m2 = moved_bytes(b1, nnz_total, sched), moved_bytes(b2, nnz_total, sched)
+        return {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'], 'window_kernels': sched['window'],
+                'spmv_ms': ms1, 'spmv_moved_GBps': m1 / ms1 * 1e-6, 'spmv_frac_of_peak': m1 / ms1 * 1e-6 / HBM_PEAK_GBS,
+                'spmv_algorithmic_GBps': b1 / ms1 * 1e-6,
+                'spmm2_ms': ms2, 'spmm2_moved_GBps': m2 / ms2 * 1e-6, 'spmm2_frac_of_peak': m2 / ms2 * 1e-6 / HBM_PEAK_GBS,
+                'spmm2_algorithmic_GBps': b2 / ms2 * 1e-6}
 
     elapsed, t_enq, tim, finite = timed_run(dev)
     sched = dev.schedule()
+    spmv = product_rates(dev, sched) if world == 1 else None
 
-    # The synthetic operators have few distinct values per tile, which the device exploits (lossless
-    # 1-byte value-dictionary stream).  An operator with incompressible values (an assembled FEM
-    # matrix) streams the doubles themselves: time that path too, same matrix, dictionary off.
+    # An operator whose values do not repeat (an assembled FEM matrix) streams the doubles themselves: time
+    # that path too, same matrix, value dictionary off.  This leg IS what SURVEY.md 8d's algorithmic bytes
+    # (12 B per nonzero) describe up to the narrower column stream.
     plain = None
     if world == 1 and not args.force_comm and sched['value_dict'] and not args.no_plain_values:
-        from new_cg_variants_amd.device import DeviceCSR
         dev2 = DeviceCSR(A_rows.tocsr(), device=local_rank, knobs={'PRCG_VALDICT': '0'})
         e2, _, tim2, fin2 = timed_run(dev2)
-        plain = (e2, tim2, fin2, dev2.schedule())
+        sched2 = dev2.schedule()
+        plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2))
         dev2.close()
 
+    # What the schedule every rank of an N>1 run executes costs on ONE GPU: the same loop with a 1-rank
+    # RCCL communicator (two streams, events, merged all-gather / all-reduce per iteration).
+    multi = None
+    if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant == 'pipe_pr_cg':
+        try:
+            dev3 = one_rank_comm_device()
+            e3, q3, tim3, fin3 = timed_run(dev3)
+            s3 = dev3.schedule()
+            multi = {'what': 'same workload and steps through the multi-rank schedule with a 1-rank RCCL communicator '
+                             '(update kernel + side-stream reduction/all-gather + SpMM per iteration)',
+                     'value': K / e3, 'unit': 'iters/s', 'ms_per_step': e3 / K * 1e3, 'spmm_ms': tim3['spmv_ms'],
+                     'update_ms': tim3['update_ms'], 'merged_allgather': s3['gather'], 'residual_finite': fin3,
+                     'host_enqueue_us_per_step': q3 / K * 1e6}
+            dev3.close()
+        except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it
+            multi = {'error': str(exc)[:200]}
+
     if rank == 0:
-        n_local = hi - lo
-        fused = (world == 1 and not args.force_comm and args.variant == 'pipe_pr_cg'
-                 and os.environ.get('PRCG_FUSED', '1') != '0')
+        fused = sched['fused']
         if fused:
             kbytes = fused_bytes(n_local, nnz_local)
-            kname = ('k_spmv_tiles<2,fused> (two-vector SpMM + next vector update + inner products, '
-                     'one launch per iteration)')
+            kname = ('one-launch pipelined iteration: two-vector SpMM + next vector update + inner products '
+                     '(' + ('k_win_tiles<2,fused>' if sched['window'] else 'k_spmv_tiles<2,fused>') + ')')
         elif args.variant == 'pipe_pr_cg':
             kbytes = spmm2_bytes(n_local, nnz_local)
-            kname = 'k_spmv_tiles<2> (two-vector SpMM, interior launch)'
+            kname = 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
         else:
             kbytes = spmv_bytes(n_local, nnz_local)
-            kname = 'k_spmv_tiles<1> (SpMV, interior launch)'
-        achieved = kbytes / tim['spmv_ms'] * 1e-6 if tim['spmv_ms'] > 0 else 0.0
-        # bytes the ENCODED operator needs on the stream (column offsets of col_bytes, values as
-        # 1-byte dictionary indices or as doubles; dictionaries themselves < 1 byte/nonzero, not counted)
-        per_nnz = sched['col_bytes'] + (1 if sched['value_dict'] else 8)
-        stream_bytes = kbytes - 12 * nnz_local + per_nnz * nnz_local
-        stream_rate = stream_bytes / tim['spmv_ms'] * 1e-6 if tim['spmv_ms'] > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                key = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
-                if fused and not sched['value_dict']:
-                    key += ':plain_values'
-                traffic = json.load(open(tfile)).get(key)
-            except Exception:
-                traffic = None
+            kname = 'SpMV, interior launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
+        ms = tim['spmv_ms']
+        moved = moved_bytes(kbytes, nnz_local, sched)
+        achieved = moved / ms * 1e-6 if ms > 0 else 0.0
+        tkey = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                'traffic': measured_traffic(tkey + (':dict' if sched['value_dict'] else ':plain')),
+                'kernel': kname, 'bytes_per_launch': moved, 'avg_launch_ms': ms, 'launches_sampled': tim['spmv_samples'],
+                'update_kernel_ms': tim['update_ms'],
+                'basis': ('achieved = bytes the launch must move / mean launch time by HIP events on the compute stream: '
+                          f"{sched['col_bytes']} B column stream + " + ('1 B value-dictionary index' if sched['value_dict'] else '8 B value')
+                          + ' per nonzero, 4 B row pointer and the vector traffic of SURVEY 8d per row'),
+                'operator_stream': {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'],
+                                    'window_kernels': sched['window']},
+                'effective': {'what': 'SURVEY.md 8d algorithmic CSR bytes (12 B per nonzero + vectors) / the same launch time: '
+                                      'north_star\'s "effective" bandwidth; exceeds the peak when the stream is compressed',
+                              'bytes_per_launch': kbytes, 'GBps': kbytes / ms * 1e-6 if ms > 0 else 0.0,
+                              'frac_of_peak': kbytes / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0}}
+        assert roof['frac'] <= 1.0, 'a physical fraction cannot exceed 1: the byte count is wrong'
+        if plain is not None:
+            e2, tim2, fin2, sched2, spmv2 = plain
+            ms2 = tim2['spmv_ms']
+            mv2 = moved_bytes(kbytes, nnz_local, sched2)
+            roof['plain_values'] = {
+                'what': 'same matrix and loop with the value dictionary off (PRCG_VALDICT=0): the rate of an operator '
+                        f"whose values do not repeat; {sched2['col_bytes']} B column stream + 8 B value per nonzero",
+                'value': K / e2, 'unit': 'iters/s', 'ms_per_step': e2 / K * 1e3, 'avg_launch_ms': ms2,
+                'achieved': kbytes / ms2 * 1e-6, 'frac': kbytes / ms2 * 1e-6 / HBM_PEAK_GBS,
+                'basis': 'SURVEY.md 8d algorithmic bytes (12 B per nonzero + vectors) / mean launch time',
+                'moved_GBps': mv2 / ms2 * 1e-6, 'moved_frac': mv2 / ms2 * 1e-6 / HBM_PEAK_GBS, 'bytes_moved_per_launch': mv2,
+                'traffic': measured_traffic(tkey + ':plain'), 'residual_finite': fin2, 'spmv': spmv2}
+            assert roof['plain_values']['frac'] <= 1.0
+        if spmv:
+            roof['spmv'] = spmv
+        if multi:
+            roof['multi_rank_schedule'] = multi
         out = {
             'metric': f'{args.variant} iterations/sec (synthetic banded CSR, fp64)',
             'value': K / elapsed, 'unit': 'iters/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -231,28 +306,10 @@ def main():
             'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
                        'partition': f'row blocks x{world}' + (' (nnz-balanced)' if world > 1 and args.workload in ('s4', 'queen') else ''), 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
                        'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6,
-                       'operator_setup_s': t_setup},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': kname,
-                         'algorithmic_bytes_per_launch': kbytes, 'avg_launch_ms': tim['spmv_ms'],
-                         'launches_sampled': tim['spmv_samples'], 'update_kernel_ms': tim['update_ms'],
-                         'operator_stream': {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'],
-                                             'bytes_per_launch': stream_bytes, 'GBps': stream_rate,
-                                             'frac_of_peak': stream_rate / HBM_PEAK_GBS},
-                         'note': ('achieved = SURVEY 8d algorithmic CSR bytes (12 B/nonzero) / launch time; the '
-                                  'device streams a lossless narrower encoding of the same operator, so achieved '
-                                  'can exceed what HBM delivers -- operator_stream and traffic are the bytes moved')},
+                       'operator_setup_s': t_setup, 'prewarm_steps': PREWARM,
+                       'schedule': {k: v for k, v in sched.items()}},
+            'roofline': roof,
         }
-        if plain is not None:
-            e2, tim2, fin2, sched2 = plain
-            a2 = kbytes / tim2['spmv_ms'] * 1e-6 if tim2['spmv_ms'] > 0 else 0.0
-            out['incompressible_values'] = {
-                'what': 'same run with the value dictionary off (PRCG_VALDICT=0): the rate for an operator whose '
-                        'values do not repeat; columns still ' + str(sched2['col_bytes']) + '-byte offsets',
-                'value': K / e2, 'unit': 'iters/s', 'ms_per_step': e2 / K * 1e3, 'avg_launch_ms': tim2['spmv_ms'],
-                'achieved': a2, 'frac': a2 / HBM_PEAK_GBS, 'residual_finite': fin2}
-        if spmv:
-            out['spmv'] = spmv
         if world == 1 and not args.no_cpu_baseline:
             fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr'}[args.variant]
             out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)

@@ -150,12 +150,58 @@ __device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meur
     return c;
 }
 
+// Extra per-row operands of the one-launch iteration (see FusedState): kernel arguments
+struct FusedRowPtrs {
+    double2* XP; double2* IN_NEW; double2* RS; const double* D; double* W; double* WT;
+};
+// the row's operands as loaded (ahead of time where the kernel can)
+struct FusedRowIn { double2 xp, rs; double d, w, wt; };
+
+// Update k of row `row` while (A in.x, A in.y)_row = sum is still in registers.
+//   unpreconditioned (pipe_pr_cg.py:61-74): in = (r,s);  w_prev = A r (recomputed) or the stored recurrence
+//   Jacobi           (pipe_pr_cg.py:169-186): in = (r~,s~); w~ = d w and u~ = d u as preconditioner(w), preconditioner(u)
+// Same expressions, same order, no FMA as k_pipe_update (the two-kernel schedule) -- vectors agree bit for bit.
+template <bool PREC, bool RECOMP>
+__device__ __forceinline__ void fused_row_update(int row, const double2& sum, const FusedRowIn& q, const double2& in_old,
+                                                 const FusedRowPtrs& f, const Coefs& cf, double (&acc)[5])
+{
+    const double us = sum.y;                                   // u = A s  (A s~)
+    const double wprev = RECOMP ? sum.x : q.w;                 // w = A r  (A r~), or the recurrence
+    const double xn = q.xp.x + cf.al * q.xp.y;                 // x += a p
+    if constexpr (!PREC) {
+        const double rn = in_old.x - cf.al * in_old.y;         // r -= a s
+        const double wn = wprev - cf.al * us;                  // w -= a u
+        const double pn = rn + cf.bt * q.xp.y;                 // p = r + b p
+        const double sn = wn + cf.bt * in_old.y;               // s = w + b s
+        f.XP[row] = make_double2(xn, pn);
+        f.IN_NEW[row] = make_double2(rn, sn);
+        if constexpr (!RECOMP) f.W[row] = wn;
+        acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+    } else {
+        const double ut = q.d * us;                            // u~ = M^-1 u
+        const double wtprev = RECOMP ? q.d * sum.x : q.wt;     // w~ = M^-1 w, or the recurrence
+        const double rn = q.rs.x - cf.al * q.rs.y;             // r -= a s
+        const double rtn = in_old.x - cf.al * in_old.y;        // r~ -= a s~
+        const double wn = wprev - cf.al * us;                  // w -= a u
+        const double wtn = wtprev - cf.al * ut;                // w~ -= a u~
+        const double pn = rtn + cf.bt * q.xp.y;                // p = r~ + b p
+        const double sn = wn + cf.bt * q.rs.y;                 // s = w + b s
+        const double stn = wtn + cf.bt * in_old.y;             // s~ = w~ + b s~
+        f.XP[row] = make_double2(xn, pn);
+        f.RS[row] = make_double2(rn, sn);
+        f.IN_NEW[row] = make_double2(rtn, stn);
+        if constexpr (!RECOMP) { f.W[row] = wn; f.WT[row] = wtn; }
+        acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn; acc[3] += rtn * rn; acc[4] += rn * rn;
+    }
+}
+
 // per-row epilogue: store y (and the fused extras)
 template <int NV, int EPI>
 __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::type& sum, void* __restrict__ yout_,
                                            int write_mask, const typename VecT<NV>::type* __restrict__ X,
                                            const double* __restrict__ ep_r, const double* __restrict__ ep_d,
-                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
+                                           double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf,
+                                           const FusedRowPtrs& fr)
 {
     if constexpr (NV == 1) {
         double* Y = reinterpret_cast<double*>(yout_);
@@ -172,22 +218,15 @@ __device__ __forceinline__ void finish_row(int row, const typename VecT<NV>::typ
             const double rv = ep_r[row], zv = X[row];
             acc[3] += rv * zv; acc[1] += sum * zv; acc[4] += rv * rv;
         }
-    } else if constexpr (EPI == kEpiPipeFused) {
-        // The NEXT iteration's vector update, row by row, while (w_i,u_i) = sum is still in
-        // registers (pipe_pr_cg.py:61-74): w and u never touch memory.  r,s are read from
-        // the OLD pair array X (other rows still gather from it) and written to the NEW one.
-        double2* __restrict__ XP = reinterpret_cast<double2*>(yout_);
-        double2* __restrict__ RSN = reinterpret_cast<double2*>(ep_st);
-        const double2 xp = XP[row];
-        const double2 rs = X[row];
-        const double xn = xp.x + cf.al * xp.y;               // x += a p
-        const double rn = rs.x - cf.al * rs.y;               // r -= a s
-        const double wn = sum.x - cf.al * sum.y;             // w -= a u      (w = A r, u = A s: just computed)
-        const double pn = rn + cf.bt * xp.y;                 // p = r + b p
-        const double sn = wn + cf.bt * rs.y;                 // s = w + b s
-        XP[row] = make_double2(xn, pn);
-        RSN[row] = make_double2(rn, sn);
-        acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+    } else if constexpr (epi_fused(EPI)) {
+        // one-launch iteration on the CSR-adaptive tiles: the row's operands are loaded here
+        // (the window kernels request them a tile ahead and call fused_row_update themselves)
+        FusedRowIn q;
+        q.xp = fr.XP[row];
+        const double2 in_old = X[row];
+        if constexpr (epi_prec(EPI)) { q.rs = fr.RS[row]; q.d = fr.D[row]; }
+        if constexpr (!epi_recompute(EPI)) { q.w = fr.W[row]; if constexpr (epi_prec(EPI)) q.wt = fr.WT[row]; }
+        fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, in_old, fr, cf, acc);
     } else {
         if (write_mask == 3) {
             reinterpret_cast<double2*>(yout_)[row] = sum;

@@ -154,7 +154,7 @@ struct prcg_handle {
     int k = 0;
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
-    DevBuf x, xp, p, rs, rs2, rst, wu, wt, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf x, xp, p, rs, rs2, rst, rst2, wu, wt, wv, r, s, rt, st, b, xt, dinv, e_ext;
     DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
@@ -162,7 +162,7 @@ struct prcg_handle {
     int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
     int max_row_len = 0;
     bool want_small = true;      // PRCG_SMALL=0 turns it off
-    double* rs_cur = nullptr;    // fused: which of rs / rs2 holds the current (r,s)
+    double* rs_cur = nullptr;    // fused: the current SpMM input pairs: rs / rs2 ((r,s)), with Jacobi rst / rst2 ((r~,s~))
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
     int pend_parts = 0;          // fused: dots[pend_k] exist only as this many block partials ...
     int pend_k = -1;             // ... of iteration pend_k, in pend_buf
@@ -278,13 +278,10 @@ int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu
     const CsrDev A = which == 0 ? h->csr() : (which == 1 ? h->csr(0, h->nt_bnd == 0) : h->csr(h->nt_int, false));
     return launch_spmm2(st, A, h->tile_ptr(first), nt, h->steps, rs, wu, mask, h->kn);
 }
-int eng_fused(prcg_t* h, hipStream_t st, const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-              double* coef_out, double* partials, int meur, FusedPrev prev) {
+int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f) {
     if (h->win)
-        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(), h->nwt_int + h->nwt_bnd, h->win_geom, rs_old, rs_new,
-                                     xp, dots_prev, coef_out, partials, meur, prev, h->win_per_cu);
-    return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, rs_old, rs_new, xp, dots_prev,
-                             coef_out, partials, meur, prev, h->kn);
+        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->win_per_cu);
+    return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, f, h->kn);
 }
 
 bool is_pipe(int v) { return v == PRCG_PIPE_PR || v == PRCG_PIPE_P || v == PRCG_PIPE_PR_M || v == PRCG_PIPE_P_M; }
@@ -561,9 +558,9 @@ PipeUpdateArgs pipe_args(prcg_t* h, int k) {
     return a;
 }
 
-// One launch per iteration (single GPU, unpreconditioned 'pr' flavours): state k-1 =
-// {XP, RS in rs_cur, dots[k-1]}; the kernel recomputes (w,u) = A [r s] row by row and
-// applies update k to the row at once.  The reduction of the inner products is NOT
+// One launch per iteration (single GPU, all four pipelined flavours, with or without Jacobi): state k-1 =
+// {XP, the SpMM input pairs in rs_cur, dots[k-1]} (+ (r,s) with Jacobi, + w (w~) for the 'p' flavours); the
+// kernel computes A [in.x in.y] row by row and applies update k to the row at once.  The reduction of the inner products is NOT
 // overlapped with anything here (it is needed at the head of the next launch) -- which is
 // why ranks with a communicator keep the two-kernel schedule below.
 // make dots[pend_k] real if the last fused launch left it as block partials
@@ -575,20 +572,31 @@ void fused_flush(prcg_t* h) {
 }
 
 int iterate_pipe_fused(prcg_t* h, int k) {
+    double* const bufA = h->prec ? h->rst.d() : h->rs.d();
+    double* const bufB = h->prec ? h->rst2.d() : h->rs2.d();
     double* rs_old = h->rs_cur;
-    double* rs_new = (h->rs_cur == h->rs.d()) ? h->rs2.d() : h->rs.d();
+    double* rs_new = (h->rs_cur == bufA) ? bufB : bufA;
     // partials of iteration k-1 (if still pending) are consumed by this launch's prologue
-    FusedPrev prev{nullptr, 0, nullptr};
+    FusedPrev prev{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (h->pend_parts > 0 && h->pend_k == k - 1) {
-        prev = FusedPrev{h->pend_buf, h->pend_parts, dots_at(h, k - 1)};
+        prev = FusedPrev{h->pend_buf, h->pend_parts, dots_at(h, k - 1), nullptr, nullptr, nullptr};
     } else {
         fused_flush(h);
     }
     double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int grid = eng_fused(h, h->sc, rs_old, rs_new, h->xp.d(), dots_at(h, k - 1), coef_at(h, k), part_out,
-                               meurant(h->variant), prev);
+    const bool rec = pipe_recompute(h->variant);
+    FusedState f{};
+    f.in_old = rs_old; f.in_new = rs_new; f.xp = h->xp.d();
+    f.rs = h->prec ? h->rs.d() : nullptr;
+    f.dinv = h->prec ? h->dinv.d() : nullptr;
+    f.w = rec ? nullptr : h->wv.d();
+    f.wt = (!rec && h->prec) ? h->wt.d() : nullptr;
+    f.dots_prev = dots_at(h, k - 1); f.coef_out = coef_at(h, k); f.partials = part_out;
+    f.meurant = meurant(h->variant); f.recompute_w = rec;
+    f.prev = prev;
+    const int grid = eng_fused(h, h->sc, f);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
@@ -783,12 +791,14 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         switch (which) {
         case PRCG_VEC_X: *base = h->xp.d(); *stride = 2; return true;
         case PRCG_VEC_P: *base = h->xp.d() + 1; *stride = 2; return true;
-        case PRCG_VEC_R: *base = (h->fused ? h->rs_cur : h->rs.d()); *stride = 2; return true;
-        case PRCG_VEC_S: *base = (h->fused ? h->rs_cur : h->rs.d()) + 1; *stride = 2; return true;
-        case PRCG_VEC_W: if (h->fused) return false; *base = h->wu.d(); *stride = 2; return true;
+        case PRCG_VEC_R: *base = ((h->fused && !h->prec) ? h->rs_cur : h->rs.d()); *stride = 2; return true;
+        case PRCG_VEC_S: *base = ((h->fused && !h->prec) ? h->rs_cur : h->rs.d()) + 1; *stride = 2; return true;
+        case PRCG_VEC_W:
+            if (h->fused) { if (pipe_recompute(v)) return false; *base = h->wv.d(); return true; }   // stored recurrence
+            *base = h->wu.d(); *stride = 2; return true;
         case PRCG_VEC_U: if (h->fused) return false; *base = h->wu.d() + 1; *stride = 2; return true;
-        case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rst.d(); *stride = 2; return true;
-        case PRCG_VEC_ST: if (!h->prec) return false; *base = h->rst.d() + 1; *stride = 2; return true;
+        case PRCG_VEC_RT: if (!h->prec) return false; *base = (h->fused ? h->rs_cur : h->rst.d()); *stride = 2; return true;
+        case PRCG_VEC_ST: if (!h->prec) return false; *base = (h->fused ? h->rs_cur : h->rst.d()) + 1; *stride = 2; return true;
         case PRCG_VEC_WT: if (!h->prec || pipe_recompute(v)) return false; *base = h->wt.d(); return true;
         default: return false;
         }
@@ -1292,19 +1302,22 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
 
     if (is_pipe(variant)) {
-        h->fused = h->want_fused && !h->multi() && !h->prec && pipe_recompute(variant) && h->g == 0;
+        h->fused = h->want_fused && !h->multi() && h->g == 0;
         if ((rc = plan_gather(h))) return rc;
         HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
-        HIPCHK(h, h->rs2.ensure(h->fused ? (size_t)2 * ne * D : 16, h->sc));
+        HIPCHK(h, h->rs2.ensure((h->fused && !h->prec) ? (size_t)2 * ne * D : 16, h->sc));
+        HIPCHK(h, h->rst2.ensure((h->fused && h->prec) ? (size_t)2 * ne * D : 16, h->sc));
+        HIPCHK(h, h->wv.ensure((h->fused && !pipe_recompute(variant)) ? (size_t)n * D : 16, h->sc));
         HIPCHK(h, h->partC.ensure(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         h->rs_cur = h->rs.d();
         // one-workgroup solver: only when nothing but the recurrence residual is recorded
-        h->small = h->fused && h->want_small &&
+        h->small = h->fused && h->want_small && !h->prec && pipe_recompute(variant) &&
                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
                    small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
         HIPCHK(h, h->rst.ensure(h->prec ? (size_t)2 * ne * D : 16, h->sc));
+        if (h->prec) h->rs_cur = h->rst.d();
         HIPCHK(h, h->wu.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->wt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
         double* RS = h->rs.d();
@@ -1335,6 +1348,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
             launch_copy(sc, WU + 1, 2, t1, 1, n);                           // u = A s~       :131
         }
+        if (h->fused && !pipe_recompute(variant)) launch_copy(sc, h->wv.d(), 1, WU, 2, n);   // the stored w of the 'p' flavours
         PipeUpdateArgs a = pipe_args(h, 0);
         const int grid = launch_pipe_dots(sc, a);                           // nu, mu, delta, gamma
         LAUNCHCHK(h, grid);
@@ -1497,14 +1511,17 @@ int prcg_get_vector(prcg_t* h, int which, double* out) {
     const int64_t n = h->n;
     double* base; int stride;
     if (!locate(h, which, &base, &stride)) {
-        // fused schedule: w = A r and u = A s are never stored -- recompute on request
-        if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U)) {
+        // fused schedule: u = A s (A s~) and, in the 'pr' flavours, w = A r (A r~) are never stored --
+        // recompute on request from the current SpMM input pairs
+        const bool tilde = is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT);
+        if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U || tilde))
             LAUNCHCHK(h, eng_spmm2(h, h->sc, 0, h->rs_cur, h->wu.d(), 3));
+        if (h->fused && (which == PRCG_VEC_W || which == PRCG_VEC_U)) {
             launch_copy(h->sc, h->t1.d(), 1, h->wu.d() + (which == PRCG_VEC_U ? 1 : 0), 2, n);
             return d2h(h, out, h->t1.d(), n);
         }
         // derived tilde vectors of the Jacobi 'pr' flavours: w~ = M^-1 w, u~ = M^-1 u
-        if (is_pipe(h->variant) && h->prec && (which == PRCG_VEC_UT || which == PRCG_VEC_WT)) {
+        if (tilde) {
             launch_mul(h->sc, h->t1.d(), 1, h->dinv.d(), 1, h->wu.d() + (which == PRCG_VEC_UT ? 1 : 0), 2, n);
             return d2h(h, out, h->t1.d(), n);
         }

@@ -22,7 +22,20 @@ struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 #endif
 
 // partial inner products of the previous one-launch iteration (see launch_pipe_fused)
-struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; };
+// (+ the in-place operands of the Jacobi / 'p' flavours, see FusedState)
+struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; double* rs; double* w; double* wt; };
+// State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
+// the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row
+// by row.  in = (r,s) unpreconditioned, (r~,s~) with Jacobi; in_new = the same array of the next
+// iteration (other rows still gather the old one).  rs: the plain (r,s) pairs with Jacobi (updated in
+// place: only the row itself reads them).  w / wt: the stored w, w~ of the 'p' flavours (in place).
+struct FusedState {
+    const double* in_old; double* in_new; double* xp;
+    double* rs; const double* dinv; double* w; double* wt;
+    const double* dots_prev; double* coef_out; double* partials;
+    int meurant, recompute_w;
+    FusedPrev prev;
+};
 
 // epilogues fused into the single-vector SpMV
 enum SpmvEpilogue {
@@ -31,7 +44,13 @@ enum SpmvEpilogue {
     kEpiPR = 2,      // st = d*y (or y); partials mu=p.s, dl=r.st, gm=st.s   (pr_pcg)
     kEpiPipeFused = 3,   // two-vector only: the next pipelined vector update, fused row by row
     kEpiCG = 4,      // partials nu = r.x, eta = y.x, rr = r.r                 (cg_cg: x = r~, y = w)
+    kEpiPipeFusedP = 5,  // ... 'p' flavours: w is the stored recurrence, only u = A s is used from the product
+    kEpiPipeFusedJ = 6,  // ... Jacobi, 'pr' flavours: input (r~,s~); w~ = d w, u~ = d u in registers
+    kEpiPipeFusedPJ = 7, // ... Jacobi, 'p' flavours
 };
+constexpr bool epi_fused(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedP || e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
+constexpr bool epi_prec(int e) { return e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
+constexpr bool epi_recompute(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedJ; }
 
 struct CsrDev {
     const int* indptr;
@@ -84,8 +103,7 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 // fixed order and block 0 stores the result to prev.dots_prev_out -- no reduction launch
 // between iterations.  Otherwise the reduced values are read from dots_prev.
 int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
-                      const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant, FusedPrev prev, TileKnobs kn = TileKnobs{});
+                      const FusedState& f, TileKnobs kn = TileKnobs{});
 
 // ---- window tiles: row-per-lane kernels for bands and stencils (prcg_win.hip) ---------------
 // Planned on the host by plan_window_tiles (prcg_plan.cpp).  The CSR arrays are the caller's;
@@ -127,9 +145,8 @@ int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
                     SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu);
 int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,
                      int write_mask, int per_cu);
-int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs_old,
-                          double* rs_new, double* xp, const double* dots_prev, double* coef_out, double* partials,
-                          int meurant, FusedPrev prev, int per_cu);
+int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
+                          int per_cu);
 
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {

@@ -161,7 +161,8 @@ __device__ __forceinline__ void process_tile(
     const CsrDev& A, const TileDesc& d, int lane, const MatRegs<STEPS, C16, VD>& cur,
     typename VecT<NV>::type* my, double* dict, const typename VecT<NV>::type* __restrict__ X,
     void* __restrict__ yout_, int write_mask, const double* __restrict__ ep_r,
-    const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf)
+    const double* __restrict__ ep_d, double* __restrict__ ep_st, double (&acc)[5], const Coefs& cf,
+    const FusedRowPtrs& fr)
 {
     using V = typename VecT<NV>::type;
     constexpr int kCap = 256 * STEPS - 3;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void process_tile(
         V sum; vzero(sum);
         for (int q = lo + lane; q < hi; q += 64) vacc(sum, vmul(A.val[q], X[A.col[q]]));
         sum = vwave_sum(sum);
-        if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+        if (lane == 0) finish_row<NV, EPI>(rb, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
         return;
     }
     const int alo = lo & ~3;   // 16-B aligned start; head slots < lo are never read
@@ -204,12 +205,12 @@ __device__ __forceinline__ void process_tile(
         my[o + 3] = vmul(a3, g3);
     }
     wave_lds_sync();
-    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
-    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+    if (row0 < re) finish_row<NV, EPI>(row0, lds_row_sum<NV>(my, s0r - alo, e0r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
+    if (row1 < re) finish_row<NV, EPI>(row1, lds_row_sum<NV>(my, s1r - alo, e1r - alo), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
     for (int row = rb + 128 + lane; row < re; row += 64) {
         const int s = A.indptr[row] - alo;
         const int e = A.indptr[row + 1] - alo;
-        finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf);
+        finish_row<NV, EPI>(row, lds_row_sum<NV>(my, s, e), yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
     }
     wave_lds_sync();
 }
@@ -242,7 +243,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
-    if constexpr (EPI == kEpiPipeFused) {
+    const FusedRowPtrs fr{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st), reinterpret_cast<double2*>(fz.rs),
+                          ep_d, fz.w, fz.wt};
+    if constexpr (epi_fused(EPI)) {
         // ep_r = the reduced inner products of the previous iteration; bit 2 of write_mask =
         // Meurant's prediction; aux = where alpha, beta, nu_pred of this iteration are kept
         if (fz.nprev > 0) {
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             }
             const int t2 = t + 2 * step;
             rn = read_raw<C16, VD>(T4, tbase, vdp, t2 < tend ? t2 : t);
-            process_tile<NV, EPI, STEPS, C16, VD>(A, d0, lane, m0, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
+            process_tile<NV, EPI, STEPS, C16, VD>(A, d0, lane, m0, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf, fr);
             t += step;
         }
         if (t >= tend) break;
@@ -326,12 +329,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
             }
             const int t2 = t + 2 * step;
             rn = read_raw<C16, VD>(T4, tbase, vdp, t2 < tend ? t2 : t);
-            process_tile<NV, EPI, STEPS, C16, VD>(A, d1, lane, m1, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf);
+            process_tile<NV, EPI, STEPS, C16, VD>(A, d1, lane, m1, my, dict, X, yout_, write_mask, ep_r, ep_d, ep_st, acc, cf, fr);
             t += step;
         }
     }
 
-    if constexpr (EPI == kEpiPipeFused) { acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+    if constexpr (epi_fused(EPI)) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
     else if constexpr (EPI == kEpiCG) block_reduce_store<5>(acc, partials, 0);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
@@ -937,7 +940,7 @@ int tile_grid(K kernel, int ntiles, int per_cu_override) {
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
-                 TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
+                 TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr})
 {
     const int cw = A.tile_base == nullptr ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
     const bool vd = A.vidx8 != nullptr;   // value dictionary
@@ -957,7 +960,7 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 template <int NV, int EPI>
 int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
                        void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
-                       double* partials, TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr})
+                       double* partials, TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr})
 {
     switch (steps) {
     case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, kn, aux, fz);
@@ -990,13 +993,24 @@ int launch_spmm2(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
                                            nullptr, kn);
 }
 
-int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps,
-                      const double* rs_old, double* rs_new, double* xp, const double* dots_prev,
-                      double* coef_out, double* partials, int meurant, FusedPrev prev, TileKnobs kn)
+int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, int steps, const FusedState& f, TileKnobs kn)
 {
     if (ntiles <= 0) return 0;
-    return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0),
-                                                dots_prev, nullptr, rs_new, partials, kn, coef_out, prev);
+    FusedPrev fz = f.prev;
+    fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
+    const int mask = 3 | (f.meurant ? 4 : 0);
+    if (f.dinv) {
+        if (f.recompute_w)
+            return launch_tiles_steps<2, kEpiPipeFusedJ>(steps, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
+                                                         f.in_new, f.partials, kn, f.coef_out, fz);
+        return launch_tiles_steps<2, kEpiPipeFusedPJ>(steps, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
+                                                      f.in_new, f.partials, kn, f.coef_out, fz);
+    }
+    if (f.recompute_w)
+        return launch_tiles_steps<2, kEpiPipeFused>(steps, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
+                                                    f.in_new, f.partials, kn, f.coef_out, fz);
+    return launch_tiles_steps<2, kEpiPipeFusedP>(steps, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
+                                                 f.in_new, f.partials, kn, f.coef_out, fz);
 }
 
 size_t small_lds_bytes(int n, int nnz, int mode) {

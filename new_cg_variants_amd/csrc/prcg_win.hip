@@ -76,12 +76,15 @@ struct WRegs {
     typename RegV<NV>::type w[PG];         // page p: column pc[p] + lane
     int s[M], e[M];                        // row pointers of rows rb + j*64 + lane
     d2_t xp[M];                         // fused iteration: (x,p) of those rows
+    d2_t rsx[M];                        // ... Jacobi: the plain (r,s) of those rows
+    double dd[M], ww[M], wwt[M];        // ... Jacobi: 1/diag; 'p' flavours: the stored w, w~
 };
 
-template <int NV, int M, int PG, int CW, bool VD, bool FUSED>
+template <int NV, int EPI, int M, int PG, int CW, bool VD>
 __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
                                             const typename VecT<NV>::type* __restrict__ X,
-                                            const double2* __restrict__ XP, WRegs<NV, M, PG, CW, VD>& R) {
+                                            const FusedRowPtrs& fr, WRegs<NV, M, PG, CW, VD>& R) {
+    constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // branch-free: a lane whose chunk lies past the tile re-reads the tile's first chunk (hot line)
     const int q16 = (alo + lane * 16) < d.hi ? (alo + lane * 16) : alo;
@@ -119,7 +122,17 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         const int rr = row < d.re ? row : d.rb;
         R.s[j] = A.indptr[rr];
         R.e[j] = A.indptr[rr + 1];
-        if constexpr (FUSED) R.xp[j] = reinterpret_cast<const d2_t*>(XP)[rr];
+        if constexpr (FUSED) {
+            R.xp[j] = reinterpret_cast<const d2_t*>(fr.XP)[rr];
+            if constexpr (epi_prec(EPI)) {
+                R.rsx[j] = reinterpret_cast<const d2_t*>(fr.RS)[rr];
+                R.dd[j] = fr.D[rr];
+            }
+            if constexpr (!epi_recompute(EPI)) {
+                R.ww[j] = fr.W[rr];
+                if constexpr (epi_prec(EPI)) R.wwt[j] = fr.WT[rr];
+            }
+        }
     }
 }
 
@@ -148,6 +161,7 @@ struct WCtx {
     const typename VecT<NV>::type* X;
     void* yout; int write_mask;
     const double* ep_r; const double* ep_d; double* ep_st;
+    FusedRowPtrs fr;
     int lane;
 };
 
@@ -160,7 +174,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
-    constexpr bool FUSED = (EPI == kEpiPipeFused);
+    constexpr bool FUSED = epi_fused(EPI);
     const int lane = c.lane;
     const unsigned short* sc16 = reinterpret_cast<const unsigned short*>(c.sc);
     const int alo = dcur.lo & ~15;
@@ -186,14 +200,21 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     for (int p = 0; p < PG; ++p)
         if (p < dcur.np) reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
     int rs_[M], re_[M];
-    d2_t xp_[M];
+    FusedRowIn fin[M];
 #pragma unroll
-    for (int j = 0; j < M; ++j) { rs_[j] = R.s[j]; re_[j] = R.e[j]; if constexpr (FUSED) xp_[j] = R.xp[j]; }
+    for (int j = 0; j < M; ++j) {
+        rs_[j] = R.s[j]; re_[j] = R.e[j];
+        if constexpr (FUSED) {
+            fin[j].xp = make_double2(R.xp[j].x, R.xp[j].y);
+            if constexpr (epi_prec(EPI)) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
+            if constexpr (!epi_recompute(EPI)) { fin[j].w = R.ww[j]; if constexpr (epi_prec(EPI)) fin[j].wt = R.wwt[j]; }
+        }
+    }
     wave_lds_sync();
 
     // ---- request the tile DEPTH ahead (the image registers are free again) ----
     if (have_next)
-        issue_loads<NV, M, PG, CW, VD, FUSED>(A, dnext, lane, c.X, reinterpret_cast<const double2*>(c.yout), R);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.fr, R);
 
     // ---- lane i walks row i (and i + 64, ...) ----
     const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
@@ -223,32 +244,25 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
                 if (j0 + u < len) vacc(sum, vmul(a[u], g[u]));
         }
         if constexpr (FUSED) {
-            // update k of the row while (w_i,u_i) = sum is in registers (pipe_pr_cg.py:61-74);
-            // (r,s)_i of the OLD pair array comes from the staged window, the new pair goes
-            // to the other array (ep_st)
-            const double2 rs = c.sw[active ? dcur.own + j * 64 + lane : 0];
-            if (active) {
-                double2* __restrict__ XP = reinterpret_cast<double2*>(c.yout);
-                double2* __restrict__ RSN = reinterpret_cast<double2*>(c.ep_st);
-                const double2 xp = make_double2(xp_[j].x, xp_[j].y);
-                const double xn = xp.x + cf.al * xp.y;               // x += a p
-                const double rn = rs.x - cf.al * rs.y;               // r -= a s
-                const double wn = sum.x - cf.al * sum.y;             // w -= a u
-                const double pn = rn + cf.bt * xp.y;                 // p = r + b p
-                const double sn = wn + cf.bt * rs.y;                 // s = w + b s
-                XP[row] = make_double2(xn, pn);
-                RSN[row] = make_double2(rn, sn);
-                acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
-            }
+            // update k of the row while (A in)_i = sum is in registers; the row's own entry of the OLD input
+            // pair array comes from the staged window, the new pair goes to the other array
+            const double2 in_old = c.sw[active ? dcur.own + j * 64 + lane : 0];
+            if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, fin[j], in_old, c.fr, cf, acc);
         } else {
-            if (active) finish_row<NV, EPI>(row, sum, c.yout, c.write_mask, c.X, c.ep_r, c.ep_d, c.ep_st, acc, cf);
+            if (active) finish_row<NV, EPI>(row, sum, c.yout, c.write_mask, c.X, c.ep_r, c.ep_d, c.ep_st, acc, cf, c.fr);
         }
     }
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
 }
 
-#ifndef PRCG_WIN_DEPTH
-#define PRCG_WIN_DEPTH 2
+// tiles in flight per wave (measured, profiles/r02_sweeps.md): the 2-byte-per-nonzero dictionary stream
+// gains 1-3 % from a second image; the plain 9-byte stream is at the memory system's rate for its
+// read/write mix with ONE (tools/membench.hip "fused-like": more requests in flight cost bandwidth)
+#ifndef PRCG_WIN_DEPTH_DICT
+#define PRCG_WIN_DEPTH_DICT 2
+#endif
+#ifndef PRCG_WIN_DEPTH_PLAIN
+#define PRCG_WIN_DEPTH_PLAIN 1
 #endif
 
 // One launch over window tiles.  Persistent grid, wave `slot` takes tiles slot, slot + W, ...
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     double* __restrict__ partials, double* __restrict__ aux, FusedPrev fz)
 {
     using V = typename VecT<NV>::type;
-    constexpr bool FUSED = (EPI == kEpiPipeFused);
+    constexpr bool FUSED = epi_fused(EPI);
     static_assert(!FUSED || NV == 2, "the fused iteration works on (r,s) pairs");
     static_assert(PG * 64 <= (CW == 8 ? 256 : 65536), "window index does not fit");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "one to three tiles in flight per wave");
@@ -278,7 +292,10 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_),
-                     yout_, write_mask, ep_r, ep_d, ep_st, lane};
+                     yout_, write_mask, ep_r, ep_d, ep_st,
+                     FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
+                                  reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt},
+                     lane};
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         d[i] = WDesc<PG>{};
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            issue_loads<NV, M, PG, CW, VD, FUSED>(A, d[i], lane, c.X, reinterpret_cast<const double2*>(yout_), R[i]);
+            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
         }
     }
     if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         }
     }
 
-    if constexpr (FUSED) { acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
+    if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
@@ -392,7 +409,7 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
                  int per_cu)
 {
     const bool vd = A.vidx8 != nullptr;
-    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB, PRCG_WIN_DEPTH> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB, PRCG_WIN_DEPTH>;
+    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB, PRCG_WIN_DEPTH_DICT> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB, PRCG_WIN_DEPTH_PLAIN>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][16] = {};
     int dev = 0;
@@ -429,7 +446,7 @@ int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
                     SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu)
 {
     if (ntiles <= 0) return 0;
-    const FusedPrev none{nullptr, 0, nullptr};
+    const FusedPrev none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     switch (epi) {
     case kEpiNone: return launch_win<1, kEpiNone>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
     case kEpiDotXY: return launch_win<1, kEpiDotXY>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
@@ -445,16 +462,28 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
 {
     if (ntiles <= 0) return 0;
     return launch_win<2, kEpiNone>(geom, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                   FusedPrev{nullptr, 0, nullptr}, per_cu);
+                                   FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr}, per_cu);
 }
 
-int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs_old,
-                          double* rs_new, double* xp, const double* dots_prev, double* coef_out, double* partials,
-                          int meurant, FusedPrev prev, int per_cu)
+int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
+                          int per_cu)
 {
     if (ntiles <= 0) return 0;
-    return launch_win<2, kEpiPipeFused>(geom, st, A, tiles, ntiles, rs_old, xp, 3 | (meurant ? 4 : 0), dots_prev, nullptr,
-                                        rs_new, partials, coef_out, prev, per_cu);
+    FusedPrev fz = f.prev;
+    fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
+    const int mask = 3 | (f.meurant ? 4 : 0);
+    if (f.dinv) {
+        if (f.recompute_w)
+            return launch_win<2, kEpiPipeFusedJ>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new,
+                                                 f.partials, f.coef_out, fz, per_cu);
+        return launch_win<2, kEpiPipeFusedPJ>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new,
+                                              f.partials, f.coef_out, fz, per_cu);
+    }
+    if (f.recompute_w)
+        return launch_win<2, kEpiPipeFused>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new,
+                                            f.partials, f.coef_out, fz, per_cu);
+    return launch_win<2, kEpiPipeFusedP>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new,
+                                         f.partials, f.coef_out, fz, per_cu);
 }
 
 }  // namespace prcg

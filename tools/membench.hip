@@ -53,6 +53,44 @@ __global__ __launch_bounds__(256) void k_update_like(double2* __restrict__ a, do
         b[i] = make_double2(y.x - 0.5 * y.y, z.x + 0.25 * y.y);
     }
 }
+// The byte mix of the one-launch pipelined iteration on S3 with plain values, no arithmetic to speak of:
+// per 64-row tile a wave reads 7.5 KB of an 8-byte stream, 1 KB of a 1-byte stream, (x,p) and (r,s) of its
+// rows (1 KB each) and writes both pairs back to (x,p) and a second (r,s) array: 203 bytes per row.
+// DEPTH tiles in flight per wave, persistent strided tiles like k_win_tiles.
+template <int DEPTH>
+__global__ __launch_bounds__(128) void k_fused_like(const double2* __restrict__ val, const uint4* __restrict__ col,
+                                                    double2* __restrict__ xp, const double2* __restrict__ rs,
+                                                    double2* __restrict__ rsn, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int W = gridDim.x * 2;
+    int t = blockIdx.x * 2 + (threadIdx.x >> 6);
+    double2 v[DEPTH][8], x[DEPTH], r[DEPTH];
+    uint4 c[DEPTH];
+    auto issue = [&](int i, int tt) {
+#pragma unroll
+        for (int st = 0; st < 8; ++st) v[i][st] = val[(size_t)tt * 480 + (st * 64 + lane < 480 ? st * 64 + lane : 0)];
+        c[i] = col[(size_t)tt * 60 + (lane < 60 ? lane : 0)];
+        x[i] = xp[(size_t)tt * 64 + lane];
+        r[i] = rs[(size_t)tt * 64 + lane];
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) if (t + i * W < ntiles) issue(i, t + i * W);
+    while (t < ntiles) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            if (t < ntiles) {
+                double s = (double)(c[i].x & 1u);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) s += v[i][st].x + v[i][st].y;
+                const double2 xo = x[i], ro = r[i];
+                if (t + DEPTH * W < ntiles) issue(i, t + DEPTH * W);
+                xp[(size_t)t * 64 + lane] = make_double2(xo.x + s, xo.y + ro.x);
+                rsn[(size_t)t * 64 + lane] = make_double2(ro.x - s, ro.y + xo.y);
+                t += W;
+            }
+        }
+    }
+}
 int main() {
     const size_t bytes = (size_t)2 << 30;   // 2 GiB per buffer
     const size_t n2 = bytes / 16;
@@ -82,5 +120,16 @@ int main() {
     time([&] { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, a, b, n2); }, "copy grid 8192 (r+w bytes)", 2 * G);
     time([&] { hipLaunchKernelGGL(k_update_like, dim3(2048), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 2048", 5 * G);
     time([&] { hipLaunchKernelGGL(k_update_like, dim3(8192), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 8192", 5 * G);
+    {   // S3-shaped: 1e7 rows
+        const int ntiles = 10000000 / 64;
+        const double gb = 203.0 * 64 * ntiles / 1e9;
+        for (int per_cu : {2, 4, 6, 8}) {
+            char nm[64];
+            snprintf(nm, 64, "fused-like depth1 %d wg/CU", per_cu);
+            time([&] { hipLaunchKernelGGL(k_fused_like<1>, dim3(per_cu * 256), dim3(128), 0, 0, a, (const uint4*)b, c, c + (1 << 26), c + (1 << 25), ntiles); }, nm, gb);
+            snprintf(nm, 64, "fused-like depth2 %d wg/CU", per_cu);
+            time([&] { hipLaunchKernelGGL(k_fused_like<2>, dim3(per_cu * 256), dim3(128), 0, 0, a, (const uint4*)b, c, c + (1 << 26), c + (1 << 25), ntiles); }, nm, gb);
+        }
+    }
     return 0;
 }
