@@ -109,7 +109,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='s3',
                     help='s1 s2 s3 s4 s4b s3_8th s1_small s3_small; queen if QUEEN_4147_MTX names the MatrixMarket file')
-    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg'])
+    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg'],
+                    help='pipe_pr_pcg = the pipelined variant with the Jacobi preconditioner (figure_gen.py:42-44)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-comm', action='store_true',
                     help='N=1 only: the MAIN run uses a 1-rank RCCL communicator (multi-rank schedule)')
@@ -180,11 +181,12 @@ def main():
         op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
         dev = op.dev
     t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
-    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR}[args.variant]
+    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P}[args.variant]
+    inv_diag = (1.0 / A_rows.tocsr()[:, lo:hi].diagonal()) if args.variant == 'pipe_pr_pcg' else None
     K, W = args.steps, args.warmup
 
     def timed_run(dev):
-        dev.begin(variant, b, x0, PREWARM + W + K + 1)
+        dev.begin(variant, b, x0, PREWARM + W + K + 1, inv_diag=inv_diag)
         dev.iterate(PREWARM + W)
         dev.sync()
         dev.set_profiling(max(1, K // 100))
@@ -237,7 +239,7 @@ def main():
     # What the schedule every rank of an N>1 run executes costs on ONE GPU: the same loop with a 1-rank
     # RCCL communicator (two streams, events, merged all-gather / all-reduce per iteration).
     multi = None
-    if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant == 'pipe_pr_cg':
+    if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant.startswith('pipe_'):
         try:
             dev3 = one_rank_comm_device()
             e3, q3, tim3, fin3 = timed_run(dev3)
@@ -254,10 +256,11 @@ def main():
     if rank == 0:
         fused = sched['fused']
         if fused:
-            kbytes = fused_bytes(n_local, nnz_local)
+            # + (r,s) read and written beside (r~,s~) and the diagonal with Jacobi; + w read and written in the 'p' flavours
+            kbytes = fused_bytes(n_local, nnz_local) + (40 * n_local if inv_diag is not None else 0) + (16 * n_local if args.variant == 'pipe_p_cg' else 0)
             kname = ('one-launch pipelined iteration: two-vector SpMM + next vector update + inner products '
                      '(' + ('k_win_tiles<2,fused>' if sched['window'] else 'k_spmv_tiles<2,fused>') + ')')
-        elif args.variant == 'pipe_pr_cg':
+        elif args.variant.startswith('pipe_'):
             kbytes = spmm2_bytes(n_local, nnz_local)
             kname = 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
         else:
@@ -311,7 +314,7 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr'}[args.variant]
+            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe'}[args.variant]
             out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None

@@ -181,6 +181,8 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_VALDICT 32   /* interior tiles stream 1-byte value-dictionary indices (lossless) */
 #define PRCG_SCHED_COL8 64      /* ... and 1-byte tile-relative column offsets */
 #define PRCG_SCHED_COL16 128    /* ... 2-byte */
+#define PRCG_SCHED_FUSED_COMM 8192 /* one launch per iteration WITH a communicator: the interior launch waits in-kernel
+                                      for the reduced inner products of the previous iteration */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
 int prcg_schedule(const prcg_t* h);
@@ -221,6 +223,18 @@ int prcg_solve(prcg_t* h, int variant, const double* b, const double* x0, int ma
 int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_class,
                         int cap_nnz, int cap_rows, int32_t* tiles_out, int64_t capacity,
                         int64_t* n_class0);
+/* Window tiling (row-per-lane kernels for bands and stencils): rows are cut into tiles of at most
+ * rows_per_tile (64 | 128) consecutive rows of one class whose columns -- and the tile's own rows --
+ * are covered by a few PAGES of 64 consecutive columns; the kernels stage those pages of the input
+ * vector in LDS and stream, per nonzero, its index page*64+offset into that window (cw_out, nullable).
+ * tiles_out: 20 int32 per tile {row_begin, row_end, nnz_begin, nnz_end, pages | own_row_index << 8,
+ * longest row, 0, 0, first column of page 0..11}; n_cols = owned + ghost columns.  Returns the number
+ * of tiles, 0 if the operator does not qualify (some tile needs too many pages or holds a row longer
+ * than a tile: the CSR-adaptive kernels run instead), -needed if capacity is too small, -1 on a bad
+ * argument.  What prcg_set_csr runs internally; exported for the CPU tests. */
+int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+                         const uint8_t* row_class, int rows_per_tile, int32_t* tiles_out, int64_t capacity,
+                         uint16_t* cw_out, int64_t* n_class0, int* most_pages);
 /* Merged exchange of the multi-GPU pipelined loop (small halos ride on the one all-gather per
  * iteration): where in the gathered buffer do this rank's ghost rows lie?  `tables`: every rank's
  * send table, doubles_per_table doubles each: [n_peers, (peer, first row of its list, rows)...];

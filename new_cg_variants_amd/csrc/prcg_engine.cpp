@@ -157,6 +157,10 @@ struct prcg_handle {
     DevBuf x, xp, p, rs, rs2, rst, rst2, wu, wt, wv, r, s, rt, st, b, xt, dinv, e_ext;
     DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
+    bool fused_comm = false;     // ... with a communicator: the interior launch waits in-kernel for the reduction
+    bool want_fused_comm = true; // PRCG_FUSED_COMM=0: communicator sessions keep the two-kernel schedule
+    DevBuf pub, pub_err;         // publication record of the reduced inner products / timeout flag
+    bool red_pending = false;    // an e_red of the previous iteration is outstanding on the communication stream
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
     bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
     int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
@@ -278,9 +282,12 @@ int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu
     const CsrDev A = which == 0 ? h->csr() : (which == 1 ? h->csr(0, h->nt_bnd == 0) : h->csr(h->nt_int, false));
     return launch_spmm2(st, A, h->tile_ptr(first), nt, h->steps, rs, wu, mask, h->kn);
 }
-int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f) {
-    if (h->win)
-        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->win_per_cu);
+int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f, int which = 0) {
+    if (h->win) {
+        const int first = which == 2 ? h->nwt_int : 0;
+        const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
+        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, f, h->win_per_cu);
+    }
     return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, f, h->kn);
 }
 
@@ -402,7 +409,8 @@ void fused_flush(prcg_t* h);
 int record(prcg_t* h, int k) {
     const uint32_t m = h->hist_mask;
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
-    if (h->fused) fused_flush(h);    // the recorders reuse the partials buffers
+    if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
+    if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
     const int64_t n = h->n;
     int rc;
     if (m & PRCG_HIST_RESIDUAL_2_NORM) {
@@ -604,8 +612,75 @@ int iterate_pipe_fused(prcg_t* h, int k) {
     return PRCG_OK;
 }
 
+// One launch per iteration WITH a communicator (window operators): the GPU form of
+// VecDotBegin ... KSP_MatMult ... VecDotEnd (scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173).
+//
+//   compute stream : [interior tiles k: products of each wave's first tiles | wait pub >= k-1 | their updates |
+//                     remaining tiles fused] -wait Er(k-1)-> [boundary tiles k, fused] -E1(k)-> [interior tiles k+1 ...
+//   comm stream    : wait E1(k) -> [pack partials + rows] [ncclAllGather] [unpack: dots[k], ghosts of (r,s)_k,
+//                     publish k] -Er(k)->          (large halos: [send/recv] [reduce] [ncclAllReduce] [publish k])
+//
+// The reduction of iteration k-1 runs while the interior launch of iteration k computes A [r s] -- the
+// overlap the two-kernel schedule has, without storing (w,u) and without a separate update launch.
+int iterate_pipe_fused_comm(prcg_t* h, int k) {
+    double* const bufA = h->prec ? h->rst.d() : h->rs.d();
+    double* const bufB = h->prec ? h->rst2.d() : h->rs2.d();
+    double* in_old = h->rs_cur;
+    double* in_new = (h->rs_cur == bufA) ? bufB : bufA;
+    double* part_out = (k & 1) ? h->partB.d() : h->partC.d();
+    const bool rec = pipe_recompute(h->variant);
+    FusedState f{};
+    f.in_old = in_old; f.in_new = in_new; f.xp = h->xp.d();
+    f.rs = h->prec ? h->rs.d() : nullptr;
+    f.dinv = h->prec ? h->dinv.d() : nullptr;
+    f.w = rec ? nullptr : h->wv.d();
+    f.wt = (!rec && h->prec) ? h->wt.d() : nullptr;
+    f.dots_prev = dots_at(h, k - 1); f.coef_out = coef_at(h, k); f.partials = part_out;
+    f.meurant = meurant(h->variant); f.recompute_w = rec;
+    f.prev = FusedPrev{};
+    f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
+    if (getenv("PRCG_DEBUG_NOWAIT")) f.prev.want = 0u;     // timing experiment only: results are wrong
+    f.deferred = 1;
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int g1 = eng_fused(h, h->sc, f, 1);
+    LAUNCHCHK(h, g1);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    int g2 = 0;
+    if (h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));   // dots[k-1] final, ghosts of (r,s)_{k-1} in place
+    if (h->nwt_bnd > 0) {
+        f.deferred = 0;
+        f.partials = part_out + (size_t)g1 * kPartialStride;
+        f.coef_out = coef_at(h, k);
+        g2 = eng_fused(h, h->sc, f, 2);
+        LAUNCHCHK(h, g2);
+    }
+    HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    const int nparts = g1 + g2;
+    int rc;
+    if (h->gather) {
+        const int np = h->have_halo ? h->n_peers : 0;
+        double* slot = h->gbuf.d() + (size_t)h->rank * h->g_slot;
+        launch_gather_pack(h->sm, part_out, nparts, slot, in_new, h->send_idx.i(), np > 0 ? (int)h->send_ptr[np] : 0);
+        NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
+        launch_gather_unpack(h->sm, h->gbuf.d(), h->g_slot, h->nranks, dots_at(h, k), in_new + 2 * h->n, h->ghost_src.i(),
+                             (int)h->g, h->pub.d(), (unsigned)k);
+    } else {
+        if (h->have_halo && h->n_peers > 0 && (rc = exchange(h, in_new, 2, h->sm))) return rc;
+        launch_reduce_final(h->sm, part_out, nparts, dots_at(h, k), 0, 0, 5);
+        if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
+        launch_publish(h->sm, dots_at(h, k), h->pub.d(), (unsigned)k);
+    }
+    HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+    h->red_pending = true;
+    h->rs_cur = in_new;
+    return PRCG_OK;
+}
+
 int iterate_pipe(prcg_t* h, int k) {
     // pipe_pr_cg.py:61-75 / :169-187
+    if (h->fused_comm) return iterate_pipe_fused_comm(h, k);
     if (h->fused) return iterate_pipe_fused(h, k);
     PipeUpdateArgs a = pipe_args(h, k);
     bool on = false;
@@ -762,6 +837,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_TILE_ORDER") h->kn.chunked = (val[0] == 'c') ? 1 : 0;
     else if (k == "PRCG_TILE_STEPS") h->steps_override = (v == 1 || v == 2 || v == 4) ? (int)v : 0;
     else if (k == "PRCG_WIN") h->want_win = v != 0;
+    else if (k == "PRCG_FUSED_COMM") h->want_fused_comm = v != 0;
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
     else if (k == "PRCG_WIN_MAX_MEAN") { if (v >= 1) h->win_max_mean = (int)v; }
     else return false;
@@ -769,7 +845,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 }
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
-                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN"};
+                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1303,17 +1379,28 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
 
     if (is_pipe(variant)) {
         h->fused = h->want_fused && !h->multi() && h->g == 0;
+        // with a communicator: the same kernel in its deferred form (window operators only)
+        h->fused_comm = false;
+        h->red_pending = false;
         if ((rc = plan_gather(h))) return rc;
+        // with a communicator: the same kernel in its deferred form -- window operators whose halo rides on the
+        // one all-gather per iteration (bands; the merged exchange).  Larger halos (send/recv + all-reduce chain)
+        // keep the two-kernel schedule: RCCL's point-to-point path was seen to stall for ~1 s on its first use
+        // from the communication stream while a launch waited for it (profiles/r02_sweeps.md).
+        h->fused_comm = h->want_fused && h->want_fused_comm && h->multi() && h->win && !h->fused_final && h->gather;
+        if (h->fused_comm) h->fused = true;        // state layout, derived vectors: as the one-launch schedule
         HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
         HIPCHK(h, h->rs2.ensure((h->fused && !h->prec) ? (size_t)2 * ne * D : 16, h->sc));
         HIPCHK(h, h->rst2.ensure((h->fused && h->prec) ? (size_t)2 * ne * D : 16, h->sc));
         HIPCHK(h, h->wv.ensure((h->fused && !pipe_recompute(variant)) ? (size_t)n * D : 16, h->sc));
         HIPCHK(h, h->partC.ensure(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
+        HIPCHK(h, h->pub.ensure(h->fused_comm ? kPubDoubles * sizeof(double) : 16, h->sc));
+        HIPCHK(h, h->pub_err.ensure(64, h->sc));
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         h->rs_cur = h->rs.d();
         // one-workgroup solver: only when nothing but the recurrence residual is recorded
-        h->small = h->fused && h->want_small && !h->prec && pipe_recompute(variant) &&
+        h->small = h->fused && !h->fused_comm && h->want_small && !h->prec && pipe_recompute(variant) &&
                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
                    small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
         HIPCHK(h, h->rst.ensure(h->prec ? (size_t)2 * ne * D : 16, h->sc));
@@ -1354,6 +1441,32 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         LAUNCHCHK(h, grid);
         if (!h->fused_final) launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
         if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+        if (h->fused_comm) {
+            // Can a kernel of the communication stream run while a kernel of the compute stream waits for it?  (HIP
+            // may have mapped both streams to one hardware queue -- then the deferred form would only ever time
+            // out.)  Probe once per session: a one-wave kernel on sc waits ~2 ms at most for a record that a kernel
+            // on sm publishes.
+            HIPCHK(h, hipStreamSynchronize(sc));
+            // first use of the communicator from the communication stream happens HERE, not inside a launch that waits
+            {
+                double* slot = h->gbuf.d() + (size_t)h->rank * h->g_slot;
+                NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
+                HIPCHK(h, hipStreamSynchronize(h->sm));
+            }
+            launch_probe_wait(sc, h->pub.d(), 0x7f000000u, static_cast<unsigned*>(h->pub_err.p));
+            launch_publish(h->sm, dots_at(h, 0), h->pub.d(), 0x7f000000u);
+            HIPCHK(h, hipStreamSynchronize(h->sm));
+            HIPCHK(h, hipStreamSynchronize(sc));
+            unsigned perr = 0;
+            HIPCHK(h, hipMemcpy(&perr, h->pub_err.p, sizeof perr, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemset(h->pub_err.p, 0, sizeof perr));
+            if (perr) { h->fused_comm = false; h->fused = false; }       // streams are serialised here: two-kernel schedule
+        }
+        if (h->fused_comm) {
+            // iteration 1 waits for "0": the initial inner products; ghosts of the initial (r,s) for its boundary tiles
+            launch_publish(sc, dots_at(h, 0), h->pub.d(), 0u);
+            if ((rc = exchange(h, h->rs_cur, 2, sc))) return rc;
+        }
     } else if (is_cg_family(variant)) {
         // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
@@ -1471,7 +1584,11 @@ int prcg_iterate(prcg_t* h, int iters) {
         if ((rc = record(h, k))) return rc;
         h->k = k;
     }
-    if (h->fused) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
+    if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
+    if (h->fused_comm && h->red_pending) {
+        // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
+        HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+    }
     return PRCG_OK;
 }
 
@@ -1481,6 +1598,13 @@ int prcg_sync(prcg_t* h) {
     HIPCHK(h, hipStreamSynchronize(h->sh));
     HIPCHK(h, hipStreamSynchronize(h->sm));
     HIPCHK(h, hipStreamSynchronize(h->sc));
+    if (h->in_session && h->fused_comm && h->pub_err.p) {
+        unsigned err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->pub_err.p, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(h, PRCG_ERCCL, "a one-launch iteration waited more than its bound for the reduced inner products "
+                                            "(communication stream starved or a peer stalled); results are invalid. "
+                                            "PRCG_FUSED_COMM=0 selects the two-kernel schedule");
+    }
     return PRCG_OK;
 }
 
@@ -1488,7 +1612,7 @@ int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
-    return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+    return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW
@@ -1500,6 +1624,16 @@ int prcg_set_iteration(prcg_t* h, int k) {
     CHECK(h, h->in_session, "prcg_set_iteration: no open session");
     CHECK(h, k >= 0 && k < h->max_iter, "prcg_set_iteration: k out of range");
     h->k = k;
+    if (h->fused_comm) {
+        // teacher forcing: what the deferred launch of iteration k+1 waits for and what its boundary tiles read
+        // must describe the state just loaded
+        int rc = prcg_sync(h);
+        if (rc) return rc;
+        launch_publish(h->sc, dots_at(h, k), h->pub.d(), (unsigned)k);
+        if ((rc = exchange(h, h->rs_cur, 2, h->sc))) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->sc));
+        h->red_pending = false;
+    }
     return PRCG_OK;
 }
 
@@ -1564,7 +1698,12 @@ int prcg_set_scalars(prcg_t* h, int k, const double* in) {
     CHECK(h, h->in_session && in && k >= 0 && k <= h->max_iter, "prcg_set_scalars: bad argument");
     int rc = prcg_sync(h);
     if (rc) return rc;
-    return h2d(h, dots_at(h, k), in, kNS);
+    if ((rc = h2d(h, dots_at(h, k), in, kNS))) return rc;
+    if (h->fused_comm) {      // the deferred launch of iteration k+1 reads the published copy
+        launch_publish(h->sc, dots_at(h, k), h->pub.d(), (unsigned)k);
+        HIPCHK(h, hipStreamSynchronize(h->sc));
+    }
+    return PRCG_OK;
 }
 
 int prcg_get_coefficients(prcg_t* h, int k, double* out) {
@@ -1654,6 +1793,26 @@ int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_cla
     int64_t o = 0;
     for (const auto& t : t0) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
     for (const auto& t : t1) { tiles_out[2 * o] = t.row_begin; tiles_out[2 * o + 1] = t.row_end; ++o; }
+    return total;
+}
+
+int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const uint8_t* row_class,
+                         int rows_per_tile, int32_t* tiles_out, int64_t capacity, uint16_t* cw_out, int64_t* n_class0,
+                         int* most_pages) {
+    if (n < 0 || n_cols < n || !indptr || (indptr[n] > 0 && !indices) || (rows_per_tile != 64 && rows_per_tile != 128) ||
+        (!tiles_out && capacity > 0))
+        return -1;
+    WinPlan wp;
+    plan_window_tiles(n, n_cols, indptr, indices, row_class, rows_per_tile, kWinCapNnz, win_max_pages(rows_per_tile), wp);
+    if (!wp.ok0 || !wp.ok1) return 0;                       // not a window operator
+    const int64_t total = (int64_t)wp.t0.size() + (int64_t)wp.t1.size();
+    if (n_class0) *n_class0 = (int64_t)wp.t0.size();
+    if (most_pages) *most_pages = wp.pages0 > wp.pages1 ? wp.pages0 : wp.pages1;
+    if (total > capacity) return -total;
+    int64_t o = 0;
+    for (const auto* v : {&wp.t0, &wp.t1})
+        for (const auto& t : *v) { memcpy(tiles_out + 20 * o, &t, sizeof t); ++o; }
+    if (cw_out) memcpy(cw_out, wp.cw.data(), (size_t)indptr[n] * sizeof(uint16_t));
     return total;
 }
 

@@ -23,7 +23,14 @@ struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 
 // partial inner products of the previous one-launch iteration (see launch_pipe_fused)
 // (+ the in-place operands of the Jacobi / 'p' flavours, see FusedState)
-struct FusedPrev { const double* prev_partials; int nprev; double* dots_prev_out; double* rs; double* w; double* wt; };
+struct FusedPrev {
+    const double* prev_partials; int nprev; double* dots_prev_out; double* rs; double* w; double* wt;
+    // multi-rank one-launch schedule: the inner products of the previous iteration arrive WHILE this launch
+    // runs (reduced across ranks on the communication stream, published in `pub`: kPubCopies records of 64
+    // bytes, each 5 doubles + a 32-bit iteration counter at byte 48, all stored write-through).  Each wave first computes the products of
+    // its first tiles, then waits for pub's counter to reach `want`, then applies the deferred updates.
+    const double* pub; unsigned want; unsigned* err;
+};
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
 // the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row
 // by row.  in = (r,s) unpreconditioned, (r~,s~) with Jacobi; in_new = the same array of the next
@@ -35,6 +42,7 @@ struct FusedState {
     const double* dots_prev; double* coef_out; double* partials;
     int meurant, recompute_w;
     FusedPrev prev;
+    int deferred;     // 1: the launch waits in-kernel for prev.pub (communicator sessions, interior tiles)
 };
 
 // epilogues fused into the single-vector SpMV
@@ -227,6 +235,13 @@ void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, i
 void launch_gather_pack(hipStream_t st, const double* partials, int nparts, double* slot, const double* rs,
                         const int* send_idx, int nsend);
 void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
-                          double* rs_ghost, const int* ghost_src, int nghost);
+                          double* rs_ghost, const int* ghost_src, int nghost, double* pub = nullptr, unsigned pub_value = 0);
+// every copy c: pub[8c .. 8c+5) = dots[0..5), then the copy's counter (byte 48 of the record) = value: what the
+// deferred one-launch iteration waits for
+constexpr int kPubCopies = 64;
+constexpr int kPubDoubles = 8 * kPubCopies;
+void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value);
+// one wave on `st` waits (bounded, ~2 ms) for the record to reach `want`; *err = 1 if it does not
+void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigned* err);
 
 }  // namespace prcg

@@ -802,17 +802,43 @@ __global__ __launch_bounds__(kFinalThreads) void k_gather_pack(
 
 // unpack: global sums = the ranks' partial sums added in rank order (the same bits on every
 // rank, whatever algorithm RCCL picked for the transport); ghost rows copied into place.
+// Publication for waves that WAIT inside a running launch (cdna_hip_programming.md Guideline 16, the
+// all-write-through form): payload and counter are stored with agent-scope atomic stores (sc1: they
+// leave the XCD's L2), the storing wave drains them before the counter goes out, and the readers
+// (k_win_tiles, deferred form) use agent-scope atomic loads for the counter AND the payload.
+// The record is REPLICATED kPubCopies times, one copy per 64-byte line: thousands of waves poll, and they
+// spread over the copies (one hot word would saturate its L2 channel and delay the very store they wait for).
+__device__ __forceinline__ void publish(double* pub, double v, int nvals, unsigned value) {
+    // called by ONE wave; lane q < nvals holds value q; lane c writes copy c
+    const int lane = threadIdx.x & 63;
+    double* mine = pub + (size_t)lane * 8;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double vq = __shfl(v, q, 64);
+        if (q < nvals) __hip_atomic_store(mine + q, vq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every lane's payload has left before its counter does
+    __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 6), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(kFinalThreads) void k_gather_unpack(
     const double* __restrict__ gbuf, int slot_doubles, int nranks, double* __restrict__ dots_out,
-    double2* __restrict__ rs_ghost, const int* __restrict__ ghost_src, int nghost)
+    double2* __restrict__ rs_ghost, const int* __restrict__ ghost_src, int nghost, double* pub, unsigned pub_value)
 {
+    double v = 0.0;
     if ((int)threadIdx.x < 5) {
-        double v = gbuf[threadIdx.x];
+        v = gbuf[threadIdx.x];
         for (int r = 1; r < nranks; ++r) v += gbuf[(size_t)r * slot_doubles + threadIdx.x];
         dots_out[threadIdx.x] = v;
     }
+    if (pub && threadIdx.x < 64) publish(pub, v, 5, pub_value);     // wave 0 publishes the sums first: somebody is waiting
     const double2* g2 = reinterpret_cast<const double2*>(gbuf);
     for (int j = threadIdx.x; j < nghost; j += kFinalThreads) rs_ghost[j] = g2[ghost_src[j]];
+}
+
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ dots, double* pub, unsigned value) {
+    const double v = threadIdx.x < 5 ? dots[threadIdx.x] : 0.0;
+    publish(pub, v, 5, value);
 }
 
 // ---- utilities -------------------------------------------------------------------------
@@ -940,7 +966,7 @@ int tile_grid(K kernel, int ntiles, int per_cu_override) {
 template <int NV, int EPI, int STEPS>
 int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x, void* y,
                  int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials,
-                 TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr})
+                 TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{})
 {
     const int cw = A.tile_base == nullptr ? 0 : (A.col8 ? 8 : (A.col16 ? 16 : 0));
     const bool vd = A.vidx8 != nullptr;   // value dictionary
@@ -960,7 +986,7 @@ int launch_tiles(hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles,
 template <int NV, int EPI>
 int launch_tiles_steps(int steps, hipStream_t st, const CsrDev& A, const Tile* tiles, int ntiles, const void* x,
                        void* y, int write_mask, const double* ep_r, const double* ep_d, double* ep_st,
-                       double* partials, TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr})
+                       double* partials, TileKnobs kn, double* aux = nullptr, FusedPrev fz = FusedPrev{})
 {
     switch (steps) {
     case 1: return launch_tiles<NV, EPI, 1>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, kn, aux, fz);
@@ -1133,9 +1159,27 @@ void launch_gather_pack(hipStream_t st, const double* partials, int nparts, doub
                        reinterpret_cast<const double2*>(rs), send_idx, nsend);
 }
 void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
-                          double* rs_ghost, const int* ghost_src, int nghost) {
+                          double* rs_ghost, const int* ghost_src, int nghost, double* pub, unsigned pub_value) {
     hipLaunchKernelGGL(k_gather_unpack, dim3(1), dim3(kFinalThreads), 0, st, gbuf, slot_doubles, nranks, dots_out,
-                       reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost);
+                       reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost, pub, pub_value);
+}
+// One wave that waits (bounded, ~2 ms) for copy 0 of a publication record to reach `want`: the probe
+// prcg_solve_begin uses to find out whether a kernel of the communication stream can run WHILE a kernel of
+// the compute stream waits for it (two HIP streams may share one hardware queue, which is in order).
+__global__ __launch_bounds__(64) void k_probe_wait(const double* pub, unsigned want, unsigned* err) {
+    const unsigned* cnt = reinterpret_cast<const unsigned*>(pub + 6);
+    unsigned spins = 0;
+    bool ok = false;
+    while (!(ok = (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) && ++spins < 4096u)
+        __builtin_amdgcn_s_sleep(16);
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigned* err) {
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, st, pub, want, err);
+}
+
+void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, dots, pub, value);
 }
 void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, int64_t count, int nc) {
     if (count <= 0) return;

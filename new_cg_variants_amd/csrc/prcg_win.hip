@@ -167,10 +167,12 @@ struct WCtx {
 
 // One tile: park its image (R, requested DEPTH tiles ago) in LDS, request tile `dnext` into the
 // freed registers, then lane i walks row i (and i + 64, ...).
-template <int NV, int EPI, int M, int PG, int CW, bool VD>
+// STASH: only the products -- the row sums go to `stash` (this wave's LDS, [M][64] pairs), the epilogue
+// follows later (deferred form of the one-launch iteration).
+template <int NV, int EPI, int M, int PG, int CW, bool VD, bool STASH = false>
 __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<NV, M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
-                                         double (&acc)[5], const Coefs& cf)
+                                         double (&acc)[5], const Coefs& cf, double2* stash = nullptr)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -243,7 +245,9 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
             for (int u = 0; u < kU; ++u)
                 if (j0 + u < len) vacc(sum, vmul(a[u], g[u]));
         }
-        if constexpr (FUSED) {
+        if constexpr (STASH) {
+            stash[j * 64 + lane] = sum;
+        } else if constexpr (FUSED) {
             // update k of the row while (A in)_i = sum is in registers; the row's own entry of the OLD input
             // pair array comes from the staged window, the new pair goes to the other array
             const double2 in_old = c.sw[active ? dcur.own + j * 64 + lane : 0];
@@ -271,7 +275,14 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
 // dictionary, WPB waves per workgroup (waves are independent: no workgroup barrier in the loop),
 // DEPTH register images = tiles in flight per wave (few resident waves, each with a deep queue of
 // coalesced loads, stream better than many shallow ones: profiles/r02_sweeps.md).
-template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH>
+// DEF > 0 (communicator sessions): the inner products that update k needs are still being reduced across
+// the ranks when this launch starts.  Each wave therefore computes the products of its first DEF tiles
+// (the part of the iteration that only needs the old vectors) with the sums parked in LDS, then waits
+// for the publication of the reduced inner products (FusedPrev::pub), then applies the DEF deferred
+// updates and carries on in the fused form -- the GPU counterpart of VecDotBegin ... KSP_MatMult ...
+// VecDotEnd (scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173) inside ONE launch.  The wait is
+// bounded; a timeout sets *err and lets the wave continue (wrong numbers, never a hang).
+template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH, int DEF = 0>
 __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     WinDev A, const int4* __restrict__ wt, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -283,6 +294,8 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     static_assert(!FUSED || NV == 2, "the fused iteration works on (r,s) pairs");
     static_assert(PG * 64 <= (CW == 8 ? 256 : 65536), "window index does not fit");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "one to three tiles in flight per wave");
+    static_assert(DEF == 0 || (FUSED && DEF % DEPTH == 0), "the deferred tiles are whole turns of the image ring");
+    __shared__ __attribute__((aligned(16))) double2 s_stash[WPB][DEF > 0 ? DEF * M * 64 : 1];
     __shared__ __attribute__((aligned(16))) double s_val[WPB][VD ? 2 : kWinSlots];
     __shared__ __attribute__((aligned(16))) unsigned char s_vi[WPB][VD ? kWinSlots : 16];
     __shared__ __attribute__((aligned(16))) unsigned char s_col[WPB][kWinSlots * (CW / 8)];
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
-    if constexpr (FUSED) {
+    if constexpr (FUSED && DEF == 0) {
         // inner products of the previous iteration: still one row of partials per block of the
         // previous launch -- every block of this launch sums them in the same fixed order
         // (thread t: rows t, t+B, ...; butterfly; waves in order), see prcg_kernels.hip
@@ -349,6 +362,84 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     }
     if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
 
+    if constexpr (DEF > 0) {
+        // ---- phase A: products of the first DEF tiles, sums parked in LDS ----
+        int n_def = 0;
+        int rbA[DEF], reA[DEF];            // rows of the deferred tiles (wave-uniform)
+#pragma unroll
+        for (int turn = 0; turn < DEF / DEPTH; ++turn) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                if (t < ntiles) {
+                    const WDesc<PG> dcur = d[i];
+                    const int tnext = t + DEPTH * W;
+                    const bool have_next = tnext < ntiles;
+                    d[i] = dn;
+                    rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re;
+                    win_step<NV, EPI, M, PG, CW, VD, true>(A, c, R[i], dcur, have_next, d[i], acc, cf,
+                                                           s_stash[wv] + (turn * DEPTH + i) * M * 64);
+                    if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
+                    t += W;
+                    ++n_def;
+                }
+            }
+        }
+        // ---- wait for the reduced inner products of the previous iteration ----
+        {
+            // this wave's copy of the record (the copies spread the pollers over the L2 channels)
+            const double* rec = fz.pub + (size_t)((blockIdx.x * WPB + wv) & (kPubCopies - 1)) * 8;
+            const unsigned* cnt = reinterpret_cast<const unsigned*>(rec + 6);
+            unsigned spins = 0;
+            bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // sticky: never wait twice
+            while (!timed_out && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fz.want) < 0) {
+                __builtin_amdgcn_s_sleep(32);                                 // ~1 us between polls
+                if (++spins > (1u << 23)) timed_out = true;                  // ~10 s: a stalled peer, not a slow one
+            }
+            if (timed_out && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double dp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dp[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cf = predict(dp, (write_mask >> 2) & 1);
+            if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+        }
+        // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
+        //      at once (one memory round trip per chunk, not per tile), then the chunk is updated ----
+        constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : DEF;
+#pragma unroll
+        for (int c0 = 0; c0 < DEF; c0 += CH) {
+            if (c0 < n_def) {                                              // wave-uniform
+                FusedRowIn q[CH][M];
+                double2 io[CH][M];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if (c0 + i < n_def) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            const int row = rbA[c0 + i] + j * 64 + lane;
+                            const int rr = row < reA[c0 + i] ? row : rbA[c0 + i];
+                            q[i][j].xp = c.fr.XP[rr];
+                            io[i][j] = c.X[rr];
+                            if constexpr (epi_prec(EPI)) { q[i][j].rs = c.fr.RS[rr]; q[i][j].d = c.fr.D[rr]; }
+                            if constexpr (!epi_recompute(EPI)) { q[i][j].w = c.fr.W[rr]; if constexpr (epi_prec(EPI)) q[i][j].wt = c.fr.WT[rr]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if (c0 + i < n_def) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            const int row = rbA[c0 + i] + j * 64 + lane;
+                            if (row < reA[c0 + i])
+                                fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, s_stash[wv][((c0 + i) * M + j) * 64 + lane],
+                                                                                    q[i][j], io[i][j], c.fr, cf, acc);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
     while (t < ntiles) {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) {
@@ -373,7 +464,8 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     }
 }
 
-constexpr int kWPB = 2;   // waves per workgroup
+constexpr int kWPB = 2;        // waves per workgroup
+constexpr int kWPBDefer = 4;   // ... of the deferred form: one wave on EACH SIMD of the CU, see defer_grid_per_cu
 
 // Workgroups per CU.  Upper bounds: what is truly co-resident (LDS is handed out per 80 KiB half of a
 // CU; the occupancy API knows the register limit) -- a persistent strided grid with queued workgroups
@@ -383,59 +475,90 @@ constexpr int kWPB = 2;   // waves per workgroup
 // 4.8 k it/s, 8 per CU 4.5 k, S2 5.2 k vs 3.8 k); the single-vector kernels with the dictionary stream
 // (50 bytes per row) keep gaining up to 16 waves.
 template <typename K>
-int win_grid(K kernel, int ntiles, int per_cu_override, int tuned) {
+int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
     int dev = 0, cus = 256, occ = 4;
     if (hipGetDevice(&dev) == hipSuccess) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64 * kWPB, 0) != hipSuccess || occ < 1) occ = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64 * wpb, 0) != hipSuccess || occ < 1) occ = 4;
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0) {
             const int by_lds = 2 * (int)((80 * 1024) / fa.sharedSizeBytes);
             if (by_lds >= 1 && by_lds < occ) occ = by_lds;
         }
-        if (occ > 32 / kWPB) occ = 32 / kWPB;
+        if (occ > 32 / wpb) occ = 32 / wpb;
         if (occ > tuned) occ = tuned;
     }
     if (per_cu_override >= 1 && per_cu_override <= 32) occ = per_cu_override;
-    int g = (ntiles + kWPB - 1) / kWPB;
+    int g = (ntiles + wpb - 1) / wpb;
     if (g > occ * cus) g = occ * cus;
     if (g < 1) g = 1;
     return g;
 }
 
-template <int NV, int EPI, int M, int PG, int CW>
+// The deferred form WAITS inside the launch for kernels of the communication stream (reduction, pack /
+// unpack, RCCL): those must be able to become resident on a chip whose every CU already holds our
+// persistent workgroups, or nobody ever publishes what the waves wait for.  Measured footprint of the
+// largest of them, rcclGenericKernel of RCCL 2.26 (rocprofv3 --kernel-trace): 256 threads = one wave per
+// SIMD, 132 VGPRs, 19,968 bytes of LDS.  With 4-wave workgroups every one of OUR workgroups also puts
+// exactly one wave on each SIMD, so b workgroups per CU leave 512 - b * vgprs registers on every SIMD;
+// LDS is handed out per 80 KiB half.  The bound below keeps room for one such workgroup on every CU
+// (2-wave workgroups do not: two of them can land on the same SIMD pair and fill its register file --
+// seen as a stalled reduction with the 250-register 128-row geometry).
+int defer_grid_per_cu(const void* kernel) {
+    constexpr int kGuestVgprs = 144, kGuestLds = 24 * 1024;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return 1;
+    const int vg = ((fa.numRegs + 7) / 8) * 8;
+    const int lds = (int)fa.sharedSizeBytes;
+    int best = 1;
+    for (int b = 2; b <= 4; ++b) {
+        const bool regs_ok = b * vg + kGuestVgprs <= 512;
+        const int lighter_half = b / 2;                          // workgroups in the emptier LDS half
+        const bool lds_ok = ((b + 1) / 2) * lds <= 80 * 1024 && lighter_half * lds + kGuestLds <= 80 * 1024;
+        if (regs_ok && lds_ok) best = b;
+    }
+    return best;
+}
+
+constexpr int kDeferTiles = 6;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
+
+template <int NV, int EPI, int M, int PG, int CW, bool DEFER = false>
 int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu)
 {
     const bool vd = A.vidx8 != nullptr;
-    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, kWPB, PRCG_WIN_DEPTH_DICT> : k_win_tiles<NV, EPI, M, PG, CW, false, kWPB, PRCG_WIN_DEPTH_PLAIN>;
+    constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 4) : 0;
+    constexpr int WPB = DEFER ? kWPBDefer : kWPB;
+    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, WPB, PRCG_WIN_DEPTH_DICT, DEF>
+                : k_win_tiles<NV, EPI, M, PG, CW, false, WPB, PRCG_WIN_DEPTH_PLAIN, DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
-    const int tuned = (NV == 1 && vd) ? 8 : 4;
-    if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned);
-    int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned) : cap;
-    const int need = (ntiles + kWPB - 1) / kWPB;
+    int tuned = (NV == 1 && vd) ? 8 : 4;
+    if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k));
+    if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
+    int grid = (per_cu >= 1 && !DEFER) ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
+    const int need = (ntiles + WPB - 1) / WPB;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * kWPB), 0, st, A, reinterpret_cast<const int4*>(tiles), ntiles, x, y,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, A, reinterpret_cast<const int4*>(tiles), ntiles, x, y,
                        write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
     return hipGetLastError() == hipSuccess ? grid : -1;
 }
 
-template <int NV, int EPI>
+template <int NV, int EPI, bool DEFER = false>
 int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y,
                int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux,
                FusedPrev fz, int per_cu)
 {
     switch (geom) {
-    case 0: return launch_win_g<NV, EPI, 1, 2, 8>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 1: return launch_win_g<NV, EPI, 1, 4, 8>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 2: return launch_win_g<NV, EPI, 2, 8, 16>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 3: return launch_win_g<NV, EPI, 2, 12, 16>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 0: return launch_win_g<NV, EPI, 1, 2, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 1: return launch_win_g<NV, EPI, 1, 4, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 2: return launch_win_g<NV, EPI, 2, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 3: return launch_win_g<NV, EPI, 2, 12, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
     default: return -1;
     }
 }
@@ -446,7 +569,7 @@ int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
                     SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu)
 {
     if (ntiles <= 0) return 0;
-    const FusedPrev none{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    const FusedPrev none{};
     switch (epi) {
     case kEpiNone: return launch_win<1, kEpiNone>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
     case kEpiDotXY: return launch_win<1, kEpiDotXY>(geom, st, A, tiles, ntiles, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
@@ -462,7 +585,7 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
 {
     if (ntiles <= 0) return 0;
     return launch_win<2, kEpiNone>(geom, st, A, tiles, ntiles, rs, wu, write_mask, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                   FusedPrev{nullptr, 0, nullptr, nullptr, nullptr, nullptr}, per_cu);
+                                   FusedPrev{}, per_cu);
 }
 
 int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
@@ -472,6 +595,20 @@ int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, i
     FusedPrev fz = f.prev;
     fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
     const int mask = 3 | (f.meurant ? 4 : 0);
+    if (f.deferred) {
+        if (f.dinv) {
+            if (f.recompute_w)
+                return launch_win<2, kEpiPipeFusedJ, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
+                                                           f.in_new, f.partials, f.coef_out, fz, per_cu);
+            return launch_win<2, kEpiPipeFusedPJ, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
+                                                        f.in_new, f.partials, f.coef_out, fz, per_cu);
+        }
+        if (f.recompute_w)
+            return launch_win<2, kEpiPipeFused, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
+                                                      f.in_new, f.partials, f.coef_out, fz, per_cu);
+        return launch_win<2, kEpiPipeFusedP, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
+                                                   f.in_new, f.partials, f.coef_out, fz, per_cu);
+    }
     if (f.dinv) {
         if (f.recompute_w)
             return launch_win<2, kEpiPipeFusedJ>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new,

@@ -158,7 +158,7 @@ class DeviceCSR:
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
                 'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
-                'window': bool(s & 4096)}
+                'window': bool(s & 4096), 'fused_comm': bool(s & 8192)}
 
     def set_iteration(self, k):
         self._check(self._lib.prcg_set_iteration(self._h, int(k)))

@@ -173,3 +173,97 @@ def test_merged_exchange_plan_moves_the_right_rows(workload, nranks):
     peers = np.ascontiguousarray(halo['peers'], dtype=np.int32)
     recv_ptr = np.ascontiguousarray(halo['recv_ptr'], dtype=np.int64)
     assert L.lib().prcg_plan_gather(0, T, L.ptr(broken), len(peers), L.ptr(peers), L.ptr(recv_ptr), slot, L.ptr(src)) == 1
+
+
+def plan_window(A_local, rows_per_tile, row_class=None):
+    A_local = A_local.tocsr()
+    n, n_cols = A_local.shape
+    indptr = np.ascontiguousarray(A_local.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A_local.indices, dtype=np.int32)
+    rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
+    cap = n + 8
+    tiles = np.zeros((cap, 20), dtype=np.int32)
+    cw = np.zeros(A_local.nnz + 1, dtype=np.uint16)
+    n0, most = C.c_int64(0), C.c_int(0)
+    got = L.lib().prcg_plan_window(n, n_cols, L.ptr(indptr), L.ptr(indices), L.ptr(rc), rows_per_tile, L.ptr(tiles), cap,
+                                   L.ptr(cw), C.byref(n0), C.byref(most))
+    return got, tiles[:max(got, 0)], cw[:A_local.nnz], int(n0.value), int(most.value)
+
+
+@pytest.mark.parametrize('name,rows,max_pages', [('band', 64, 2), ('band', 128, 3), ('lap2d', 64, 4), ('lap2d', 128, 9),
+                                                 ('lap3d', 128, 12), ('ragged', 64, 2), ('ghosts', 64, 4)])
+def test_window_tiling_covers_rows_columns_and_own_rows(name, rows, max_pages):
+    """Host planner of the row-per-lane kernels: every row in exactly one tile (classes apart, order kept),
+    every nonzero's column = first column of its page + offset, the tile's own rows contiguous in the
+    window (the fused epilogues read (r,s) of their row from it), pages inside the vector."""
+    import scipy.sparse as sp
+    from new_cg_variants_amd import partition
+    rng = np.random.default_rng(6)
+    row_class = None
+    if name == 'band':
+        A = problems.banded_ex2b(5000, 7)
+    elif name == 'lap2d':
+        A = problems.laplace_2d(90, 70)
+    elif name == 'lap3d':
+        A = problems.laplace_3d(24, 20, 16)
+    elif name == 'ragged':
+        n = 4000
+        lens = rng.integers(0, 15, size=n)
+        lens[100:300] = 0
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        r = np.repeat(np.arange(n), lens)
+        A = sp.csr_matrix((np.ones(indptr[-1]), (r + rng.integers(-8, 9, size=r.size)).clip(0, n - 1).astype(np.int32), indptr),
+                          shape=(n, n))
+    else:   # a middle row block of a band: ghost columns on both sides, two classes of rows
+        full = problems.banded_ex2b(6000, 7)
+        A, ghost_ids = partition.localize(full[2000:4000], 2000, 4000)
+        assert ghost_ids.size == 14
+        row_class = (np.diff(A.indptr) > 0) & np.array([(A.indices[A.indptr[i]:A.indptr[i + 1]] >= 2000).any() for i in range(2000)])
+    got, tiles, cw, n0, most = plan_window(A, rows, row_class)
+    assert got > 0 and most <= max_pages, (got, most)
+    n, n_cols = A.shape
+    seen = np.zeros(n, dtype=int)
+    for ti, t in enumerate(tiles):
+        rb, re, lo, hi, geo, maxlen = (int(v) for v in t[:6])
+        npages, own = geo & 255, geo >> 8
+        pages = t[8:8 + npages].astype(np.int64)
+        assert 0 < re - rb <= rows and hi - lo <= 1024 - 15 and (lo, hi) == (A.indptr[rb], A.indptr[re])
+        assert np.all(np.diff(pages) >= 64) and pages[0] >= 0 and pages[-1] + 64 <= n_cols + 64
+        seen[rb:re] += 1
+        if row_class is not None:
+            assert np.all(row_class[rb:re] == (ti >= n0))
+        assert maxlen == np.diff(A.indptr[rb:re + 1]).max()
+        c = cw[lo:hi].astype(np.int64)
+        assert np.all(c < npages * 64)
+        assert np.array_equal(pages[c >> 6] + (c & 63), A.indices[lo:hi])
+        i = np.arange(re - rb) + own                       # window index of the tile's own rows
+        assert np.array_equal(pages[i >> 6] + (i & 63), np.arange(rb, re))
+    assert np.all(seen == 1)
+    # interior tiles come first, each class in row order
+    for part in (tiles[:n0], tiles[n0:]):
+        assert np.all(np.diff(part[:, 0]) > 0)
+
+
+def test_window_tiling_refuses_wide_and_long_rows():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(7)
+    n = 3000
+    lens = rng.integers(1, 9, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    wide = sp.csr_matrix((np.ones(indptr[-1]), rng.integers(0, n, size=indptr[-1]).astype(np.int32), indptr), shape=(n, n))
+    assert plan_window(wide, 128)[0] == 0                      # random columns: far too many pages per tile
+    lens[7] = 1200
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    r = np.repeat(np.arange(n), lens)
+    long_row = sp.csr_matrix((np.ones(indptr[-1]), (r + rng.integers(-5, 6, size=r.size)).clip(0, n - 1).astype(np.int32), indptr),
+                             shape=(n, n))
+    assert plan_window(long_row, 64)[0] == 0                   # one row longer than a tile
+
+
+def test_operator_cache_fingerprint_sees_sum_preserving_edits():
+    import scipy.sparse as sp
+    from new_cg_variants_amd.cg_variants import _fingerprint
+    A = sp.random(2000, 2000, density=5e-3, format='csr', random_state=0)
+    f0 = _fingerprint(A)
+    A.data[3], A.data[7] = A.data[3] + 1.0, A.data[7] - 1.0
+    assert _fingerprint(A) != f0

@@ -95,11 +95,12 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
     n = A.shape[0]
     uid, path = rccl_ids(1)
     plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})     # same two-kernel schedule as with a communicator
-    comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
+    comm = DeviceCSR(A, comm_init=(0, 1, uid, path), knobs={'PRCG_FUSED_COMM': '0'})
     for variant in (L.PIPE_PR, L.HS, L.PR, L.CG_CG, L.GV, L.PIPE_P):
         outs = []
         for op in (plain, comm):
             op.begin(variant, z['b'], np.zeros(n), 400, x_true=z['x_true'], hist_mask=15)
+            assert not op.schedule()['fused']
             op.iterate(399)
             op.sync()
             outs.append((op.history(), op.get_vector('x')))
@@ -108,6 +109,52 @@ def test_single_rank_rccl_communicator_drives_full_schedule(matrices):
         assert np.array_equal(outs[0][1], outs[1][1])
     plain.close()
     comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,prec', [('s3_small', False), ('s3_small', True), ('s1_small', False)])
+def test_one_launch_schedule_with_a_communicator(workload, prec):
+    """With a communicator the pipelined variants of a window operator run ONE launch per iteration whose
+    waves wait inside the launch for the inner products that the communication stream reduces meanwhile
+    (pack -> ncclAllGather -> unpack + publish).  Driven here by a 1-rank communicator, with and without a
+    loopback halo (boundary tiles + ghost rows through the all-gather).  Same arithmetic per element as the
+    plain one-launch schedule; the inner products are summed in another order (per-launch partials reduced
+    by k_gather_pack instead of by the next launch's prologue), so histories agree to rounding on the
+    prefix and at convergence level beyond; no wave may have timed out."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    from oracle import ne_oracle as orc
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    inv_diag = (1 / A.diagonal()) if prec else None
+    A_loop, halo, moved = loopback_problem(A, 9 if workload == 's3_small' else 70)
+    uid, path = rccl_ids(1)
+    uid2, _ = rccl_ids(1)
+    plain = DeviceCSR(A)
+    comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid2, path), halo=halo)
+    for variant in (L.PIPE_PR, L.PIPE_P_M):
+        outs = []
+        for op in (plain, comm, loop):
+            op.begin(variant, b, x0, 300, x_true=x_true, inv_diag=inv_diag, hist_mask=15)
+            s = op.schedule()
+            assert s['fused'] and s['fused_comm'] == (op is not plain) and (op is plain or s['gather']), s
+            op.iterate(299)
+            op.sync()                                        # raises if a launch waited beyond its bound
+            outs.append((op.history(), op.get_vector('x')))
+        for other in outs[1:]:
+            for q in outs[0][0]:
+                np.testing.assert_allclose(other[0][q][:8], outs[0][0][q][:8], rtol=1e-11, atol=1e-13 * outs[0][0][q][0])
+            # beyond the prefix the kappa = 1e6 problems amplify the different summation order like any other
+            # (DESIGN.md section 2): the solves must still be the same solve at convergence level
+            # (the paper's two statistics, figure_gen.py:86-89; a converged run may end in 0/0 = nan, as in the reference)
+            ia, aa = orc.convergence_summary(other[0]['error_A_norm'])
+            ib, ab = orc.convergence_summary(outs[0][0]['error_A_norm'])
+            assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
+    for op in (plain, comm, loop):
+        op.close()
 
 
 def loopback_problem(A, k):
@@ -153,7 +200,7 @@ def test_halo_path_on_one_gpu_through_rccl_loopback(workload, k, n_ids, gather):
     b, x0, x_true = problems.reference_rhs(A, n)
     uid, path = rccl_ids(n_ids)      # 2 ids: halo exchange on its own communicator + stream
     plain = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
-    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo, knobs={'PRCG_GATHER': gather})
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid, path), halo=halo, knobs={'PRCG_GATHER': gather, 'PRCG_FUSED_COMM': '0'})
     x = np.random.default_rng(2).standard_normal(n)
     y0, _ = plain.matvec(x)
     y1, _ = loop.matvec(x)

@@ -6,9 +6,13 @@ Bars (stated here, used below):
     order, no FMA);
   * teacher-forced single iteration from every stored reference state: vectors and
     scalars <= 1e-12 relative (north_star's tolerance);
-  * free-running histories: <= 1e-12 on the prefix k<=8 (bcsstk03) / k<=15 (nos7);
-    beyond that any change of summation order diverges on these ill-conditioned
-    problems (SURVEY.md 7.2), so the rest is held to convergence-level agreement;
+  * free-running histories: <= 1e-12 on the prefix k<=5 (bcsstk03) / k<=11 (nos7) -- PREFIX below,
+    the same numbers as DESIGN.md section 2 and BASELINE.md section 2; the test prints the deviation
+    at the following iterations.  Beyond the prefix any change of summation order diverges on these
+    ill-conditioned problems: the rest is held to convergence-level agreement, ONE
+    rule: the paper's two statistics (figure_gen.py:86-89) must lie inside the spread the reference's
+    own algorithm shows when only the order of its summations changes, computed in the test with
+    six summation orders of oracle/ne_oracle.py (margins: 2 % of the iteration count, 0.5 decades);
   * against the oracle run with the device's own reduction order (tests/device_order.py):
     the whole free-running trajectory, <= 1e-13 on every recorded norm (normally
     bit-exact).
@@ -309,7 +313,19 @@ PUBLISHED = {
 # problems amplify ANY change of summation order (about 30x per iteration on bcsstk03):
 # measured on MI355X the recurrence residual leaves 1e-12 around k=8 (bcsstk03) / k=14 (nos7),
 # one or two iterations earlier or later depending on the reduction tree in use.
-PREFIX = {'bcsstk03': 6, 'nos7': 12}
+PREFIX = {'bcsstk03': 6, 'nos7': 12}      # history entries compared: k <= 5 / k <= 11
+
+
+def _interleaved(a, b):
+    return float(sum(np.dot(a[i::4], b[i::4]) for i in range(4)))
+
+
+# six orders of the SAME inner product (test infrastructure): the reference's BLAS ddot, NumPy's pairwise sum,
+# back to front, the device's reduction tree, four interleaved partial sums, the exactly rounded sum
+SUMMATION_ORDERS = [
+    ('blas', np.dot), ('pairwise', lambda a, b: float(np.sum(a * b))), ('reversed', lambda a, b: float(np.dot(a[::-1], b[::-1]))),
+    ('device', device_dot), ('interleaved', _interleaved), ('exact', lambda a, b: __import__('math').fsum(a * b)),
+]
 FREE = [r for r in all_runs() if r[1] in VARIANT_OF and not (r[0] == 'nos7' and r[1] in ('pr_pcg', 'pipe_p_cg', 'cg_cg', 'gv_cg'))]
 # (the four excluded nos7 runs are 1000-iteration stubs that never reach 1e-5; they serve the forced steps)
 
@@ -342,18 +358,29 @@ def test_free_running_against_reference(amd, matrices, matrix, method, prec):
                                        err_msg=f'{matrix}/{method}/{prec}/{q}')
     its, acc = orc.convergence_summary(out['error_A_norm'])
     ref_its, ref_acc = int(run['iters_to_1e-5']), float(run['log10_min_rel_error_A'])
-    # Two anchors: the reference re-run in the build container (fixture) and the value the
-    # reference publishes (figures/convergence_table_data.tex:5,26,38,52).  Spread of the
-    # statistic under a mere permutation of the summation order inside the reference's own
-    # loop (measured with oracle/, 8 orders): bcsstk03 pipe_pr 398..422 iterations (fixture
-    # 398 is the low end; published 411), hs 363..373; nos7 pipe_pr 2867..2930 and attained
-    # accuracy -7.0..-9.7 (fixture -9.66 is the outlier; published -7.24).
+    q = 'updated_residual_2_norm'
+    nxt = [float(abs(out[q][k] - run['hist_' + q][k]) / run['hist_' + q][k]) for k in range(prefix, min(prefix + 3, max_iter))]
+    # the spread of the same two statistics over re-orderings of the reference's own inner products
+    prec_fn = (lambda v: (1 / A.diagonal()) * v) if prec == 'jacobi' else None
+    sp_its, sp_acc = [], []
+    for name, dot in SUMMATION_ORDERS:
+        o = getattr(orc, method)(A, z['b'], np.zeros(A.shape[0]), max_iter, preconditioner=prec_fn, callbacks=['error_A_norm'],
+                                 x_true=z['x_true'], dot=dot)
+        i_, a_ = orc.convergence_summary(o['error_A_norm'])
+        if name == 'blas':
+            assert (i_, a_) == (ref_its, ref_acc), 'the oracle in the reference order must reproduce the fixture'
+        sp_its.append(i_)
+        sp_acc.append(a_)
+    never = [i for i in sp_its if i == 0]
     pub = PUBLISHED.get((matrix, prec, method))
-    its_anchors = [ref_its] + ([pub[0]] if pub else [])
-    acc_anchors = [ref_acc] + ([pub[1]] if pub else [])
-    assert any(abs(its - a) <= max(2, 0.08 * a) for a in its_anchors), (its, its_anchors)
-    assert min(acc_anchors) - 1.5 <= acc <= max(acc_anchors) + 1.5, (acc, acc_anchors)
-    print(f'{matrix}/{method}/{prec}: its {its} (ref {ref_its}), log10 min err {acc:.2f} (ref {ref_acc:.2f})')
+    print(f'{matrix}/{method}/{prec}: its {its} (fixture {ref_its}, spread {min(sp_its)}..{max(sp_its)}'
+          f'{", published " + str(pub[0]) if pub else ""}), log10 min err {acc:.2f} (fixture {ref_acc:.2f}, spread '
+          f'{min(sp_acc):.2f}..{max(sp_acc):.2f}); rel. deviation of |r_k| at k={prefix}..: ' + ' '.join(f'{v:.1e}' for v in nxt))
+    if never and len(never) < len(sp_its):
+        return      # "never reaches 1e-5" for some orders, reaches it for others: the statistic is undefined here
+    lo, hi = min(sp_its), max(sp_its)
+    assert lo - max(2, 0.02 * lo) <= its <= hi + max(2, 0.02 * hi), (its, sp_its)
+    assert min(sp_acc) - 0.5 <= acc <= max(sp_acc) + 0.5, (acc, sp_acc)
 
 
 @pytest.mark.parametrize('matrix,flavour,method,max_iter', [
