@@ -68,7 +68,8 @@ def measured_traffic(key):
     or None when the kernels have changed since they were collected."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-        return t['entries'].get(key) if t.get('kernel_sha') == kernel_source_sha() else None
+        e = t['entries'].get(key) if t.get('kernel_sha') == kernel_source_sha() else None
+        return e['bytes_per_launch'] if isinstance(e, dict) else e
     except Exception:
         return None
 
@@ -244,8 +245,11 @@ def main():
             dev3 = one_rank_comm_device()
             e3, q3, tim3, fin3 = timed_run(dev3)
             s3 = dev3.schedule()
-            multi = {'what': 'same workload and steps through the multi-rank schedule with a 1-rank RCCL communicator '
-                             '(update kernel + side-stream reduction/all-gather + SpMM per iteration)',
+            multi = {'what': 'same workload and steps through the schedule every rank of an N>1 run executes, driven by a 1-rank RCCL '
+                             'communicator: ' + ('one launch per iteration that waits in-kernel for the reduction the communication '
+                             'stream performs meanwhile (pack, ncclAllGather, unpack + publish)' if s3['fused_comm'] else
+                             'update kernel + SpMM per iteration, reduction and exchange on the communication stream'),
+                     'one_launch': s3['fused_comm'],
                      'value': K / e3, 'unit': 'iters/s', 'ms_per_step': e3 / K * 1e3, 'spmm_ms': tim3['spmv_ms'],
                      'update_ms': tim3['update_ms'], 'merged_allgather': s3['gather'], 'residual_finite': fin3,
                      'host_enqueue_us_per_step': q3 / K * 1e6}

@@ -88,6 +88,8 @@ struct prcg_handle {
     hipStream_t sm = nullptr;   // reductions + all-reduce
     hipStream_t sh = nullptr;   // halo exchange (own stream + own communicator: runs beside the all-reduce)
     hipEvent_t e_upd = nullptr, e_halo = nullptr, e_red = nullptr;
+    hipEvent_t e_kdone = nullptr;   // completion signal of a launch itself (hipExtLaunchKernel), see FusedState::done
+    hipEvent_t e_rdone = nullptr;   // ... of the unpack launch that ends the communication chain of an iteration
 
     // ---- communicator ----
     Rccl* rccl = nullptr;
@@ -115,6 +117,7 @@ struct prcg_handle {
     bool want_win = true;                // PRCG_WIN=0 turns them off
     int win_per_cu = 0;                  // PRCG_WIN_GRID_PER_CU
     int win_max_mean = 24;               // PRCG_WIN_MAX_MEAN: longest mean row the window form is tried for
+    int win_rows_override = 0;           // PRCG_WIN_ROWS = 64 | 128: rows per window tile (default: by mean row length)
     bool win = false;
     int win_geom = 0, win_rows = 0;
     bool win_vd = false;
@@ -159,8 +162,10 @@ struct prcg_handle {
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool fused_comm = false;     // ... with a communicator: the interior launch waits in-kernel for the reduction
     bool want_fused_comm = true; // PRCG_FUSED_COMM=0: communicator sessions keep the two-kernel schedule
+    bool ext_signal = true;      // PRCG_EXT_SIGNAL=0: separate hipEventRecord instead of the launch's own completion signal
     DevBuf pub, pub_err;         // publication record of the reduced inner products / timeout flag
-    bool red_pending = false;    // an e_red of the previous iteration is outstanding on the communication stream
+    bool red_pending = false;    // the communication chain of the previous iteration is outstanding ...
+    hipEvent_t red_event = nullptr;   // ... and this event marks its end
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
     bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
     int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
@@ -410,7 +415,7 @@ int record(prcg_t* h, int k) {
     const uint32_t m = h->hist_mask;
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
     if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
-    if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+    if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     const int64_t n = h->n;
     int rc;
     if (m & PRCG_HIST_RESIDUAL_2_NORM) {
@@ -641,22 +646,31 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
     if (getenv("PRCG_DEBUG_NOWAIT")) f.prev.want = 0u;     // timing experiment only: results are wrong
     f.deferred = 1;
+    // the last launch of the iteration on the compute stream signals the communication stream by itself
+    const bool ext_signal = h->ext_signal;
+    f.done = (ext_signal && h->nwt_bnd == 0) ? h->e_kdone : nullptr;
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int g1 = eng_fused(h, h->sc, f, 1);
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     int g2 = 0;
-    if (h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));   // dots[k-1] final, ghosts of (r,s)_{k-1} in place
+    // boundary tiles: dots[k-1] final, ghosts of (r,s)_{k-1} in place
+    if (h->red_pending && h->nwt_bnd > 0) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     if (h->nwt_bnd > 0) {
         f.deferred = 0;
         f.partials = part_out + (size_t)g1 * kPartialStride;
         f.coef_out = coef_at(h, k);
+        f.done = ext_signal ? h->e_kdone : nullptr;
         g2 = eng_fused(h, h->sc, f, 2);
         LAUNCHCHK(h, g2);
     }
-    HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
-    HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    if (ext_signal) {
+        HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_kdone, 0));
+    } else {
+        HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
+        HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
+    }
     const int nparts = g1 + g2;
     int rc;
     if (h->gather) {
@@ -665,14 +679,17 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
         launch_gather_pack(h->sm, part_out, nparts, slot, in_new, h->send_idx.i(), np > 0 ? (int)h->send_ptr[np] : 0);
         NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
         launch_gather_unpack(h->sm, h->gbuf.d(), h->g_slot, h->nranks, dots_at(h, k), in_new + 2 * h->n, h->ghost_src.i(),
-                             (int)h->g, h->pub.d(), (unsigned)k);
+                             (int)h->g, h->pub.d(), (unsigned)k, ext_signal ? h->e_rdone : nullptr);
+        if (!ext_signal) HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+        h->red_event = ext_signal ? h->e_rdone : h->e_red;
     } else {
         if (h->have_halo && h->n_peers > 0 && (rc = exchange(h, in_new, 2, h->sm))) return rc;
         launch_reduce_final(h->sm, part_out, nparts, dots_at(h, k), 0, 0, 5);
         if ((rc = allreduce(h, dots_at(h, k), 5, h->sm))) return rc;
         launch_publish(h->sm, dots_at(h, k), h->pub.d(), (unsigned)k);
+        HIPCHK(h, hipEventRecord(h->e_red, h->sm));
+        h->red_event = h->e_red;
     }
-    HIPCHK(h, hipEventRecord(h->e_red, h->sm));
     h->red_pending = true;
     h->rs_cur = in_new;
     return PRCG_OK;
@@ -838,14 +855,16 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_TILE_STEPS") h->steps_override = (v == 1 || v == 2 || v == 4) ? (int)v : 0;
     else if (k == "PRCG_WIN") h->want_win = v != 0;
     else if (k == "PRCG_FUSED_COMM") h->want_fused_comm = v != 0;
+    else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
     else if (k == "PRCG_WIN_MAX_MEAN") { if (v >= 1) h->win_max_mean = (int)v; }
+    else if (k == "PRCG_WIN_ROWS") h->win_rows_override = (v == 64 || v == 128) ? (int)v : 0;
     else return false;
     return true;
 }
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
-                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM"};
+                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -945,7 +964,8 @@ int prcg_create(prcg_t** out, int device_id) {
         hipStreamCreateWithPriority(&h->sh, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->e_red, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->e_red, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&h->e_kdone) != hipSuccess || hipEventCreate(&h->e_rdone) != hipSuccess) {
         prcg_destroy(h);
         return fail(nullptr, PRCG_EHIP, "prcg_create: stream/event creation failed");
     }
@@ -964,6 +984,8 @@ void prcg_destroy(prcg_t* h) {
     if (h->e_upd) (void)hipEventDestroy(h->e_upd);
     if (h->e_halo) (void)hipEventDestroy(h->e_halo);
     if (h->e_red) (void)hipEventDestroy(h->e_red);
+    if (h->e_kdone) (void)hipEventDestroy(h->e_kdone);
+    if (h->e_rdone) (void)hipEventDestroy(h->e_rdone);
     if (h->sc) (void)hipStreamDestroy(h->sc);
     if (h->sm) (void)hipStreamDestroy(h->sm);
     if (h->sh) (void)hipStreamDestroy(h->sh);
@@ -1061,7 +1083,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     std::vector<uint8_t> wvidx;
     std::vector<double> wvdict;
     if (h->want_win && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)h->win_max_mean * n_rows) {
-        const int rows = nnz < 10 * n_rows ? 128 : 64;
+        const int rows = h->win_rows_override ? h->win_rows_override : (nnz < 10 * n_rows ? 128 : 64);
         plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, rows, kWinCapNnz,
                           win_max_pages(rows), wp);
         const int most = wp.pages0 > wp.pages1 ? wp.pages0 : wp.pages1;
@@ -1587,7 +1609,7 @@ int prcg_iterate(prcg_t* h, int iters) {
     if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
     if (h->fused_comm && h->red_pending) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
-        HIPCHK(h, hipStreamWaitEvent(h->sc, h->e_red, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     }
     return PRCG_OK;
 }

@@ -43,6 +43,9 @@ struct FusedState {
     int meurant, recompute_w;
     FusedPrev prev;
     int deferred;     // 1: the launch waits in-kernel for prev.pub (communicator sessions, interior tiles)
+    hipEvent_t done;  // non-null: the launch's own completion signal is this event (hipExtLaunchKernel): the
+                      // communication stream waits for it, and NO marker packet sits between two launches
+                      // on the compute stream (a separate hipEventRecord cost ~15 us of idle queue per iteration)
 };
 
 // epilogues fused into the single-vector SpMV
@@ -235,7 +238,8 @@ void launch_pack(hipStream_t st, double* buf, const double* v, const int* idx, i
 void launch_gather_pack(hipStream_t st, const double* partials, int nparts, double* slot, const double* rs,
                         const int* send_idx, int nsend);
 void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
-                          double* rs_ghost, const int* ghost_src, int nghost, double* pub = nullptr, unsigned pub_value = 0);
+                          double* rs_ghost, const int* ghost_src, int nghost, double* pub = nullptr, unsigned pub_value = 0,
+                          hipEvent_t done = nullptr);
 // every copy c: pub[8c .. 8c+5) = dots[0..5), then the copy's counter (byte 48 of the record) = value: what the
 // deferred one-launch iteration waits for
 constexpr int kPubCopies = 64;

@@ -12,6 +12,7 @@
 // fixed reduction tree (thread-sequential -> wave xor-butterfly -> waves in order ->
 // blocks in order), deterministic run to run.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -1159,9 +1160,13 @@ void launch_gather_pack(hipStream_t st, const double* partials, int nparts, doub
                        reinterpret_cast<const double2*>(rs), send_idx, nsend);
 }
 void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
-                          double* rs_ghost, const int* ghost_src, int nghost, double* pub, unsigned pub_value) {
-    hipLaunchKernelGGL(k_gather_unpack, dim3(1), dim3(kFinalThreads), 0, st, gbuf, slot_doubles, nranks, dots_out,
-                       reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost, pub, pub_value);
+                          double* rs_ghost, const int* ghost_src, int nghost, double* pub, unsigned pub_value, hipEvent_t done) {
+    if (done)      // the launch's own completion signal (no marker packet behind it)
+        hipExtLaunchKernelGGL(k_gather_unpack, dim3(1), dim3(kFinalThreads), 0, st, nullptr, done, 0, gbuf, slot_doubles, nranks,
+                              dots_out, reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost, pub, pub_value);
+    else
+        hipLaunchKernelGGL(k_gather_unpack, dim3(1), dim3(kFinalThreads), 0, st, gbuf, slot_doubles, nranks, dots_out,
+                           reinterpret_cast<double2*>(rs_ghost), ghost_src, nghost, pub, pub_value);
 }
 // One wave that waits (bounded, ~2 ms) for copy 0 of a publication record to reach `want`: the probe
 // prcg_solve_begin uses to find out whether a kernel of the communication stream can run WHILE a kernel of

@@ -19,6 +19,7 @@
 // no dependent second round trip, which is what the latency-bound CSR-adaptive form suffered
 // from on narrow streams (profiles/r01_e_*: 70 % of wave cycles in s_waitcnt).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -525,7 +526,7 @@ constexpr int kDeferTiles = 6;     // 64-row tiles whose update waits for the re
 template <int NV, int EPI, int M, int PG, int CW, bool DEFER = false>
 int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
-                 int per_cu)
+                 int per_cu, hipEvent_t done = nullptr)
 {
     const bool vd = A.vidx8 != nullptr;
     constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 4) : 0;
@@ -544,21 +545,25 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     const int need = (ntiles + WPB - 1) / WPB;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, A, reinterpret_cast<const int4*>(tiles), ntiles, x, y,
-                       write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    if (done)
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, nullptr, done, 0, A, reinterpret_cast<const int4*>(tiles), ntiles,
+                              x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
+    else
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, A, reinterpret_cast<const int4*>(tiles), ntiles, x, y,
+                           write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
     return hipGetLastError() == hipSuccess ? grid : -1;
 }
 
 template <int NV, int EPI, bool DEFER = false>
 int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y,
                int write_mask, const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux,
-               FusedPrev fz, int per_cu)
+               FusedPrev fz, int per_cu, hipEvent_t done = nullptr)
 {
     switch (geom) {
-    case 0: return launch_win_g<NV, EPI, 1, 2, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 1: return launch_win_g<NV, EPI, 1, 4, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 2: return launch_win_g<NV, EPI, 2, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
-    case 3: return launch_win_g<NV, EPI, 2, 12, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu);
+    case 0: return launch_win_g<NV, EPI, 1, 2, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
+    case 1: return launch_win_g<NV, EPI, 1, 4, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
+    case 2: return launch_win_g<NV, EPI, 2, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
+    case 3: return launch_win_g<NV, EPI, 2, 12, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     default: return -1;
     }
 }
@@ -599,28 +604,28 @@ int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, i
         if (f.dinv) {
             if (f.recompute_w)
                 return launch_win<2, kEpiPipeFusedJ, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
-                                                           f.in_new, f.partials, f.coef_out, fz, per_cu);
+                                                           f.in_new, f.partials, f.coef_out, fz, per_cu, f.done);
             return launch_win<2, kEpiPipeFusedPJ, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
-                                                        f.in_new, f.partials, f.coef_out, fz, per_cu);
+                                                        f.in_new, f.partials, f.coef_out, fz, per_cu, f.done);
         }
         if (f.recompute_w)
             return launch_win<2, kEpiPipeFused, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
-                                                      f.in_new, f.partials, f.coef_out, fz, per_cu);
+                                                      f.in_new, f.partials, f.coef_out, fz, per_cu, f.done);
         return launch_win<2, kEpiPipeFusedP, true>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr,
-                                                   f.in_new, f.partials, f.coef_out, fz, per_cu);
+                                                   f.in_new, f.partials, f.coef_out, fz, per_cu, f.done);
     }
     if (f.dinv) {
         if (f.recompute_w)
             return launch_win<2, kEpiPipeFusedJ>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new,
-                                                 f.partials, f.coef_out, fz, per_cu);
+                                                 f.partials, f.coef_out, fz, per_cu, f.done);
         return launch_win<2, kEpiPipeFusedPJ>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new,
-                                              f.partials, f.coef_out, fz, per_cu);
+                                              f.partials, f.coef_out, fz, per_cu, f.done);
     }
     if (f.recompute_w)
         return launch_win<2, kEpiPipeFused>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new,
-                                            f.partials, f.coef_out, fz, per_cu);
+                                            f.partials, f.coef_out, fz, per_cu, f.done);
     return launch_win<2, kEpiPipeFusedP>(geom, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new,
-                                         f.partials, f.coef_out, fz, per_cu);
+                                         f.partials, f.coef_out, fz, per_cu, f.done);
 }
 
 }  // namespace prcg

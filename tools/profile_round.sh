@@ -4,7 +4,10 @@
 #   bench.json                 the default bench line (no profiler)
 #   bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats
 #   kernel_stats.csv           rocprofv3's per-kernel summary of that run
-#   pmc.json                   per-kernel counter means (tools/pmc.sh: one pass per counter group)
+#   pmc_dict.json / pmc_plain.json   per-kernel counter means (tools/pmc.sh: one pass per counter group), value
+#                              dictionary on (the default) and off (PRCG_VALDICT=0)
+#   traffic.json               HBM bytes per launch of the dominant kernel from those counters, stamped with the
+#                              kernel-source hash bench.py checks before quoting it
 tag=${1:-x}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_$tag
@@ -12,11 +15,14 @@ mkdir -p $out
 cd $root
 timeout -k 10 900 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --no-plain-values --no-multi-rank-leg > $out/bench_under_rocprof.json 2> $out/trace.err || exit 1
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err || exit 1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 rm -rf $out/trace
 cd $root
-./tools/pmc.sh $tag --workload s3 --steps 30 --warmup 5 > $out/pmc.log 2>&1
-cp gpurun_out/pmc_$tag.json $out/pmc.json
-rm -rf gpurun_out/pmc_$tag
-head -c 1500 $out/bench.json; echo; head -4 $out/kernel_stats.csv
+./tools/pmc.sh ${tag}_dict --workload s3 --steps 30 --warmup 5 > $out/pmc_dict.log 2>&1
+cp gpurun_out/pmc_${tag}_dict.json $out/pmc_dict.json
+PRCG_VALDICT=0 ./tools/pmc.sh ${tag}_plain --workload s3 --steps 30 --warmup 5 > $out/pmc_plain.log 2>&1
+cp gpurun_out/pmc_${tag}_plain.json $out/pmc_plain.json
+rm -rf gpurun_out/pmc_${tag}_dict gpurun_out/pmc_${tag}_plain
+python3 tools/make_traffic.py $out/pmc_dict.json $out/pmc_plain.json > $out/traffic.json
+head -c 1200 $out/bench.json; echo; head -5 $out/kernel_stats.csv; cat $out/traffic.json
