@@ -620,13 +620,15 @@ int iterate_pipe_fused(prcg_t* h, int k) {
 // One launch per iteration WITH a communicator (window operators): the GPU form of
 // VecDotBegin ... KSP_MatMult ... VecDotEnd (scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173).
 //
-//   compute stream : [interior tiles k: products of each wave's first tiles | wait pub >= k-1 | their updates |
-//                     remaining tiles fused] -wait Er(k-1)-> [boundary tiles k, fused] -E1(k)-> [interior tiles k+1 ...
-//   comm stream    : wait E1(k) -> [pack partials + rows] [ncclAllGather] [unpack: dots[k], ghosts of (r,s)_k,
-//                     publish k] -Er(k)->          (large halos: [send/recv] [reduce] [ncclAllReduce] [publish k])
+//   compute stream : [launch k: every wave: products of its first interior tiles | wait pub >= k-1 | their updates |
+//                     remaining tiles fused, the tiles that touch ghost rows last] [launch k+1 ...          (back to back)
+//   comm stream    : wait "launch k done" -> [pack partials + rows] [ncclAllGather] [unpack: dots[k], ghosts of
+//                     (r,s)_k into place, release, publish k]
 //
-// The reduction of iteration k-1 runs while the interior launch of iteration k computes A [r s] -- the
-// overlap the two-kernel schedule has, without storing (w,u) and without a separate update launch.
+// The reduction AND the halo of iteration k travel while launch k+1 computes A [r s] on interior rows -- the overlap
+// the two-kernel schedule has, without storing (w,u), without a separate update launch, without a second launch for
+// the boundary rows and without any wait of the compute stream on the communication stream: the only
+// synchronisation the compute stream sees is inside the kernel.
 int iterate_pipe_fused_comm(prcg_t* h, int k) {
     double* const bufA = h->prec ? h->rst.d() : h->rs.d();
     double* const bufB = h->prec ? h->rst2.d() : h->rs2.d();
@@ -646,25 +648,18 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
     if (getenv("PRCG_DEBUG_NOWAIT")) f.prev.want = 0u;     // timing experiment only: results are wrong
     f.deferred = 1;
-    // the last launch of the iteration on the compute stream signals the communication stream by itself
+    f.prev.nt_int = h->nwt_int;
+    // ONE launch over all tiles: the boundary tiles come last in the table and are touched only after the wave has
+    // seen the publication (which the ghost rows precede).  The launch signals the communication stream with its own
+    // completion (no marker packet on the compute stream: the next iteration's launch follows directly).
     const bool ext_signal = h->ext_signal;
-    f.done = (ext_signal && h->nwt_bnd == 0) ? h->e_kdone : nullptr;
+    f.done = ext_signal ? h->e_kdone : nullptr;
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
-    const int g1 = eng_fused(h, h->sc, f, 1);
+    const int g1 = eng_fused(h, h->sc, f, 0);
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
-    int g2 = 0;
-    // boundary tiles: dots[k-1] final, ghosts of (r,s)_{k-1} in place
-    if (h->red_pending && h->nwt_bnd > 0) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
-    if (h->nwt_bnd > 0) {
-        f.deferred = 0;
-        f.partials = part_out + (size_t)g1 * kPartialStride;
-        f.coef_out = coef_at(h, k);
-        f.done = ext_signal ? h->e_kdone : nullptr;
-        g2 = eng_fused(h, h->sc, f, 2);
-        LAUNCHCHK(h, g2);
-    }
+    const int g2 = 0;
     if (ext_signal) {
         HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_kdone, 0));
     } else {

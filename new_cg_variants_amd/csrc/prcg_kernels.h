@@ -30,6 +30,8 @@ struct FusedPrev {
     // bytes, each 5 doubles + a 32-bit iteration counter at byte 48, all stored write-through).  Each wave first computes the products of
     // its first tiles, then waits for pub's counter to reach `want`, then applies the deferred updates.
     const double* pub; unsigned want; unsigned* err;
+    int nt_int;       // tiles [nt_int, ntiles) touch ghost columns: they are neither computed nor even requested before
+                      // the publication has arrived (the ghost rows travel with it)
 };
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
 // the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row

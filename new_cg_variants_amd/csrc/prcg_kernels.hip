@@ -832,9 +832,20 @@ __global__ __launch_bounds__(kFinalThreads) void k_gather_unpack(
         for (int r = 1; r < nranks; ++r) v += gbuf[(size_t)r * slot_doubles + threadIdx.x];
         dots_out[threadIdx.x] = v;
     }
-    if (pub && threadIdx.x < 64) publish(pub, v, 5, pub_value);     // wave 0 publishes the sums first: somebody is waiting
     const double2* g2 = reinterpret_cast<const double2*>(gbuf);
     for (int j = threadIdx.x; j < nghost; j += kFinalThreads) rs_ghost[j] = g2[ghost_src[j]];
+    if (pub) {
+        // the ghost rows are part of what the waiting launch reads after the publication (its boundary tiles):
+        // plain stores of every wave drained -> barrier -> agent-scope release -> publication
+        // (cdna_hip_programming.md Guideline 16: producer side of the release / acquire form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish(pub, v, 5, pub_value);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_publish(const double* __restrict__ dots, double* pub, unsigned value) {

@@ -173,7 +173,8 @@ struct WCtx {
 template <int NV, int EPI, int M, int PG, int CW, bool VD, bool STASH = false>
 __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<NV, M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
-                                         double (&acc)[5], const Coefs& cf, double2* stash = nullptr)
+                                         double (&acc)[5], const Coefs& cf, double2* stash = nullptr,
+                                         bool acquire_first = false)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -216,8 +217,11 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     wave_lds_sync();
 
     // ---- request the tile DEPTH ahead (the image registers are free again) ----
-    if (have_next)
+    if (have_next) {
+        // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
+        if (acquire_first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.fr, R);
+    }
 
     // ---- lane i walks row i (and i + 64, ...) ----
     const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
@@ -353,12 +357,19 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
     WRegs<NV, M, PG, CW, VD> R[DEPTH];
     WDesc<PG> d[DEPTH], dn = {};
+    // deferred form: tiles from `safe` on read ghost rows that arrive with the publication -- their loads are
+    // postponed (pend) until the wave has seen it
+    const int safe = DEF > 0 ? (fz.nt_int < ntiles ? fz.nt_int : ntiles) : ntiles;
+    bool pend[DEPTH];
+    bool acquired = false;
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
         d[i] = WDesc<PG>{};
+        pend[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
+            else pend[i] = true;
         }
     }
     if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
@@ -371,11 +382,12 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         for (int turn = 0; turn < DEF / DEPTH; ++turn) {
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) {
-                if (t < ntiles) {
+                if (t < safe && n_def == turn * DEPTH + i) {            // (stops for good at the first tile that must wait)
                     const WDesc<PG> dcur = d[i];
                     const int tnext = t + DEPTH * W;
-                    const bool have_next = tnext < ntiles;
+                    const bool have_next = tnext < safe;
                     d[i] = dn;
+                    pend[i] = tnext < ntiles && !have_next;
                     rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re;
                     win_step<NV, EPI, M, PG, CW, VD, true>(A, c, R[i], dcur, have_next, d[i], acc, cf,
                                                            s_stash[wv] + (turn * DEPTH + i) * M * 64);
@@ -403,6 +415,25 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             cf = predict(dp, (write_mask >> 2) & 1);
             if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
         }
+        // the ring continues with image (n_def mod DEPTH): bring that image to position 0
+        if constexpr (DEPTH == 2) {
+            if (n_def & 1) {
+                const WRegs<NV, M, PG, CW, VD> r0 = R[0]; R[0] = R[1]; R[1] = r0;
+                const WDesc<PG> d0 = d[0]; d[0] = d[1]; d[1] = d0;
+                const bool p0 = pend[0]; pend[0] = pend[1]; pend[1] = p0;
+            }
+        }
+        static_assert(DEPTH <= 2, "ring rotation after the deferred phase is written for one or two images");
+        // the postponed requests.  Consumer side of the release / acquire hand-off, paid only by the waves that read
+        // ghost rows (an agent-scope acquire invalidates the CU's L1: ~1.7 us each, serialised per CU): what the wave
+        // loads from here on is what the publisher wrote before publishing
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (pend[i]) {
+                if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
+                pend[i] = false;
+            }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
         //      at once (one memory round trip per chunk, not per tile), then the chunk is updated ----
         constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : DEF;
@@ -449,7 +480,9 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                 const int tnext = t + DEPTH * W;
                 const bool have_next = tnext < ntiles;
                 d[i] = dn;
-                win_step<NV, EPI, M, PG, CW, VD>(A, c, R[i], dcur, have_next, d[i], acc, cf);
+                const bool acq = DEF > 0 && have_next && tnext >= safe && !acquired;
+                win_step<NV, EPI, M, PG, CW, VD>(A, c, R[i], dcur, have_next, d[i], acc, cf, nullptr, acq);
+                if (acq) acquired = true;
                 // descriptor of the tile after that one: loaded now, looked at one step later
                 if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
                 t += W;
