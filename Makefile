@@ -7,9 +7,11 @@ OUT := new_cg_variants_amd/libprcg.so
 # -ffp-contract=off: the reference's arithmetic is "multiply, round, add, round"
 # (NumPy ufuncs, scipy csr_matvec); an FMA would change the bits.
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
+# TEST INFRASTRUCTURE: a stand-in for librccl.so that connects ranks living in threads of one process on one GPU
+TRANSPORT := tests/transport/libthreads_ccl.so
 OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
 
-all: $(OUT)
+all: $(OUT) $(TRANSPORT)
 
 $(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
@@ -29,7 +31,10 @@ $(CSRC)/prcg_rccl.o: $(CSRC)/prcg_rccl.cpp $(CSRC)/prcg_rccl.h
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
+$(TRANSPORT): tests/transport/threads_ccl.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared $< -o $@
+
 clean:
-	rm -f $(OBJS) $(OUT)
+	rm -f $(OBJS) $(OUT) $(TRANSPORT)
 
 .PHONY: all clean

@@ -163,6 +163,8 @@ struct prcg_handle {
     bool fused_comm = false;     // ... with a communicator: the interior launch waits in-kernel for the reduction
     bool want_fused_comm = true; // PRCG_FUSED_COMM=0: communicator sessions keep the two-kernel schedule
     bool ext_signal = true;      // PRCG_EXT_SIGNAL=0: separate hipEventRecord instead of the launch's own completion signal
+    int defer_per_cu = 0;        // PRCG_DEFER_GRID_PER_CU: workgroups per CU of the deferred launch (several ranks sharing one
+                                 // GPU in the tests must all be resident at once: 1)
     DevBuf pub, pub_err;         // publication record of the reduced inner products / timeout flag
     bool red_pending = false;    // the communication chain of the previous iteration is outstanding ...
     hipEvent_t red_event = nullptr;   // ... and this event marks its end
@@ -291,7 +293,8 @@ int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f, int which = 0) {
     if (h->win) {
         const int first = which == 2 ? h->nwt_int : 0;
         const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
-        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, f, h->win_per_cu);
+        return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, f,
+                                     f.deferred ? h->defer_per_cu : h->win_per_cu);
     }
     return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, f, h->kn);
 }
@@ -851,6 +854,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN") h->want_win = v != 0;
     else if (k == "PRCG_FUSED_COMM") h->want_fused_comm = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
+    else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
     else if (k == "PRCG_WIN_MAX_MEAN") { if (v >= 1) h->win_max_mean = (int)v; }
     else if (k == "PRCG_WIN_ROWS") h->win_rows_override = (v == 64 || v == 128) ? (int)v : 0;
@@ -859,7 +863,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 }
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
-                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL"};
+                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));

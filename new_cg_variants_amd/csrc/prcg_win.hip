@@ -574,7 +574,7 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     int tuned = (NV == 1 && vd) ? 8 : 4;
     if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k));
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
-    int grid = (per_cu >= 1 && !DEFER) ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
+    int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
     const int need = (ntiles + WPB - 1) / WPB;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;

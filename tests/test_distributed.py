@@ -253,3 +253,120 @@ def test_two_ranks_through_rccl_when_the_box_allows_it(tmp_path):
     for r in range(2):
         res = np.load(tmp_path / f'result_gpu_{r}.npy', allow_pickle=True).item()
         assert set(res) == {'pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'} and all(v <= 1e-11 for v in res.values()), res
+
+
+# ---------------------------------------------------------------------------------------
+# N > 1 ranks on ONE GPU: ranks in threads, connected by tests/transport/libthreads_ccl.so (a stand-in
+# for librccl.so that moves the collectives' bytes with device-to-device copies; RCCL itself refuses two
+# ranks on one device).  Real inter-rank data: what rank r reads in its ghost rows was computed by the
+# kernels of rank r +- 1.
+# ---------------------------------------------------------------------------------------
+def run_ranks_in_threads(A, nranks, variant, iters, knobs=None, inv_diag=None, hist_mask=15, offsets=None):
+    """Solve with `nranks` row blocks, one thread per rank, all on cuda:0.  Returns (x, histories of rank 0, schedules)."""
+    import threading
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems
+    from new_cg_variants_amd.device import DeviceCSR
+    path = os.path.join(ROOT, 'tests', 'transport', 'libthreads_ccl.so')
+    assert os.path.exists(path), 'build it with `make` (tests/transport/threads_ccl.hip)'
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    offsets, parts = partition.split_serial(A, nranks, offsets)
+    uid = np.zeros(128, dtype=np.uint8)
+    L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid)))
+    out = [None] * nranks
+    errs = []
+
+    def rank_main(r):
+        try:
+            A_local, ghost_ids, halo = parts[r]
+            lo, hi = int(offsets[r]), int(offsets[r + 1])
+            op = DeviceCSR(A_local, comm_init=(r, nranks, uid.tobytes(), path), halo=halo, knobs=knobs)
+            y = op.matvec(x_true[lo:hi] * (1.0 + np.arange(lo, hi)))[0]
+            op.begin(variant, b[lo:hi], x0[lo:hi], iters + 1, x_true=x_true[lo:hi],
+                     inv_diag=None if inv_diag is None else inv_diag[lo:hi], hist_mask=hist_mask)
+            sched = op.schedule()
+            op.iterate(iters)
+            op.sync()
+            out[r] = (op.get_vector('x'), op.history(), sched, y)
+            op.close()
+        except Exception as exc:           # noqa: BLE001 -- reported by the caller
+            errs.append((r, repr(exc)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errs, errs
+    assert all(o is not None for o in out), 'a rank did not finish'
+    x = np.concatenate([o[0] for o in out])
+    y = np.concatenate([o[3] for o in out])
+    assert np.array_equal(y, A @ (x_true * (1.0 + np.arange(n)))), 'distributed SpMV differs from the global product'
+    return x, out[0][1], [o[2] for o in out]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,nranks,variant', [
+    ('s3_small', 2, 'PIPE_PR'), ('s3_small', 4, 'PIPE_PR'), ('s3_small', 3, 'PIPE_P_M'), ('s1_small', 2, 'PIPE_PR'),
+    ('s3_small', 2, 'HS'), ('s1_small', 3, 'PR'), ('s3_small', 2, 'CG_CG'), ('s1_small', 2, 'GV')])
+def test_ranks_in_threads_two_kernel_schedule(workload, nranks, variant):
+    """2-4 ranks with real halos, two-kernel schedule (merged all-gather for the band's 7-row halo, send/recv +
+    all-reduce for the stencil's grid-line halo), all variant families.  The distributed SpMV is the global
+    one bit for bit; the pipelined variants' inner products come from the update kernel, whose per-rank sums
+    are added in rank order, so the whole solve agrees with the single-GPU two-kernel solve to rounding on the
+    prefix and at convergence level beyond."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    from oracle import ne_oracle as orc
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    iters = 120
+    x, hist, scheds = run_ranks_in_threads(A, nranks, getattr(L, variant), iters, knobs={'PRCG_FUSED_COMM': '0'})
+    assert all(s['comm'] and not s['fused'] for s in scheds), scheds
+    one = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
+    one.begin(getattr(L, variant), b, x0, iters + 1, x_true=x_true, hist_mask=15)
+    one.iterate(iters)
+    one.sync()
+    ref_hist, ref_x = one.history(), one.get_vector('x')
+    one.close()
+    for q in ref_hist:
+        np.testing.assert_allclose(hist[q][:8], ref_hist[q][:8], rtol=1e-11, atol=1e-13 * ref_hist[q][0], err_msg=q)
+    ia, aa = orc.convergence_summary(hist['error_A_norm'])
+    ib, ab = orc.convergence_summary(ref_hist['error_A_norm'])
+    assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,nranks,variant,prec', [
+    ('s3_small', 2, 'PIPE_PR', False), ('s3_small', 3, 'PIPE_PR', True), ('s3_small', 2, 'PIPE_P', False)])
+def test_ranks_in_threads_one_launch_schedule(workload, nranks, variant, prec):
+    """The one-launch schedule with REAL peers: every rank's launch k+1 waits inside the kernel for a publication
+    that needs the other ranks' launch k (pack -> all-gather -> unpack), and its boundary tiles read ghost rows the
+    neighbours' kernels wrote.  The ranks share one GPU here, so each launches one workgroup per CU
+    (PRCG_DEFER_GRID_PER_CU=1: all of them must be resident at once); no wave may time out."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    from oracle import ne_oracle as orc
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    inv_diag = (1 / A.diagonal()) if prec else None
+    iters = 200
+    x, hist, scheds = run_ranks_in_threads(A, nranks, getattr(L, variant), iters, knobs={'PRCG_DEFER_GRID_PER_CU': '1'},
+                                           inv_diag=inv_diag)
+    assert all(s['fused_comm'] and s['gather'] for s in scheds), scheds
+    one = DeviceCSR(A)
+    one.begin(getattr(L, variant), b, x0, iters + 1, x_true=x_true, inv_diag=inv_diag, hist_mask=15)
+    one.iterate(iters)
+    one.sync()
+    ref_hist = one.history()
+    one.close()
+    for q in ref_hist:
+        np.testing.assert_allclose(hist[q][:8], ref_hist[q][:8], rtol=1e-11, atol=1e-13 * ref_hist[q][0], err_msg=q)
+    ia, aa = orc.convergence_summary(hist['error_A_norm'])
+    ib, ab = orc.convergence_summary(ref_hist['error_A_norm'])
+    assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
