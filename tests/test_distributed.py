@@ -370,3 +370,28 @@ def test_ranks_in_threads_one_launch_schedule(workload, nranks, variant, prec):
     ia, aa = orc.convergence_summary(hist['error_A_norm'])
     ib, ab = orc.convergence_summary(ref_hist['error_A_norm'])
     assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
+
+
+@pytest.mark.gpu
+def test_s3_full_size_row_blocks_in_threads():
+    """north_star's multi-GPU workload (S3, n = 1e7, ~150 M nonzeros) cut into row blocks whose ranks run in threads
+    on ONE GPU: 8 blocks through the two-kernel schedule, 2 blocks through the one-launch schedule (more would not
+    all be resident on one GPU).  Residual histories against the single-GPU run."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.WORKLOADS['s3']['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    iters = 30
+    one = DeviceCSR(A)
+    one.begin(L.PIPE_PR, b, x0, iters + 1, hist_mask=1)
+    one.iterate(iters)
+    one.sync()
+    ref = one.history()['updated_residual_2_norm']
+    one.close()
+    for nranks, knobs, flag in ((8, {'PRCG_FUSED_COMM': '0'}, False), (2, {'PRCG_DEFER_GRID_PER_CU': '1'}, True)):
+        x, hist, scheds = run_ranks_in_threads(A, nranks, L.PIPE_PR, iters, knobs=knobs, hist_mask=1)
+        assert all(s['fused_comm'] == flag and s['gather'] and s['window'] for s in scheds), scheds
+        np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
+        np.testing.assert_allclose(hist['updated_residual_2_norm'], ref, rtol=1e-4)
