@@ -1462,18 +1462,24 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         LAUNCHCHK(h, grid);
         if (!h->fused_final) launch_reduce_final(sc, h->partA.d(), grid, dots_at(h, 0), 0, 0, 5);
         if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
-        if (h->fused_comm) {
-            // Can a kernel of the communication stream run while a kernel of the compute stream waits for it?  (HIP
-            // may have mapped both streams to one hardware queue -- then the deferred form would only ever time
-            // out.)  Probe once per session: a one-wave kernel on sc waits ~2 ms at most for a record that a kernel
-            // on sm publishes.
+        if (h->gather) {
+            // COLLECTIVE part, the same on every rank of a merged-exchange session whatever schedule the rank itself
+            // ends up with (a rank's block may be no window operator, or its probe below may fail: the ranks then
+            // still issue the same collectives in the same order -- one all-gather per iteration either way):
+            // the first use of the communicator from the communication stream happens HERE, not inside a launch that
+            // waits for it, and the ghosts of the initial input pairs are in place for the first boundary tiles.
             HIPCHK(h, hipStreamSynchronize(sc));
-            // first use of the communicator from the communication stream happens HERE, not inside a launch that waits
-            {
-                double* slot = h->gbuf.d() + (size_t)h->rank * h->g_slot;
-                NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
-                HIPCHK(h, hipStreamSynchronize(h->sm));
-            }
+            double* slot = h->gbuf.d() + (size_t)h->rank * h->g_slot;
+            NCCLCHK(h, h->rccl->AllGather(slot, h->gbuf.p, (size_t)h->g_slot, ncclDouble, h->comm, h->sm));
+            HIPCHK(h, hipStreamSynchronize(h->sm));
+            if ((rc = exchange(h, h->rs_cur, 2, sc))) return rc;
+        }
+        if (h->fused_comm) {
+            // LOCAL part.  Can a kernel of the communication stream run while a kernel of the compute stream waits for
+            // it?  (HIP may have mapped both streams to one hardware queue -- then the deferred form would only ever
+            // time out.)  Probe once per session: a one-wave kernel on sc waits ~2 ms at most for a record that a
+            // kernel on sm publishes.
+            HIPCHK(h, hipStreamSynchronize(sc));
             launch_probe_wait(sc, h->pub.d(), 0x7f000000u, static_cast<unsigned*>(h->pub_err.p));
             launch_publish(h->sm, dots_at(h, 0), h->pub.d(), 0x7f000000u);
             HIPCHK(h, hipStreamSynchronize(h->sm));
@@ -1483,11 +1489,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             HIPCHK(h, hipMemset(h->pub_err.p, 0, sizeof perr));
             if (perr) { h->fused_comm = false; h->fused = false; }       // streams are serialised here: two-kernel schedule
         }
-        if (h->fused_comm) {
-            // iteration 1 waits for "0": the initial inner products; ghosts of the initial (r,s) for its boundary tiles
-            launch_publish(sc, dots_at(h, 0), h->pub.d(), 0u);
-            if ((rc = exchange(h, h->rs_cur, 2, sc))) return rc;
-        }
+        if (h->fused_comm) launch_publish(sc, dots_at(h, 0), h->pub.d(), 0u);   // iteration 1 waits for "0": the initial inner products
     } else if (is_cg_family(variant)) {
         // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
@@ -1645,13 +1647,13 @@ int prcg_set_iteration(prcg_t* h, int k) {
     CHECK(h, h->in_session, "prcg_set_iteration: no open session");
     CHECK(h, k >= 0 && k < h->max_iter, "prcg_set_iteration: k out of range");
     h->k = k;
-    if (h->fused_comm) {
+    if (h->gather && is_pipe(h->variant)) {
         // teacher forcing: what the deferred launch of iteration k+1 waits for and what its boundary tiles read
-        // must describe the state just loaded
+        // must describe the state just loaded (the exchange is collective over the session's ranks)
         int rc = prcg_sync(h);
         if (rc) return rc;
-        launch_publish(h->sc, dots_at(h, k), h->pub.d(), (unsigned)k);
-        if ((rc = exchange(h, h->rs_cur, 2, h->sc))) return rc;
+        if (h->fused_comm) launch_publish(h->sc, dots_at(h, k), h->pub.d(), (unsigned)k);
+        if ((rc = exchange(h, h->fused ? h->rs_cur : (h->prec ? h->rst.d() : h->rs.d()), 2, h->sc))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->sc));
         h->red_pending = false;
     }

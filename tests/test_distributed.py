@@ -281,7 +281,8 @@ def run_ranks_in_threads(A, nranks, variant, iters, knobs=None, inv_diag=None, h
         try:
             A_local, ghost_ids, halo = parts[r]
             lo, hi = int(offsets[r]), int(offsets[r + 1])
-            op = DeviceCSR(A_local, comm_init=(r, nranks, uid.tobytes(), path), halo=halo, knobs=knobs)
+            op = DeviceCSR(A_local, comm_init=(r, nranks, uid.tobytes(), path), halo=halo,
+                           knobs=knobs[r] if isinstance(knobs, list) else knobs)
             y = op.matvec(x_true[lo:hi] * (1.0 + np.arange(lo, hi)))[0]
             op.begin(variant, b[lo:hi], x0[lo:hi], iters + 1, x_true=x_true[lo:hi],
                      inv_diag=None if inv_diag is None else inv_diag[lo:hi], hist_mask=hist_mask)
@@ -395,3 +396,29 @@ def test_s3_full_size_row_blocks_in_threads():
         assert all(s['fused_comm'] == flag and s['gather'] and s['window'] for s in scheds), scheds
         np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
         np.testing.assert_allclose(hist['updated_residual_2_norm'], ref, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_ranks_in_threads_may_run_different_schedules():
+    """A rank whose block is no window operator, or whose stream-concurrency probe fails, keeps the two-kernel schedule
+    while its peers run one launch per iteration: both issue ONE all-gather per iteration carrying the same things
+    (partial inner products of iteration k, rows of (r,s)_k), so a mixed session is the same solve."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.WORKLOADS['s3_small']['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    iters = 150
+    knobs = [{'PRCG_DEFER_GRID_PER_CU': '1'}, {'PRCG_FUSED_COMM': '0'}, {'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_WIN': '0'}]
+    x, hist, scheds = run_ranks_in_threads(A, 3, L.PIPE_PR, iters, knobs=knobs)
+    assert [s['fused_comm'] for s in scheds] == [True, False, False] and all(s['gather'] for s in scheds), scheds
+    one = DeviceCSR(A)
+    one.begin(L.PIPE_PR, b, x0, iters + 1, x_true=x_true, hist_mask=15)
+    one.iterate(iters)
+    one.sync()
+    ref_hist = one.history()
+    one.close()
+    for q in ref_hist:
+        np.testing.assert_allclose(hist[q][:8], ref_hist[q][:8], rtol=1e-11, atol=1e-13 * ref_hist[q][0], err_msg=q)
+    np.testing.assert_allclose(hist['error_A_norm'][-1], ref_hist['error_A_norm'][-1], rtol=0.5)
