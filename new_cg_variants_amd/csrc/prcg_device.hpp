@@ -135,6 +135,38 @@ __device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], doub
     if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch (kernel boundary orders it)
 }
 
+// Every block of a launch sums the block partials the PREVIOUS launch left (slots slot0 .. slot0 + NQ) itself:
+// thread t rows t, t + T, ...; butterfly; waves in order -- the same order in every block, so all blocks hold the
+// same bits and no reduction launch sits between the two (the kernel boundary orders the partials).
+template <int NQ, int NWAVES>
+__device__ __forceinline__ void sum_prev_partials(const double* __restrict__ prev, int nprev, int slot0, double (&out)[NQ]) {
+    __shared__ double redp[NWAVES][NQ];
+    __shared__ double tot_s[NQ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double tot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+    for (int j = threadIdx.x; j < nprev; j += 64 * NWAVES) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tot[q] += prev[(size_t)j * kPartialStride + slot0 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double v = wave_sum(tot[q]);
+        if (lane == 0) redp[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = redp[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) v += redp[w][threadIdx.x];
+        tot_s[threadIdx.x] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = tot_s[q];
+}
+
 struct Coefs { double al, bt, nup; };
 
 __device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meurant) {

@@ -32,6 +32,7 @@ struct FusedPrev {
     const double* pub; unsigned want; unsigned* err;
     int nt_int;       // tiles [nt_int, ntiles) touch ghost columns: they are neither computed nor even requested before
                       // the publication has arrived (the ghost rows travel with it)
+    const double* dots_old;   // Hestenes-Stiefel product launch: the scalars of iteration k-1 (nu_k1 for b_k = nu_k / nu_k1)
 };
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
 // the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row
@@ -60,6 +61,7 @@ enum SpmvEpilogue {
     kEpiPipeFusedP = 5,  // ... 'p' flavours: w is the stored recurrence, only u = A s is used from the product
     kEpiPipeFusedJ = 6,  // ... Jacobi, 'pr' flavours: input (r~,s~); w~ = d w, u~ = d u in registers
     kEpiPipeFusedPJ = 7, // ... Jacobi, 'p' flavours
+    kEpiHS = 8,      // window kernels only: the Hestenes-Stiefel product launch (launch_win_hs)
 };
 constexpr bool epi_fused(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedP || e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_prec(int e) { return e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
@@ -160,6 +162,18 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
                      int write_mask, int per_cu);
 int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
                           int per_cu);
+// Second of the TWO launches of a Hestenes-Stiefel iteration on a window operator (hs_cg.py:57-61,
+// hs_pcg :120-124).  The first (launch_hs_update_xr with `prev`) left nu_k = <r~,r> as block partials;
+// every workgroup of this launch sums them in the same fixed order, b_k = nu_k / nu_k1, and the window of
+// the input vector is FORMED while it is staged: p = z + b_k p_old (z = r, or r~ with Jacobi; mul then add,
+// two roundings, as the reference's `r_k + b_k * p_k1`), so p_k is never gathered from memory.  Then
+// s = A p with mu = <p,s> as block partials (partials[grid][0]); the row's own p goes to p_new (other
+// tiles still stage p_old: double-buffered).  hs.prev_partials / nprev: the update launch's partials
+// (slots 3, 4); hs.dots_old: scalars of iteration k-1; hs.dots_prev_out: scalars of iteration k (nu, rr
+// written by workgroup 0); coef_out[1] = b_k.  nprev == 0: nu_k is read from dots_prev_out instead.
+int launch_win_hs(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* z,
+                  const double* p_old, double* p_new, double* s, double* partials, double* coef_out,
+                  const FusedPrev& hs, int per_cu);
 
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {
@@ -200,8 +214,14 @@ struct HsArgs {
     double* x; double* r; double* rt; double* p; const double* s; const double* d;
     const double* dots_prev; const double* dots_cur; double* coef_out; double* partials;
 };
-int launch_hs_update_xr(hipStream_t st, const HsArgs& a);   // x,r,(rt); partial nu (slot 3), rr (slot 4)
-int launch_hs_update_p(hipStream_t st, const HsArgs& a);    // p = z + beta p
+// prev_mu / nprev: mu = <p,s> of iteration k-1 still as block partials (slot 0) of the product launch -- every
+// block sums them in the same fixed order and block 0 stores mu to dots_prev_w[0]; nprev == 0: a.dots_prev[0]
+int launch_hs_update_xr(hipStream_t st, const HsArgs& a, const double* prev_mu = nullptr, int nprev = 0,
+                        double* dots_prev_w = nullptr);   // x,r,(rt); partial nu (slot 3), rr (slot 4)
+// prev_nu / nprev: nu_k, rr_k still as block partials (slots 3, 4) of launch_hs_update_xr; block 0 stores them
+// to dots_cur_w[3], [4]
+int launch_hs_update_p(hipStream_t st, const HsArgs& a, const double* prev_nu = nullptr, int nprev = 0,
+                       double* dots_cur_w = nullptr);    // p = z + beta p
 int launch_hs_init_dots(hipStream_t st, const HsArgs& a);   // nu, rr of the initial state
 
 struct PrArgs {   // non-pipelined predict-and-recompute (pr_pcg / m_pcg)

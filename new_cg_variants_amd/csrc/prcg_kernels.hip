@@ -444,10 +444,21 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
 
 // ---- Hestenes-Stiefel (hs_cg.py:54-61, hs_pcg :116-124) ------------------------------
 template <bool PREC, bool DOTS_ONLY>
-__global__ __launch_bounds__(kBlock) void k_hs_update_xr(HsArgs a, int trips) {
+__global__ __launch_bounds__(kBlock) void k_hs_update_xr(HsArgs a, int trips, const double* __restrict__ prev_mu, int nprev,
+                                                         double* dots_prev_w) {
     double al = 0.0;
     if constexpr (!DOTS_ONLY) {
-        al = a.dots_prev[3] / a.dots_prev[0];                   // a_k1 = nu/mu
+        double mu;
+        if (nprev > 0) {
+            // mu = <p,s> of the previous iteration: still the product launch's block partials
+            double m[1];
+            sum_prev_partials<1, kWaves>(prev_mu, nprev, 0, m);
+            mu = m[0];
+            if (blockIdx.x == 0 && threadIdx.x == 0) dots_prev_w[0] = mu;
+        } else {
+            mu = a.dots_prev[0];
+        }
+        al = a.dots_prev[3] / mu;                               // a_k1 = nu/mu
         if (blockIdx.x == 0 && threadIdx.x == 0) a.coef_out[0] = al;
     }
     double acc[2] = {0.0, 0.0};   // nu, rr
@@ -476,8 +487,18 @@ __global__ __launch_bounds__(kBlock) void k_hs_update_xr(HsArgs a, int trips) {
     block_reduce_store<2>(acc, a.partials, 3);
 }
 
-__global__ __launch_bounds__(kBlock) void k_hs_update_p(HsArgs a, int trips) {
-    const double bt = a.dots_cur[3] / a.dots_prev[3];           // b_k = nu_k / nu_k1
+__global__ __launch_bounds__(kBlock) void k_hs_update_p(HsArgs a, int trips, const double* __restrict__ prev_nu, int nprev,
+                                                        double* dots_cur_w) {
+    double nu;
+    if (nprev > 0) {
+        double m[2];
+        sum_prev_partials<2, kWaves>(prev_nu, nprev, 3, m);     // nu_k, rr_k: still the update launch's block partials
+        nu = m[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { dots_cur_w[3] = m[0]; dots_cur_w[4] = m[1]; }
+    } else {
+        nu = a.dots_cur[3];
+    }
+    const double bt = nu / a.dots_prev[3];                      // b_k = nu_k / nu_k1
     if (blockIdx.x == 0 && threadIdx.x == 0) a.coef_out[1] = bt;
     const double* __restrict__ z = a.rt ? a.rt : a.r;
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
@@ -1090,21 +1111,23 @@ int launch_pipe_dots(hipStream_t st, const PipeUpdateArgs& a) {
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 
-int launch_hs_update_xr(hipStream_t st, const HsArgs& a) {
+int launch_hs_update_xr(hipStream_t st, const HsArgs& a, const double* prev_mu, int nprev, double* dots_prev_w) {
     const Chunking c = chunking(a.n);
-    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
-    else     hipLaunchKernelGGL((k_hs_update_xr<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, prev_mu, nprev, dots_prev_w);
+    else     hipLaunchKernelGGL((k_hs_update_xr<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, prev_mu, nprev, dots_prev_w);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 int launch_hs_init_dots(hipStream_t st, const HsArgs& a) {
     const Chunking c = chunking(a.n);
-    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
-    else     hipLaunchKernelGGL((k_hs_update_xr<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    const double* none = nullptr;
+    double* nonew = nullptr;
+    if (a.d) hipLaunchKernelGGL((k_hs_update_xr<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, none, 0, nonew);
+    else     hipLaunchKernelGGL((k_hs_update_xr<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, none, 0, nonew);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
-int launch_hs_update_p(hipStream_t st, const HsArgs& a) {
+int launch_hs_update_p(hipStream_t st, const HsArgs& a, const double* prev_nu, int nprev, double* dots_cur_w) {
     const Chunking c = chunking(a.n);
-    hipLaunchKernelGGL(k_hs_update_p, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    hipLaunchKernelGGL(k_hs_update_p, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, prev_nu, nprev, dots_cur_w);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 

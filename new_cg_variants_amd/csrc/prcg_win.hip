@@ -68,6 +68,9 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 template <int NV> struct RegV;
 template <> struct RegV<1> { using type = double; };
 template <> struct RegV<2> { using type = d2_t; };
+// components per staged window entry AS LOADED: the Hestenes-Stiefel product launch loads (z, p_old) and stages
+// p = z + b p_old as one double
+constexpr int win_nw(int nv, int epi) { return epi == kEpiHS ? 2 : nv; }
 template <int NV, int M, int PG, int CW, bool VD>
 struct WRegs {
     d2_t v[VD ? 1 : kWinSlots / 128];   // plain values: nonzeros alo + st*128 + lane*2 .. +2
@@ -83,8 +86,8 @@ struct WRegs {
 
 template <int NV, int EPI, int M, int PG, int CW, bool VD>
 __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
-                                            const typename VecT<NV>::type* __restrict__ X,
-                                            const FusedRowPtrs& fr, WRegs<NV, M, PG, CW, VD>& R) {
+                                            const typename VecT<NV>::type* __restrict__ X, const double* __restrict__ X2,
+                                            const FusedRowPtrs& fr, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // branch-free: a lane whose chunk lies past the tile re-reads the tile's first chunk (hot line)
@@ -115,8 +118,12 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         }
     }
 #pragma unroll
-    for (int p = 0; p < PG; ++p)
-        if (p < d.np) R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];               // wave-uniform branch
+    for (int p = 0; p < PG; ++p) {
+        if (p < d.np) {                                                     // wave-uniform branch
+            if constexpr (EPI == kEpiHS) { R.w[p].x = X[d.pc[p] + lane]; R.w[p].y = X2[d.pc[p] + lane]; }
+            else R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int row = d.rb + j * 64 + lane;
@@ -159,7 +166,7 @@ __device__ __forceinline__ void win_block_reduce_store(double (&acc)[NQ], double
 template <int NV>
 struct WCtx {
     double* sv; unsigned char* svi; unsigned char* sc; double* sd; typename VecT<NV>::type* sw;
-    const typename VecT<NV>::type* X;
+    const typename VecT<NV>::type* X; const double* X2;
     void* yout; int write_mask;
     const double* ep_r; const double* ep_d; double* ep_st;
     FusedRowPtrs fr;
@@ -171,7 +178,7 @@ struct WCtx {
 // STASH: only the products -- the row sums go to `stash` (this wave's LDS, [M][64] pairs), the epilogue
 // follows later (deferred form of the one-launch iteration).
 template <int NV, int EPI, int M, int PG, int CW, bool VD, bool STASH = false>
-__device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<NV, M, PG, CW, VD>& R,
+__device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
                                          double (&acc)[5], const Coefs& cf, double2* stash = nullptr,
                                          bool acquire_first = false)
@@ -201,8 +208,13 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
         for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(c.sc + (k * 512 + lane * 8) * 2) = R.c[k];
     }
 #pragma unroll
-    for (int p = 0; p < PG; ++p)
-        if (p < dcur.np) reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
+    for (int p = 0; p < PG; ++p) {
+        if (p < dcur.np) {
+            // Hestenes-Stiefel: the direction is formed here, p = z + b p_old (hs_cg.py:60), never gathered
+            if constexpr (EPI == kEpiHS) c.sw[p * 64 + lane] = R.w[p].x + cf.bt * R.w[p].y;
+            else reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
+        }
+    }
     int rs_[M], re_[M];
     FusedRowIn fin[M];
 #pragma unroll
@@ -220,7 +232,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     if (have_next) {
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.fr, R);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, R);
     }
 
     // ---- lane i walks row i (and i + 64, ...) ----
@@ -257,6 +269,14 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
             // pair array comes from the staged window, the new pair goes to the other array
             const double2 in_old = c.sw[active ? dcur.own + j * 64 + lane : 0];
             if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, fin[j], in_old, c.fr, cf, acc);
+        } else if constexpr (EPI == kEpiHS) {
+            // s = A p, mu += p_i s_i (hs_cg.py:61-62); the row's own p comes from the staged window and goes to p_new
+            const double pn = c.sw[active ? dcur.own + j * 64 + lane : 0];
+            if (active) {
+                reinterpret_cast<double*>(c.yout)[row] = sum;
+                c.ep_st[row] = pn;
+                acc[0] += pn * sum;
+            }
         } else {
             if (active) finish_row<NV, EPI>(row, sum, c.yout, c.write_mask, c.X, c.ep_r, c.ep_d, c.ep_st, acc, cf, c.fr);
         }
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_),
+    const WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_), ep_r,
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
                                   reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt},
@@ -350,12 +370,27 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
     }
 
+    if constexpr (EPI == kEpiHS) {
+        // nu_k = <r~,r> of the update launch just before: still its block partials (slots 3, 4)
+        double nu;
+        if (fz.nprev > 0) {
+            double m[2];
+            sum_prev_partials<2, WPB>(fz.prev_partials, fz.nprev, 3, m);
+            nu = m[0];
+            if (blockIdx.x == 0 && threadIdx.x == 0) { fz.dots_prev_out[3] = m[0]; fz.dots_prev_out[4] = m[1]; }
+        } else {
+            nu = fz.dots_prev_out[3];
+        }
+        cf.bt = nu / fz.dots_old[3];                                        // b_k = nu_k / nu_k1   hs_cg.py:59
+        if (blockIdx.x == 0 && threadIdx.x == 0) aux[1] = cf.bt;
+    }
+
     const int nblk = gridDim.x;
     const int W = nblk * WPB;
     int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
 
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
-    WRegs<NV, M, PG, CW, VD> R[DEPTH];
+    WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
     WDesc<PG> d[DEPTH], dn = {};
     // deferred form: tiles from `safe` on read ghost rows that arrive with the publication -- their loads are
     // postponed (pend) until the wave has seen it
@@ -368,7 +403,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         pend[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, R[i]);
             else pend[i] = true;
         }
     }
@@ -418,7 +453,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         // the ring continues with image (n_def mod DEPTH): bring that image to position 0
         if constexpr (DEPTH == 2) {
             if (n_def & 1) {
-                const WRegs<NV, M, PG, CW, VD> r0 = R[0]; R[0] = R[1]; R[1] = r0;
+                const WRegs<win_nw(NV, EPI), M, PG, CW, VD> r0 = R[0]; R[0] = R[1]; R[1] = r0;
                 const WDesc<PG> d0 = d[0]; d[0] = d[1]; d[1] = d0;
                 const bool p0 = pend[0]; pend[0] = pend[1]; pend[1] = p0;
             }
@@ -431,7 +466,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         for (int i = 0; i < DEPTH; ++i)
             if (pend[i]) {
                 if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.fr, R[i]);
+                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, R[i]);
                 pend[i] = false;
             }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -616,6 +651,14 @@ int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
     default: break;
     }
     return -1;
+}
+
+int launch_win_hs(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* z,
+                  const double* p_old, double* p_new, double* s, double* partials, double* coef_out,
+                  const FusedPrev& hs, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    return launch_win<1, kEpiHS>(geom, st, A, tiles, ntiles, z, s, 3, p_old, nullptr, p_new, partials, coef_out, hs, per_cu);
 }
 
 int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,

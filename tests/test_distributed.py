@@ -399,6 +399,41 @@ def test_s3_full_size_row_blocks_in_threads():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('workload,nranks,variant', [('s2', 4, 'PIPE_PR'), ('s2', 2, 'HS'), ('s4b', 3, 'PIPE_PR')])
+def test_full_size_stencil_and_fem_row_blocks_in_threads(workload, nranks, variant):
+    """The other two multi-GPU configurations of BASELINE.json at full size, cut into row blocks whose ranks run in
+    threads on ONE GPU: S2 (7-point Laplacian 216^3; blocks of whole grid planes, halo = one 216^2 plane per side =
+    746 KB of (r,s) pairs -> send/recv + all-reduce) and the FEM-like stand-in for Queen_4147 (nnz-balanced split
+    points, gather lists per peer).  The distributed SpMV must be the global product bit for bit (checked inside
+    run_ranks_in_threads); residual histories against the single-GPU run of the same schedule family."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    iters = 30
+    var = getattr(L, variant)
+    if workload == 's2':
+        planes = 216 // nranks
+        offsets = np.arange(nranks + 1, dtype=np.int64) * planes * 216 * 216
+    else:
+        offsets = partition.nnz_balanced_offsets(A.indptr, nranks)
+        nnz = np.diff(A.indptr[offsets])
+        assert nnz.max() <= 1.02 * nnz.mean(), nnz
+    one = DeviceCSR(A, knobs={'PRCG_FUSED': '0'})
+    one.begin(var, b, x0, iters + 1, hist_mask=1)
+    one.iterate(iters)
+    one.sync()
+    ref = one.history()['updated_residual_2_norm']
+    one.close()
+    x, hist, scheds = run_ranks_in_threads(A, nranks, var, iters, hist_mask=1, offsets=offsets)
+    assert all(s['comm'] and not s['fused_comm'] for s in scheds), scheds
+    np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
+    np.testing.assert_allclose(hist['updated_residual_2_norm'], ref, rtol=1e-4)
+
+
+@pytest.mark.gpu
 def test_ranks_in_threads_may_run_different_schedules():
     """A rank whose block is no window operator, or whose stream-concurrency probe fails, keeps the two-kernel schedule
     while its peers run one launch per iteration: both issue ONE all-gather per iteration carrying the same things

@@ -603,26 +603,42 @@ def test_figure_run_reproduces_the_reference_table_row(amd, tmp_path):
     assert row.startswith('\\texttt{bcsstk03} & - & 112 & 640&') and row.rstrip().endswith('\\\\')
 
 
-def test_ex2b_driver_matches_the_published_petsc_errors(amd, capfd):
+# re-orderings of the DEVICE's inner products (other grids = other partial sums, other kernels): what the oracle's
+# SUMMATION_ORDERS are for the small matrices, at sizes the oracle cannot iterate 4000 times in a test
+DEVICE_ORDERS = [{}, {'PRCG_WIN_GRID_PER_CU': '2'}, {'PRCG_WIN_GRID_PER_CU': '3'}, {'PRCG_WIN_GRID_PER_CU': '6'},
+                 {'PRCG_WIN': '0'}]
+
+
+def test_ex2b_driver_matches_the_published_petsc_errors(amd, capfd, monkeypatch):
     """The reference's PETSc run (n=650000, k=32, rho=.95, kappa=1e6, off=1e-4, 4000 iterations,
     config_info/slurm-864568.out:129,186,205) printed
         cg         Norm of error 1.60099e-07 iterations 4000
         pipeprcg   Norm of error 3.24332e-07 iterations 4000
         pipeprcg_0 Norm of error 8.94408e-05 iterations 4000
-    The same command line through the device must land in the same decade."""
+    The same command line through the device, under five orders of its own inner products: the published
+    value must lie inside the spread of the device's values (+- 0.5 decades, the margin of the convergence rule
+    of test_free_running_against_reference) -- PETSc's VecDot order is one more such order."""
     from new_cg_variants_amd.experiments import ex2b
     base = '-n 650000 -rho 0.95 -kappa 1e6 -k 32 -off_value 1e-4 -pc_type none -num_repeat 1 ' \
            '-ksp_norm_type none -ksp_max_it 4000'
     published = {'-ksp_type cg': 1.60099e-07, '-ksp_type pipeprcg': 3.24332e-07,
                  '-ksp_type pipeprcg -recompute_q 0': 8.94408e-05}
+    report = []
     for flags, err_pub in published.items():
-        ex2b.main((base + ' ' + flags).split())
-        lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith('Norm of error ')]
-        assert len(lines) == 1 and lines[0].endswith(' iterations 4000'), lines
-        out = lines[0]
-        err = float(out.split()[3])
-        assert abs(np.log10(err) - np.log10(err_pub)) < 1.0, (flags, err, err_pub)
-        print(f'ex2b {flags}: {out}   (PETSc run published {err_pub:g})')
+        errs = []
+        for knobs in DEVICE_ORDERS:
+            with monkeypatch.context() as mp:
+                for key, val in knobs.items():
+                    mp.setenv(key, val)
+                ex2b.main((base + ' ' + flags).split())
+            lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith('Norm of error ')]
+            assert len(lines) == 1 and lines[0].endswith(' iterations 4000'), lines
+            errs.append(float(lines[0].split()[3]))
+        lg = np.log10(errs)
+        report.append(f'ex2b {flags}: Norm of error {errs[0]:g} (PETSc run published {err_pub:g}); over {len(errs)} orders '
+                      f"of the device's sums {min(errs):.3e}..{max(errs):.3e}")
+        assert lg.min() - 0.5 <= np.log10(err_pub) <= lg.max() + 0.5, (flags, errs, err_pub)
+    print('\n'.join(report))
 
 
 @pytest.mark.parametrize('name', ['pipe_pr_cg', 'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg'])
@@ -677,19 +693,34 @@ def test_scaling_mirror_takes_the_reference_drivers_dense_column_block(amd):
 def test_scaling_tests_driver_matches_the_published_errors(amd, tmp_path, monkeypatch, capfd):
     """The reference's own run of `scaling_tests.py 12288 1500` (scaling_experiments_mpi4py/data/,
     BASELINE.md / SURVEY.md section 6) ended with errors hs 1.10e-7, cg_cg 2.08e-6, gv 5.74e-5,
-    pr 2.26e-7, pipe_pr 4.01e-7.  The same command line through the device must land in the same
-    decade (the attained accuracy of each variant is the experiment's second result), print the same
-    lines and save the same dicts."""
+    pr 2.26e-7, pipe_pr 4.01e-7.  The same command line through the device must print the same lines, save
+    the same dicts, and end with an error inside the spread the MP oracle shows for that variant under the six
+    SUMMATION_ORDERS of its inner products (+- 0.5 decades: the one convergence rule of this file); the
+    published value must lie in that band too (it is the 'blas' order on the reference's machine)."""
     from new_cg_variants_amd.experiments import scaling_tests
     monkeypatch.chdir(tmp_path)
-    res = scaling_tests.main(['12288', '1500', 'unit'])
+    n, its = 12288, 1500
+    res = scaling_tests.main([str(n), str(its), 'unit'])
     out = capfd.readouterr().out
     published = {'hs_cg': 1.10e-7, 'cg_cg': 2.08e-6, 'gv_cg': 5.74e-5, 'pr_cg': 2.26e-7, 'pipe_pr_cg': 4.01e-7}
+    lam = mp_oracle.model_problem_eigs(n)
+
+    class Diagonal:
+        def matvec_local(self, V):
+            return lam * V if V.ndim == 1 else lam[:, None] * V
+    comm = mp_oracle.SingleRankComm()
     for name, err_pub in published.items():
         assert f'{name} error: ' in out
-        saved = np.load(tmp_path / 'data' / '12288' / f'{name}_unit.npy', allow_pickle=True).item()
+        saved = np.load(tmp_path / 'data' / str(n) / f'{name}_unit.npy', allow_pickle=True).item()
         assert set(saved) == {'error', 'timings'} and saved['timings']['tot'] > 0
-        assert abs(np.log10(saved['error']) - np.log10(err_pub)) < 1.0, (name, saved['error'], err_pub)
-        print(f'scaling_tests {name}: error {saved["error"]:.3e} (published {err_pub:.2e}), '
-              f'{1500 / saved["timings"]["tot"]:.0f} it/s')
+        spread = []
+        for _, dot in SUMMATION_ORDERS:
+            x, _t = getattr(mp_oracle, name)(comm, Diagonal(), lam / np.sqrt(n), its, dot=dot)
+            spread.append(np.log10(np.linalg.norm(np.ones(n) / np.sqrt(n) - x)))
+        lo, hi = min(spread) - 0.5, max(spread) + 0.5
+        print(f'scaling_tests {name}: error {saved["error"]:.3e} (published {err_pub:.2e}; oracle under '
+              f'{len(spread)} summation orders {10 ** min(spread):.2e}..{10 ** max(spread):.2e}), '
+              f'{its / saved["timings"]["tot"]:.0f} it/s')
+        assert lo <= np.log10(saved['error']) <= hi, (name, saved['error'], spread)
+        assert lo <= np.log10(err_pub) <= hi, (name, err_pub, spread)
     assert res.keys() == published.keys()
