@@ -135,31 +135,39 @@ __device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], doub
     if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch (kernel boundary orders it)
 }
 
-// Every block of a launch sums the block partials the PREVIOUS launch left (slots slot0 .. slot0 + NQ) itself:
-// thread t rows t, t + T, ...; butterfly; waves in order -- the same order in every block, so all blocks hold the
-// same bits and no reduction launch sits between the two (the kernel boundary orders the partials).
+// Every block of a launch sums the block partials the PREVIOUS launch left (slots slot0 .. slot0 + NQ) itself, in
+// the order of k_reduce_final (a 256-thread tree: thread v rows v, v + 256, ...; butterfly over each 64 lanes; the
+// four wave sums in order) whatever the block's own size: a block of NWAVES < 4 waves lets each thread play
+// 4 / NWAVES of the tree's threads.  The same order in every block and in the separate reduction launch, so all
+// blocks hold the same bits, and the schedules with and without reduction launches give the same numbers.
 template <int NQ, int NWAVES>
 __device__ __forceinline__ void sum_prev_partials(const double* __restrict__ prev, int nprev, int slot0, double (&out)[NQ]) {
-    __shared__ double redp[NWAVES][NQ];
+    constexpr int kTreeWaves = 4;
+    static_assert(kTreeWaves % NWAVES == 0, "1, 2 or 4 waves per block");
+    constexpr int R = kTreeWaves / NWAVES;
+    __shared__ double redp[kTreeWaves][NQ];
     __shared__ double tot_s[NQ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double tot[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
-    for (int j = threadIdx.x; j < nprev; j += 64 * NWAVES) {
+    for (int r = 0; r < R; ++r) {
+        double tot[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) tot[q] += prev[(size_t)j * kPartialStride + slot0 + q];
-    }
+        for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+        for (int j = threadIdx.x + r * 64 * NWAVES; j < nprev; j += 64 * kTreeWaves) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double v = wave_sum(tot[q]);
-        if (lane == 0) redp[wv][q] = v;
+            for (int q = 0; q < NQ; ++q) tot[q] += prev[(size_t)j * kPartialStride + slot0 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double v = wave_sum(tot[q]);
+            if (lane == 0) redp[wv + r * NWAVES][q] = v;
+        }
     }
     __syncthreads();
     if (threadIdx.x < NQ) {
         double v = redp[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < NWAVES; ++w) v += redp[w][threadIdx.x];
+        for (int w = 1; w < kTreeWaves; ++w) v += redp[w][threadIdx.x];
         tot_s[threadIdx.x] = v;
     }
     __syncthreads();

@@ -157,7 +157,7 @@ struct prcg_handle {
     int k = 0;
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
-    DevBuf x, xp, p, rs, rs2, rst, rst2, wu, wt, wv, r, s, rt, st, b, xt, dinv, e_ext;
+    DevBuf x, xp, p, p2, rs, rs2, rst, rst2, wu, wt, wv, r, s, rt, st, b, xt, dinv, e_ext;
     DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
     bool fused_comm = false;     // ... with a communicator: the interior launch waits in-kernel for the reduction
@@ -175,6 +175,10 @@ struct prcg_handle {
     bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: the current SpMM input pairs: rs / rs2 ((r,s)), with Jacobi rst / rst2 ((r~,s~))
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
+    bool hs_fused = false;       // Hestenes-Stiefel without reduction launches: 2 launches per iteration on window
+                                 // operators (update; product with the direction formed in the staged window), else 3
+    double* p_cur = nullptr;     // ... the current direction: p / p2 (the product launch writes the other one)
+    int hs_pend_mu = 0;          // ... mu of iteration pend_k exists only as this many block partials in partB
     int pend_parts = 0;          // fused: dots[pend_k] exist only as this many block partials ...
     int pend_k = -1;             // ... of iteration pend_k, in pend_buf
     double* pend_buf = nullptr;
@@ -412,12 +416,14 @@ double* dots_at(prcg_t* h, int k) { return h->dots.d() + (size_t)k * kNS; }
 double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride; }
 
 void fused_flush(prcg_t* h);
+void hs_flush(prcg_t* h);
 
 // ---- history recorders for the state of iteration k (compute stream) -------------------
 int record(prcg_t* h, int k) {
     const uint32_t m = h->hist_mask;
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
     if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
+    if (h->hs_fused) hs_flush(h);
     if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     const int64_t n = h->n;
     int rc;
@@ -710,7 +716,7 @@ HsArgs hs_args(prcg_t* h, int k) {
     HsArgs a{};
     a.n = h->n;
     a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
-    a.p = h->p.d(); a.s = h->s.d(); a.d = h->prec ? h->dinv.d() : nullptr;
+    a.p = h->p_cur; a.s = h->s.d(); a.d = h->prec ? h->dinv.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.dots_cur = dots_at(h, k);
     a.coef_out = coef_at(h, k);
@@ -731,9 +737,59 @@ int iterate_hs(prcg_t* h, int k) {
     if (rc) return rc;
     LAUNCHCHK(h, launch_hs_update_p(h->sc, a));
     int nparts = 0;
-    if ((rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &nparts))) return rc;
+    if ((rc = overlapped_spmv(h, k, h->p_cur, h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &nparts))) return rc;
     launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, PRCG_S_MU, 1);
     return allreduce(h, dots_at(h, k) + PRCG_S_MU, 1, h->sc);           // reduction 2: mu
+}
+
+// make mu of iteration pend_k real if the last product launch left it as block partials
+void hs_flush(prcg_t* h) {
+    if (h->hs_pend_mu > 0) {
+        launch_reduce_final(h->sc, h->partB.d(), h->hs_pend_mu, dots_at(h, h->pend_k), 0, PRCG_S_MU, 1);
+        h->hs_pend_mu = 0;
+    }
+}
+
+// hs_cg.py:54-62 (hs_pcg :116-125) on one GPU without reduction launches.  The two inner products still separate
+// the iteration into two phases (that IS Hestenes-Stiefel), but each phase's block partials are summed by every
+// workgroup of the NEXT launch (same fixed order everywhere):
+//   launch 1  [mu_k1 from the product's partials; a = nu_k1 / mu_k1]  x += a p;  r -= a s;  (r~ = d r);  nu_k partials
+//   launch 2  [nu_k from launch 1's partials; b = nu_k / nu_k1]  window operators: p = z + b p_old formed while the
+//             input window is staged, s = A p, mu_k partials, p_k written to the other direction buffer;
+//             CSR-adaptive tiles: the p update (with that prologue) and the product are two launches.
+int iterate_hs_fused(prcg_t* h, int k) {
+    HsArgs a = hs_args(h, k);
+    const bool have_mu = h->hs_pend_mu > 0 && h->pend_k == k - 1;
+    if (!have_mu) hs_flush(h);
+    bool on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    const int g1 = launch_hs_update_xr(h->sc, a, have_mu ? h->partB.d() : nullptr, have_mu ? h->hs_pend_mu : 0, dots_at(h, k - 1));
+    LAUNCHCHK(h, g1);
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    h->hs_pend_mu = 0;
+    int grid = 0;
+    on = false;
+    if (h->win) {
+        FusedPrev hs{};
+        hs.prev_partials = h->partA.d(); hs.nprev = g1;
+        hs.dots_prev_out = dots_at(h, k); hs.dots_old = dots_at(h, k - 1);
+        double* p_new = (h->p_cur == h->p.d()) ? h->p2.d() : h->p.d();
+        prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+        grid = launch_win_hs(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom,
+                             h->prec ? h->rt.d() : h->r.d(), h->p_cur, p_new, h->s.d(), h->partB.d(), coef_at(h, k), hs,
+                             h->win_per_cu);
+        LAUNCHCHK(h, grid);
+        prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        h->p_cur = p_new;
+    } else {
+        LAUNCHCHK(h, launch_hs_update_p(h->sc, a, h->partA.d(), g1, dots_at(h, k)));
+        prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+        grid = eng_spmv(h, h->sc, 0, h->p_cur, h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, h->partB.d());
+        LAUNCHCHK(h, grid);
+        prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    }
+    h->hs_pend_mu = grid; h->pend_k = k;
+    return PRCG_OK;
 }
 
 PrArgs pr_args(prcg_t* h, int k) {
@@ -913,7 +969,7 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
     }
     switch (which) {
     case PRCG_VEC_X: *base = h->x.d(); return true;
-    case PRCG_VEC_P: *base = h->p.d(); return true;
+    case PRCG_VEC_P: *base = h->p_cur; return true;
     case PRCG_VEC_R: *base = h->r.d(); return true;
     case PRCG_VEC_S: *base = h->s.d(); return true;
     case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
@@ -1369,6 +1425,8 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->in_session = false;
     h->variant = variant;
     h->fused = false;
+    h->hs_fused = false;
+    h->hs_pend_mu = 0;
     h->small = false;
     h->gather = false;
     h->prec = inv_diag != nullptr;
@@ -1534,6 +1592,9 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     } else {
         // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
+        h->p_cur = h->p.d();
+        h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0;
+        HIPCHK(h, h->p2.ensure((h->hs_fused && h->win) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->r.ensure((size_t)n * D, h->sc));
         HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
@@ -1599,7 +1660,7 @@ int prcg_iterate(prcg_t* h, int iters) {
         const int k = h->k + 1;
         int rc;
         if (is_pipe(h->variant)) rc = iterate_pipe(h, k);
-        else if (h->variant == PRCG_HS) rc = iterate_hs(h, k);
+        else if (h->variant == PRCG_HS) rc = h->hs_fused ? iterate_hs_fused(h, k) : iterate_hs(h, k);
         else if (h->variant == PRCG_CG_CG) rc = iterate_cgcg(h, k);
         else if (h->variant == PRCG_GV) rc = iterate_gv(h, k);
         else rc = iterate_pr(h, k);
@@ -1608,6 +1669,7 @@ int prcg_iterate(prcg_t* h, int iters) {
         h->k = k;
     }
     if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
+    if (h->hs_fused) hs_flush(h);
     if (h->fused_comm && h->red_pending) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
@@ -1635,7 +1697,7 @@ int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
-    return (h->fused ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+    return ((h->fused || h->hs_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW

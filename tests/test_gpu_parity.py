@@ -456,6 +456,51 @@ def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant, pr
     print(f'{matrix}/{variant}/{prec}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
+@pytest.mark.parametrize('source,prec,knobs', [
+    ('s3_small', None, {}), ('s3_small', 'jacobi', {}), ('s3_small', None, {'PRCG_VALDICT': '0'}),
+    ('s1_small', None, {}), ('lap3d_20', 'jacobi', {}), ('lap3d_20', None, {'PRCG_VALDICT': '0'}),
+    ('bcsstk03', None, {}), ('nos7', 'jacobi', {}), ('s3_small', None, {'PRCG_WIN': '0'})])
+def test_hestenes_stiefel_without_reduction_launches(amd, matrices, source, prec, knobs):
+    """hs_cg / hs_pcg on one GPU: two launches per iteration on window operators (update; product whose staged
+    window IS the new direction p = z + b p_old, hs_cg.py:57-62), three on CSR-adaptive tiles, the inner products
+    summed by the following launch's workgroups in the order of the separate reduction kernel.  Same arithmetic, same
+    summation order as the five-launch schedule (PRCG_FUSED=0): every vector, scalar and coefficient of a
+    free-running solve must agree BIT FOR BIT, whatever the chunking of the iterate calls (pending partials across
+    calls, recorders in between)."""
+    L = amd['L']
+    if source in matrices:
+        A, z = matrices[source]
+        b = z['b']
+    else:
+        A = amd['problems'].laplace_3d(20, 20, 20) if source == 'lap3d_20' else amd['problems'].WORKLOADS[source]['make']()
+        b = amd['problems'].reference_rhs(A, A.shape[0])[0]
+    n = A.shape[0]
+    inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
+    total = 60
+    for op, mask in zip(ops, (1, 1)):
+        op.begin(L.HS, b, np.zeros(n), total + 1, inv_diag=inv_diag, hist_mask=mask)
+    assert ops[0].schedule()['fused'] and not ops[1].schedule()['fused']
+    expect_window = knobs.get('PRCG_WIN') != '0'      # (bcsstk03 and nos7 are narrow enough for window tiles too)
+    assert ops[0].schedule()['window'] == expect_window
+    k = 0
+    for chunk in (1, 7, 1, 12, 2, 37):
+        for op in ops:
+            op.iterate(chunk)
+        k += chunk
+        for v in ['x', 'r', 'p', 's'] + (['rt'] if prec else []):
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
+        for kk in range(k - chunk, k + 1):
+            assert np.array_equal(ops[0].get_scalars(kk)[:5], ops[1].get_scalars(kk)[:5], equal_nan=True), (k, kk)
+            if kk >= 1:
+                assert np.array_equal(ops[0].get_coefficients(kk)[:2], ops[1].get_coefficients(kk)[:2], equal_nan=True), (k, kk)
+    h0, h1 = ops[0].history(), ops[1].history()
+    for q in h1:
+        assert np.array_equal(h0[q], h1[q], equal_nan=True), q
+    for op in ops:
+        op.close()
+
+
 @pytest.mark.parametrize('matrix', ['bcsstk03', 'nos7', 'bcsstk14', 'model_48_8_3'])
 def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
     """n <= 4096 and nothing but the recurrence residual recorded: the whole solve runs in one
