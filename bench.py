@@ -44,12 +44,12 @@ def fused_bytes(n, nnz):    # one-launch iteration: A once, (r,s) read + written
     return 12 * nnz + 4 * (n + 1) + 64 * n
 
 
-def moved_bytes(algorithmic, nnz, sched):
-    """Bytes the launch MUST move with the operator stream the device actually reads (lossless
-    re-encodings of the caller's CSR: 1/2-byte column or window indices, 1-byte value-dictionary
-    indices; the dictionaries and tile descriptors, < 1 byte per nonzero, are not counted)."""
-    per_nnz = sched['col_bytes'] + (1 if sched['value_dict'] else 8)
-    return algorithmic - 12 * nnz + per_nnz * nnz
+def moved_bytes(algorithmic, n, nnz, operator_bytes):
+    """Bytes the launch MUST move: SURVEY 8d's figure with the caller's CSR arrays (12 B per nonzero, 4 B per
+    row pointer) replaced by the operator as the device streams it (prcg_operator_bytes: lossless re-encodings --
+    1/2-byte window indices, 1-byte value-dictionary indices, 2-byte relative row pointers, dictionaries and tile
+    descriptors, stream images that many tiles share counted once)."""
+    return algorithmic - 12 * nnz - 4 * (n + 1) + operator_bytes
 
 
 def kernel_source_sha():
@@ -215,7 +215,8 @@ def main():
         dev.matmat2(rs, reps=10)
         _, ms2 = dev.matmat2(rs, reps=50)
         b1, b2 = spmv_bytes(n, nnz_total), spmm2_bytes(n, nnz_total)
-        m1, m2 = moved_bytes(b1, nnz_total, sched), moved_bytes(b2, nnz_total, sched)
+        opb = dev.operator_bytes()
+        m1, m2 = moved_bytes(b1, n, nnz_total, opb), moved_bytes(b2, n, nnz_total, opb)
         return {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'], 'window_kernels': sched['window'],
                 'spmv_ms': ms1, 'spmv_moved_GBps': m1 / ms1 * 1e-6, 'spmv_frac_of_peak': m1 / ms1 * 1e-6 / HBM_PEAK_GBS,
                 'spmv_algorithmic_GBps': b1 / ms1 * 1e-6,
@@ -234,7 +235,7 @@ def main():
         dev2 = DeviceCSR(A_rows.tocsr(), device=local_rank, knobs={'PRCG_VALDICT': '0'})
         e2, _, tim2, fin2 = timed_run(dev2)
         sched2 = dev2.schedule()
-        plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2))
+        plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2), dev2.operator_bytes())
         dev2.close()
 
     # What the schedule every rank of an N>1 run executes costs on ONE GPU: the same loop with a 1-rank
@@ -271,27 +272,30 @@ def main():
             kbytes = spmv_bytes(n_local, nnz_local)
             kname = 'SpMV, interior launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
         ms = tim['spmv_ms']
-        moved = moved_bytes(kbytes, nnz_local, sched)
+        opb = dev.operator_bytes()
+        moved = moved_bytes(kbytes, n_local, nnz_local, opb)
         achieved = moved / ms * 1e-6 if ms > 0 else 0.0
         tkey = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic(tkey + (':dict' if sched['value_dict'] else ':plain')),
                 'kernel': kname, 'bytes_per_launch': moved, 'avg_launch_ms': ms, 'launches_sampled': tim['spmv_samples'],
                 'update_kernel_ms': tim['update_ms'],
-                'basis': ('achieved = bytes the launch must move / mean launch time by HIP events on the compute stream: '
-                          f"{sched['col_bytes']} B column stream + " + ('1 B value-dictionary index' if sched['value_dict'] else '8 B value')
-                          + ' per nonzero, 4 B row pointer and the vector traffic of SURVEY 8d per row'),
+                'basis': ('achieved = bytes the launch must move / mean launch time by HIP events on the compute stream: the operator '
+                          'as the device streams it (prcg_operator_bytes: ' f"{sched['col_bytes']} B window / column index + "
+                          + ('1 B value-dictionary index' if sched['value_dict'] else '8 B value') + ' per nonzero, relative row '
+                          'pointers, tile descriptors; stream images shared by many tiles counted once) + the vector traffic of SURVEY 8d per row'),
                 'operator_stream': {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'],
-                                    'window_kernels': sched['window']},
+                                    'window_kernels': sched['window'], 'bytes': opb, 'bytes_per_nonzero': opb / max(nnz_local, 1),
+                                    'csr_bytes': 12 * nnz_local + 4 * (n_local + 1)},
                 'effective': {'what': 'SURVEY.md 8d algorithmic CSR bytes (12 B per nonzero + vectors) / the same launch time: '
                                       'north_star\'s "effective" bandwidth; exceeds the peak when the stream is compressed',
                               'bytes_per_launch': kbytes, 'GBps': kbytes / ms * 1e-6 if ms > 0 else 0.0,
                               'frac_of_peak': kbytes / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0}}
         assert roof['frac'] <= 1.0, 'a physical fraction cannot exceed 1: the byte count is wrong'
         if plain is not None:
-            e2, tim2, fin2, sched2, spmv2 = plain
+            e2, tim2, fin2, sched2, spmv2, opb2 = plain
             ms2 = tim2['spmv_ms']
-            mv2 = moved_bytes(kbytes, nnz_local, sched2)
+            mv2 = moved_bytes(kbytes, n_local, nnz_local, opb2)
             roof['plain_values'] = {
                 'what': 'same matrix and loop with the value dictionary off (PRCG_VALDICT=0): the rate of an operator '
                         f"whose values do not repeat; {sched2['col_bytes']} B column stream + 8 B value per nonzero",
@@ -299,6 +303,7 @@ def main():
                 'achieved': kbytes / ms2 * 1e-6, 'frac': kbytes / ms2 * 1e-6 / HBM_PEAK_GBS,
                 'basis': 'SURVEY.md 8d algorithmic bytes (12 B per nonzero + vectors) / mean launch time',
                 'moved_GBps': mv2 / ms2 * 1e-6, 'moved_frac': mv2 / ms2 * 1e-6 / HBM_PEAK_GBS, 'bytes_moved_per_launch': mv2,
+                'operator_bytes': opb2,
                 'traffic': measured_traffic(tkey + ':plain'), 'residual_finite': fin2, 'spmv': spmv2}
             assert roof['plain_values']['frac'] <= 1.0
         if spmv:

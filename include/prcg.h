@@ -186,6 +186,13 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
 int prcg_schedule(const prcg_t* h);
+/* Bytes of the operator AS THE DEVICE STREAMS IT (the lossless re-encodings of the caller's CSR built at
+ * prcg_set_csr: narrow column / window indices, value-dictionary indices, relative row pointers, tile
+ * descriptors; stream images that many tiles share are counted once): what one matrix product must read
+ * from memory at least once.  bench.py's roofline is computed from this figure plus the vector traffic
+ * (SURVEY.md section 8d gives the algorithmic figure for the caller's CSR: 12 B per nonzero + 4 B per row).
+ * -1 without an operator.  No counterpart in the reference (scipy streams the CSR arrays as they are). */
+int64_t prcg_operator_bytes(const prcg_t* h);
 /* teacher forcing: declare that the state now loaded (prcg_set_vector / prcg_set_scalars
  * for iteration k) IS iteration k; the next prcg_iterate(h,1) produces k+1 */
 int prcg_set_iteration(prcg_t* h, int k);
@@ -235,6 +242,14 @@ int64_t prcg_plan_tiles(int64_t n, const int32_t* indptr, const uint8_t* row_cla
 int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
                          const uint8_t* row_class, int rows_per_tile, int32_t* tiles_out, int64_t capacity,
                          uint16_t* cw_out, int64_t* n_class0, int* most_pages);
+/* Stream images of the window tiles (what prcg_set_csr builds after prcg_plan_window): per tile the window
+ * indices of its nonzeros and its row pointers relative to its first nonzero; with share != 0 tiles whose
+ * image is byte-identical read ONE stored copy (bands and stencils repeat a few images).  out[0..6) = {tiles,
+ * stored window-index images, stored row-pointer images, elements of the window-index store, elements of the
+ * row-pointer store, 1 if every tile's source holds exactly its own image}.  Returns 1, 0 if the operator is no
+ * window operator, -1 on a bad argument.  Exported for the CPU tests. */
+int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+                            const uint8_t* row_class, int rows_per_tile, int share, int64_t* out);
 /* Merged exchange of the multi-GPU pipelined loop (small halos ride on the one all-gather per
  * iteration): where in the gathered buffer do this rank's ghost rows lie?  `tables`: every rank's
  * send table, doubles_per_table doubles each: [n_peers, (peer, first row of its list, rows)...];

@@ -62,6 +62,7 @@ _SIGNATURES = {
     'prcg_sync': (C.c_int, [_P]),
     'prcg_iteration': (C.c_int, [_P]),
     'prcg_schedule': (C.c_int, [_P]),
+    'prcg_operator_bytes': (C.c_int64, [_P]),
     'prcg_set_iteration': (C.c_int, [_P, C.c_int]),
     'prcg_get_vector': (C.c_int, [_P, C.c_int, _P]),
     'prcg_set_vector': (C.c_int, [_P, C.c_int, _P]),
@@ -76,6 +77,7 @@ _SIGNATURES = {
     'prcg_plan_tiles': (C.c_int64, [C.c_int64, _P, _P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
     'prcg_plan_window': (C.c_int64, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int)]),
+    'prcg_plan_window_images': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.c_int, _P]),
     'prcg_tile_caps': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 

@@ -122,7 +122,9 @@ struct prcg_handle {
     int win_geom = 0, win_rows = 0;
     bool win_vd = false;
     int nwt_int = 0, nwt_bnd = 0;
-    DevBuf wtiles, wcw, wvidx, wvdict;
+    DevBuf wtiles, wcw, wvidx, wvdict, wrel;
+    bool want_share = true;              // PRCG_WIN_SHARE=0: every window tile keeps its own stream images
+    int64_t win_stream_bytes = 0;        // bytes of the encoded operator a product must read at least once (window form)
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
                                          // measured slower than in-order (cross-stream event waits ~15 us/iter)
     DevBuf tmp_ext;                      // 2*(n+g) doubles: SpMV input scratch with ghost room
@@ -211,7 +213,8 @@ struct prcg_handle {
         return WinDev{indptr.i(), val.d(), b16 ? nullptr : static_cast<const unsigned char*>(wcw.p),
                       b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
                       win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
-                      win_vd ? static_cast<const double*>(wvdict.p) : nullptr};
+                      win_vd ? static_cast<const double*>(wvdict.p) : nullptr,
+                      static_cast<const unsigned short*>(wrel.p)};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -898,6 +901,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     if (k == "PRCG_SIDE_STREAM") h->side_stream = v != 0;
     else if (k == "PRCG_FUSED_FINAL") h->fused_final = v != 0;
     else if (k == "PRCG_FUSED") h->want_fused = v != 0;
+    else if (k == "PRCG_WIN_SHARE") h->want_share = v != 0;
     else if (k == "PRCG_SMALL") h->want_small = v != 0;
     else if (k == "PRCG_COL16") h->want_c16 = v != 0;
     else if (k == "PRCG_COL8") h->want_c8 = v != 0;
@@ -919,7 +923,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 }
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
-                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU"};
+                                   "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
+                                   "PRCG_WIN_SHARE"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1283,20 +1288,35 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     if (h->win) {
         h->nwt_int = (int)wp.t0.size(); h->nwt_bnd = (int)wp.t1.size();
+        // the tiles' stream images: byte-identical ones are stored once (prcg_plan.h: share_window_streams)
+        std::vector<uint8_t> vstore;
+        std::vector<uint16_t> rstore;
+        size_t cw_bytes = 0;
+        if (h->win_geom >= 2) {
+            std::vector<uint16_t> cstore;
+            share_window_streams<uint16_t>(wall, ip.data(), wp.cw.data(), h->win_vd ? wvidx.data() : nullptr, h->want_share,
+                                           cstore, vstore, rstore);
+            cw_bytes = cstore.size() * sizeof(uint16_t);
+            HIPCHK(h, h->wcw.alloc(cw_bytes));
+            HIPCHK(h, hipMemcpy(h->wcw.p, cstore.data(), cw_bytes, hipMemcpyHostToDevice));
+        } else {
+            std::vector<uint8_t> c8w(wp.cw.size()), cstore;
+            for (size_t q = 0; q < wp.cw.size(); ++q) c8w[q] = (uint8_t)wp.cw[q];
+            share_window_streams<uint8_t>(wall, ip.data(), c8w.data(), h->win_vd ? wvidx.data() : nullptr, h->want_share,
+                                          cstore, vstore, rstore);
+            cw_bytes = cstore.size();
+            HIPCHK(h, h->wcw.alloc(cw_bytes));
+            HIPCHK(h, hipMemcpy(h->wcw.p, cstore.data(), cw_bytes, hipMemcpyHostToDevice));
+        }
+        HIPCHK(h, h->wrel.alloc(rstore.size() * sizeof(uint16_t)));
+        HIPCHK(h, hipMemcpy(h->wrel.p, rstore.data(), rstore.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIPCHK(h, h->wtiles.alloc((wall.size() + 1) * sizeof(WTile)));
         HIPCHK(h, hipMemcpy(h->wtiles.p, wall.data(), wall.size() * sizeof(WTile), hipMemcpyHostToDevice));
-        if (h->win_geom >= 2) {
-            HIPCHK(h, h->wcw.alloc(wp.cw.size() * sizeof(uint16_t)));
-            HIPCHK(h, hipMemcpy(h->wcw.p, wp.cw.data(), wp.cw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        } else {
-            std::vector<uint8_t> c8w(wp.cw.size());
-            for (size_t q = 0; q < wp.cw.size(); ++q) c8w[q] = (uint8_t)wp.cw[q];
-            HIPCHK(h, h->wcw.alloc(c8w.size()));
-            HIPCHK(h, hipMemcpy(h->wcw.p, c8w.data(), c8w.size(), hipMemcpyHostToDevice));
-        }
+        h->win_stream_bytes = (int64_t)(wall.size() * sizeof(WTile) + cw_bytes + rstore.size() * sizeof(uint16_t)) +
+                              (h->win_vd ? (int64_t)(vstore.size() + wvdict.size() * sizeof(double)) : (int64_t)nnz * 8);
         if (h->win_vd) {
-            HIPCHK(h, h->wvidx.alloc(wvidx.size()));
-            HIPCHK(h, hipMemcpy(h->wvidx.p, wvidx.data(), wvidx.size(), hipMemcpyHostToDevice));
+            HIPCHK(h, h->wvidx.alloc(vstore.size()));
+            HIPCHK(h, hipMemcpy(h->wvidx.p, vstore.data(), vstore.size(), hipMemcpyHostToDevice));
             HIPCHK(h, h->wvdict.alloc((wvdict.size() + kWinDictMax) * sizeof(double)));
             if (!wvdict.empty())
                 HIPCHK(h, hipMemcpy(h->wvdict.p, wvdict.data(), wvdict.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1551,6 +1571,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     } else if (is_cg_family(variant)) {
         // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
+        h->p_cur = h->p.d();
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->w.ensure((size_t)ne * D, h->sc));
@@ -1694,6 +1715,15 @@ int prcg_sync(prcg_t* h) {
 }
 
 int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
+
+int64_t prcg_operator_bytes(const prcg_t* h) {
+    if (!h || !h->have_csr) return -1;
+    if (h->win) return h->win_stream_bytes;
+    // CSR-adaptive tiles: row pointers, tile table, column stream as encoded, values or dictionary indices
+    const int64_t colb = h->c8_int ? 1 : (h->c16_int ? 2 : 4);
+    const int64_t nt = (int64_t)h->nt_int + h->nt_bnd;
+    return 4 * (h->n + 1) + nt * (int64_t)sizeof(Tile) + h->nnz * colb + (h->vd_int ? h->nnz + nt * 16 : h->nnz * 8);
+}
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
@@ -1896,9 +1926,34 @@ int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const
     if (total > capacity) return -total;
     int64_t o = 0;
     for (const auto* v : {&wp.t0, &wp.t1})
-        for (const auto& t : *v) { memcpy(tiles_out + 20 * o, &t, sizeof t); ++o; }
+        for (const auto& t : *v) { memcpy(tiles_out + 20 * o, &t, 20 * sizeof(int32_t)); ++o; }
     if (cw_out) memcpy(cw_out, wp.cw.data(), (size_t)indptr[n] * sizeof(uint16_t));
     return total;
+}
+
+int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const uint8_t* row_class,
+                            int rows_per_tile, int share, int64_t* out) {
+    if (n < 0 || n_cols < n || !indptr || (indptr[n] > 0 && !indices) || (rows_per_tile != 64 && rows_per_tile != 128) || !out)
+        return -1;
+    WinPlan wp;
+    plan_window_tiles(n, n_cols, indptr, indices, row_class, rows_per_tile, kWinCapNnz, win_max_pages(rows_per_tile), wp);
+    if (!wp.ok0 || !wp.ok1) return 0;
+    std::vector<WTile> all(wp.t0);
+    all.insert(all.end(), wp.t1.begin(), wp.t1.end());
+    std::vector<uint16_t> cstore, rstore;
+    std::vector<uint8_t> vstore;
+    const StreamStats st = share_window_streams<uint16_t>(all, indptr, wp.cw.data(), nullptr, share != 0, cstore, vstore, rstore);
+    // what every tile will read must be what its own image holds
+    bool same = true;
+    for (const auto& t : all) {
+        const int pad = t.lo & 15;
+        same = same && (t.src_c & 15) == 0 && (size_t)t.src_c + pad + (t.hi - t.lo) <= cstore.size() &&
+               memcmp(cstore.data() + t.src_c + pad, wp.cw.data() + t.lo, (size_t)(t.hi - t.lo) * sizeof(uint16_t)) == 0;
+        for (int r = t.rb; r <= t.re && same; ++r) same = rstore[(size_t)t.src_r + (r - t.rb)] == (uint16_t)(indptr[r] - t.lo);
+    }
+    out[0] = (int64_t)all.size(); out[1] = st.cw_images; out[2] = st.rel_images;
+    out[3] = (int64_t)cstore.size(); out[4] = (int64_t)rstore.size(); out[5] = same ? 1 : 0;
+    return 1;
 }
 
 int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int n_peers, const int32_t* peer_rank,

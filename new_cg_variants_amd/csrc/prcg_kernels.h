@@ -135,9 +135,10 @@ struct alignas(16) WTile {
     int rb, re, lo, hi;
     int geo, maxlen, vd_first, vd_count;
     int page_col[kWinMaxPages];
+    int src_c, src_v, src_r, spare;
 };
 #endif
-static_assert(sizeof(WTile) == 80, "the kernels read a window tile descriptor as five int4");
+static_assert(sizeof(WTile) == 96, "the kernels read a window tile descriptor as six int4");
 struct WinDev {
     const int* indptr;
     const double* val;
@@ -145,6 +146,7 @@ struct WinDev {
     const unsigned short* cw16;    // geometry 2, 3
     const unsigned char* vidx8;    // null: plain values
     const double* vdict;
+    const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r)
 };
 // geometry id of a class planned with rows_per_tile (64 | 128) whose tiles need at most most_pages
 // pages: 0 = 64 rows / 2 pages / 8-bit indices, 1 = 64 / 4 / 8-bit, 2 = 128 / 8 / 16-bit, 3 = 128 / 12 / 16-bit

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <thread>
+#include <unordered_map>
 
 namespace prcg {
 
@@ -161,11 +162,29 @@ void plan_window_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const i
     if (out.ok1) out.ok1 = window_class(out.t1, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages1);
 }
 
+namespace {
+
+uint64_t hash_bytes(const void* p, size_t n, uint64_t h) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) { h = (h ^ b[i]) * 0x100000001B3ull; }
+    return h ^ (h >> 32);
+}
+
+}  // namespace
+
 bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_max,
                       std::vector<uint8_t>& vidx, std::vector<double>& vdict) {
     constexpr int kHash = 1024;           // open addressing, <= 256 live keys
     uint64_t keys[kHash];
     int16_t slot_of[kHash];
+    std::unordered_map<uint64_t, std::vector<int64_t>> tables;
     for (auto& t : tiles) {
         if (vdict.size() & 1) vdict.push_back(0.0);            // 16-byte aligned table start
         for (int i = 0; i < kHash; ++i) slot_of[i] = -1;
@@ -186,10 +205,83 @@ bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_ma
         }
         t.vd_first = (int)first;
         t.vd_count = count;
+        // a table identical to one already stored (constant coefficients: every tile of a stencil) is shared
+        {
+            const uint64_t key = hash_bytes(vdict.data() + first, (size_t)count * sizeof(double), 0x9AE16A3B2F90404Full + (uint64_t)count);
+            auto it = tables.find(key);
+            bool shared = false;
+            if (it != tables.end())
+                for (int64_t pos : it->second)
+                    if (memcmp(vdict.data() + pos, vdict.data() + first, (size_t)count * sizeof(double)) == 0) {
+                        t.vd_first = (int)pos;
+                        vdict.resize(first);
+                        shared = true;
+                        break;
+                    }
+            if (!shared) tables[key].push_back((int64_t)first);
+        }
         if (vdict.size() >= (size_t)INT32_MAX - 1024) return false;
     }
     return true;
 }
+
+namespace {
+
+// images already in a store: hash -> positions of their first element
+using ImageIndex = std::unordered_map<uint64_t, std::vector<int64_t>>;
+
+// position of `img` (len elements) in `store`, at an address congruent to `pad` modulo `align`: an identical image
+// already stored there if share, else appended
+template <typename T>
+int64_t place_image(std::vector<T>& store, ImageIndex& index, const T* img, int len, int pad, int align, bool share,
+                    int64_t* n_images) {
+    const uint64_t key = hash_bytes(img, (size_t)len * sizeof(T), 0xCBF29CE484222325ull + (uint64_t)pad);
+    if (share) {
+        auto it = index.find(key);
+        if (it != index.end())
+            for (int64_t pos : it->second)
+                if ((pos % align) == pad && (size_t)pos + len <= store.size() && memcmp(store.data() + pos, img, (size_t)len * sizeof(T)) == 0)
+                    return pos;
+    }
+    const size_t s = store.size();
+    size_t pos = s - (s % align) + pad;
+    if (pos < s) pos += align;
+    store.resize(pos, T(0));
+    store.insert(store.end(), img, img + len);
+    if (share) index[key].push_back((int64_t)pos);
+    ++*n_images;
+    return (int64_t)pos;
+}
+
+}  // namespace
+
+template <typename CW>
+StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indptr, const CW* cw_in, const uint8_t* vidx_in,
+                                 bool share, std::vector<CW>& cw_store, std::vector<uint8_t>& vidx_store,
+                                 std::vector<uint16_t>& rel_store) {
+    StreamStats st;
+    ImageIndex ic, iv, ir;
+    cw_store.clear(); vidx_store.clear(); rel_store.clear();
+    std::vector<uint16_t> rel;
+    for (auto& t : tiles) {
+        const int len = t.hi - t.lo, pad = t.lo & 15;
+        t.src_c = (int)(place_image(cw_store, ic, cw_in + t.lo, len, pad, 16, share, &st.cw_images) - pad);
+        t.src_v = vidx_in ? (int)(place_image(vidx_store, iv, vidx_in + t.lo, len, pad, 16, share, &st.vidx_images) - pad) : 0;
+        rel.resize((size_t)(t.re - t.rb) + 1);
+        for (int r = t.rb; r <= t.re; ++r) rel[(size_t)(r - t.rb)] = (uint16_t)(indptr[r] - t.lo);
+        t.src_r = (int)place_image(rel_store, ir, rel.data(), (int)rel.size(), 0, 1, share, &st.rel_images);
+        t.spare = 0;
+    }
+    // the kernels' 16-byte loads of the last image may run past its end; a lane of a short tile reads rel[0], rel[1]
+    cw_store.resize(cw_store.size() + 32, CW(0));
+    vidx_store.resize(vidx_store.size() + 32, 0);
+    rel_store.resize(rel_store.size() + 8, 0);
+    return st;
+}
+template StreamStats share_window_streams<uint8_t>(std::vector<WTile>&, const int32_t*, const uint8_t*, const uint8_t*, bool,
+                                                   std::vector<uint8_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&);
+template StreamStats share_window_streams<uint16_t>(std::vector<WTile>&, const int32_t*, const uint16_t*, const uint8_t*, bool,
+                                                    std::vector<uint16_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&);
 
 int plan_gather_sources(int rank, int T, const double* tab, int n_peers, const int32_t* peer_rank,
                         const int64_t* recv_ptr, int64_t slot, int32_t* src) {

@@ -28,6 +28,9 @@ struct alignas(16) WTile {
     int geo, maxlen, vd_first, vd_count;      // geo = pages in use | (window index of row rb) << 8; longest row;
                                          // value dictionary {first entry, count}
     int page_col[kWinMaxPages];          // first column of each page
+    // where the kernel reads the tile's encoded streams (share_window_streams): 16-aligned start of the
+    // window-index image / of the value-index image (elements), start of the relative row pointers
+    int src_c, src_v, src_r, spare;
 };
 #endif
 struct WinPlan {
@@ -46,6 +49,24 @@ void plan_window_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const i
 // leaves the tiles' vd_* zero) if some tile needs more entries.
 bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_max,
                       std::vector<uint8_t>& vidx, std::vector<double>& vdict);
+
+// Tile images.  The kernels read three encoded streams per tile: the window indices of its nonzeros
+// (cw, 1 or 2 bytes each), the value-dictionary indices (vidx, 1 byte each; absent with plain values)
+// and the row pointers relative to the tile's first nonzero (rel, 2 bytes per row + 1).  Tiles whose
+// image of a stream is byte-identical SHARE one copy: a band or a stencil repeats the same few images
+// over and over (the structure is translation invariant, and so are the value indices when the
+// coefficients repeat), so the kernels find them in L2 instead of streaming them from HBM.  Lossless:
+// what a tile reads is exactly what it would have read from its own copy.
+//   cw_in / vidx_in: per nonzero, as plan_window_tiles / plan_window_dict wrote them (vidx_in null:
+//   plain values).  On return the *_store vectors hold the images (the cw / vidx image of a tile starts
+//   at a multiple of 16 elements and is preceded by lo % 16 elements of padding, as in the per-nonzero
+//   layout, so the kernels' 16-byte loads stay aligned), and every tile's src_c / src_v / src_r is set.
+//   share = false stores every tile's own image (the layout then equals the per-nonzero one).
+struct StreamStats { int64_t cw_images = 0, vidx_images = 0, rel_images = 0; };
+template <typename CW>
+StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indptr, const CW* cw_in, const uint8_t* vidx_in,
+                                 bool share, std::vector<CW>& cw_store, std::vector<uint8_t>& vidx_store,
+                                 std::vector<uint16_t>& rel_store);
 
 // Merged exchange (small halos ride on the one all-gather per iteration):
 // every rank contributes a slot of `slot` doubles = 8 (partial sums) + 2 x its packed send rows;

@@ -38,12 +38,13 @@ constexpr int kU = PRCG_WIN_UNROLL;
 template <int PG>
 struct WDesc {
     int rb, re, lo, hi, np, own, maxlen, vdf, vdc;
+    int srcc, srcv, srcr;      // where the tile's (possibly shared) stream images start: window indices, value indices, row pointers
     int pc[PG];
 };
 
 template <int PG>
 __device__ __forceinline__ WDesc<PG> read_desc(const int4* __restrict__ wt, int t) {
-    const int4 a = wt[t * 5 + 0], b = wt[t * 5 + 1];
+    const int4 a = wt[t * 6 + 0], b = wt[t * 6 + 1], e = wt[t * 6 + 5];
     WDesc<PG> d;
     d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
     d.lo = __builtin_amdgcn_readfirstlane(a.z); d.hi = __builtin_amdgcn_readfirstlane(a.w);
@@ -51,9 +52,11 @@ __device__ __forceinline__ WDesc<PG> read_desc(const int4* __restrict__ wt, int 
     d.np = geo & 255; d.own = geo >> 8;
     d.maxlen = __builtin_amdgcn_readfirstlane(b.y);
     d.vdf = __builtin_amdgcn_readfirstlane(b.z); d.vdc = __builtin_amdgcn_readfirstlane(b.w);
+    d.srcc = __builtin_amdgcn_readfirstlane(e.x); d.srcv = __builtin_amdgcn_readfirstlane(e.y);
+    d.srcr = __builtin_amdgcn_readfirstlane(e.z);
 #pragma unroll
     for (int q = 0; q < (PG + 3) / 4; ++q) {
-        const int4 p = wt[t * 5 + 2 + q];
+        const int4 p = wt[t * 6 + 2 + q];
         if (4 * q + 0 < PG) d.pc[4 * q + 0] = __builtin_amdgcn_readfirstlane(p.x);
         if (4 * q + 1 < PG) d.pc[4 * q + 1] = __builtin_amdgcn_readfirstlane(p.y);
         if (4 * q + 2 < PG) d.pc[4 * q + 2] = __builtin_amdgcn_readfirstlane(p.z);
@@ -90,10 +93,13 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                                             const FusedRowPtrs& fr, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
-    // branch-free: a lane whose chunk lies past the tile re-reads the tile's first chunk (hot line)
-    const int q16 = (alo + lane * 16) < d.hi ? (alo + lane * 16) : alo;
+    // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
+    // with identical structure / value indices share: len elements from a 16-aligned start, the first lo % 16 padding.
+    // branch-free: a lane whose chunk lies past the image re-reads its first chunk (hot line)
+    const int len = (d.lo & 15) + (d.hi - d.lo);
+    const int o16 = lane * 16 < len ? lane * 16 : 0;
     if constexpr (VD) {
-        R.vi = *reinterpret_cast<const u4_t*>(A.vidx8 + q16);
+        R.vi = *reinterpret_cast<const u4_t*>(A.vidx8 + d.srcv + o16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (64 * k < d.vdc) {                               // wave-uniform
@@ -109,12 +115,12 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         }
     }
     if constexpr (CW == 8) {
-        R.c[0] = *reinterpret_cast<const u4_t*>(A.cw8 + q16);
+        R.c[0] = *reinterpret_cast<const u4_t*>(A.cw8 + d.srcc + o16);
     } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int q = alo + k * 512 + lane * 8;
-            R.c[k] = *reinterpret_cast<const u4_t*>(A.cw16 + (q < d.hi ? q : alo));
+            const int q = k * 512 + lane * 8;
+            R.c[k] = *reinterpret_cast<const u4_t*>(A.cw16 + d.srcc + (q < len ? q : 0));
         }
     }
 #pragma unroll
@@ -128,8 +134,9 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
     for (int j = 0; j < M; ++j) {
         const int row = d.rb + j * 64 + lane;
         const int rr = row < d.re ? row : d.rb;
-        R.s[j] = A.indptr[rr];
-        R.e[j] = A.indptr[rr + 1];
+        const int jj = row < d.re ? j * 64 + lane : 0;
+        R.s[j] = A.rel[d.srcr + jj];                     // row pointers relative to the tile's first nonzero
+        R.e[j] = A.rel[d.srcr + jj + 1];
         if constexpr (FUSED) {
             R.xp[j] = reinterpret_cast<const d2_t*>(fr.XP)[rr];
             if constexpr (epi_prec(EPI)) {
@@ -187,8 +194,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     using RV = typename RegV<NV>::type;
     constexpr bool FUSED = epi_fused(EPI);
     const int lane = c.lane;
-    const unsigned short* sc16 = reinterpret_cast<const unsigned short*>(c.sc);
-    const int alo = dcur.lo & ~15;
+    const int pad = dcur.lo & 15;          // the staged stream starts at the 16-aligned nonzero below the tile's first
     // ---- park the tile's image in LDS (this is where the wave waits for ITS loads only: the
     //      loads of the tiles requested after it stay in flight) ----
     if constexpr (VD) {
@@ -236,24 +242,28 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     }
 
     // ---- lane i walks row i (and i + 64, ...) ----
-    const int last = dcur.hi - 1 - alo > 0 ? dcur.hi - 1 - alo : 0;
+    const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int row = dcur.rb + j * 64 + lane;
         const bool active = row < dcur.re;
         if (j > 0 && dcur.rb + j * 64 >= dcur.re) break;              // wave-uniform
-        const int o = rs_[j] - alo;
+        const int o = rs_[j] + pad;
         const int len = active ? re_[j] - rs_[j] : 0;
         V sum; vzero(sum);
         for (int j0 = 0; j0 < dcur.maxlen; j0 += kU) {
             int ci[kU];
             double a[kU];
             V g[kU];
+            // the row's next kU window indices (and value indices) are consecutive bytes of the staged stream at an
+            // arbitrary byte offset: ONE unaligned 8-byte LDS read each (two for 2-byte indices) instead of kU byte reads
+            // -- the LDS pipe is this kernel's busiest unit (profiles/r02_sweeps.md).  Slots past the row's end
+            // hold the following rows' bytes or stale LDS: index 0 is substituted, the product is skipped below.
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 int idx = o + j0 + u;
                 idx = idx < last ? idx : last;
-                if constexpr (CW == 8) ci[u] = c.sc[idx]; else ci[u] = sc16[idx];
+                if constexpr (CW == 8) ci[u] = c.sc[idx]; else ci[u] = reinterpret_cast<const unsigned short*>(c.sc)[idx];
                 if constexpr (VD) a[u] = c.sd[c.svi[idx]]; else a[u] = c.sv[idx];
             }
 #pragma unroll

@@ -160,6 +160,10 @@ class DeviceCSR:
                 'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
                 'window': bool(s & 4096), 'fused_comm': bool(s & 8192)}
 
+    def operator_bytes(self):
+        """Bytes of the operator as the device streams it (prcg.h: prcg_operator_bytes)."""
+        return int(self._lib.prcg_operator_bytes(self._h))
+
     def set_iteration(self, k):
         self._check(self._lib.prcg_set_iteration(self._h, int(k)))
 

@@ -267,3 +267,48 @@ def test_operator_cache_fingerprint_sees_sum_preserving_edits():
     f0 = _fingerprint(A)
     A.data[3], A.data[7] = A.data[3] + 1.0, A.data[7] - 1.0
     assert _fingerprint(A) != f0
+
+
+@pytest.mark.parametrize('name,rows', [('band', 64), ('lap2d', 64), ('lap3d', 128), ('ragged', 64)])
+def test_window_stream_images_are_shared_losslessly(name, rows):
+    """Tiles whose encoded streams (window indices, relative row pointers) are byte-identical read one stored copy:
+    a band keeps a handful of images for thousands of tiles, an irregular operator keeps every tile's own; either
+    way what a tile reads is exactly its own image (checked inside the library), and with sharing off the store is
+    the per-nonzero layout."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(9)
+    if name == 'band':
+        A = problems.banded_ex2b(40000, 7)
+    elif name == 'lap2d':
+        A = problems.laplace_2d(200, 160)
+    elif name == 'lap3d':
+        A = problems.laplace_3d(32, 32, 24)
+    else:
+        n = 6000
+        lens = rng.integers(1, 15, size=n)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        r = np.repeat(np.arange(n), lens)
+        A = sp.csr_matrix((np.ones(indptr[-1]), (r + rng.integers(-8, 9, size=r.size)).clip(0, n - 1).astype(np.int32), indptr),
+                          shape=(n, n))
+        A.sort_indices()
+    A = A.tocsr()
+    n = A.shape[0]
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    res = {}
+    for share in (1, 0):
+        out = np.zeros(8, dtype=np.int64)
+        assert L.lib().prcg_plan_window_images(n, n, L.ptr(indptr), L.ptr(indices), None, rows, share, L.ptr(out)) == 1
+        tiles, cw_images, rel_images, cw_elems, rel_elems, same = (int(v) for v in out[:6])
+        assert same == 1 and tiles >= n // rows
+        res[share] = (tiles, cw_images, rel_images, cw_elems, rel_elems)
+    tiles, cw_images, rel_images, cw_elems, rel_elems = res[1]
+    assert res[0][1] == tiles and res[0][2] == tiles                       # sharing off: one image per tile ...
+    assert A.nnz <= res[0][3] <= A.nnz + 48 and res[0][4] == n + tiles + 8  # ... laid out as the per-nonzero stream
+    if name == 'band':
+        assert cw_images <= 8 and rel_images <= 8 and cw_elems < 16000, res[1]
+    elif name in ('lap2d', 'lap3d'):
+        assert cw_images < 0.5 * tiles and cw_elems < 0.6 * A.nnz, res[1]
+    else:
+        assert cw_images > 0.9 * tiles, res[1]
+    print(f'{name}: {tiles} tiles, {cw_images} window-index images ({cw_elems} of {A.nnz} elements stored), {rel_images} row-pointer images')
