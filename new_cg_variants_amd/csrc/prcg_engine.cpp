@@ -1616,9 +1616,11 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         h->p_cur = h->p.d();
         h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0;
         HIPCHK(h, h->p2.ensure((h->hs_fused && h->win) ? (size_t)ne * D : 16, h->sc));
-        HIPCHK(h, h->r.ensure((size_t)n * D, h->sc));
+        // r (r~) is the staged-window source of the Hestenes-Stiefel product launch: like every vector that feeds a
+        // product it has the spare entries behind its end (a window page of the last tile may reach past row n)
+        HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
-        HIPCHK(h, h->rt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
+        HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
         if (h->prec) {

@@ -81,7 +81,9 @@ int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n
             if (have_col && have_own) c = std::min(cols[ci], own);
             else c = have_col ? cols[ci] : own;
             if (np == max_pages || np == kWinMaxPages) { fail = true; break; }
-            // keep the page inside the vector (its 64 entries are loaded unconditionally)
+            // keep the page inside the vector where possible (its 64 entries are loaded unconditionally); a page
+            // pushed behind the previous one may still end up to 63 entries past n_cols -- every vector that feeds
+            // a product is allocated with spare entries behind its end (kGatherPad, prcg_engine.cpp)
             if ((int64_t)c + 64 > n_cols) c = (int32_t)std::max<int64_t>(n_cols - 64, 0);
             if (np > 0 && c < page[np - 1] + 64) c = page[np - 1] + 64;   // pages never overlap
             page[np++] = c;

@@ -294,11 +294,13 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
 }
 
-// tiles in flight per wave (measured, profiles/r02_sweeps.md): the 2-byte-per-nonzero dictionary stream
-// gains 1-3 % from a second image; the plain 9-byte stream is at the memory system's rate for its
-// read/write mix with ONE (tools/membench.hip "fused-like": more requests in flight cost bandwidth)
+// tiles in flight per wave (measured, profiles/r02_sweeps.md).  With shared stream images the dictionary kernels
+// are no longer bound by bytes but by what one wave can overlap: MORE resident waves with ONE image each
+// (<= 128 VGPRs: 4 waves per SIMD) beat fewer waves with two (S3: 6.2 k it/s at 8 workgroups per CU, depth 1, vs
+// 4.6 k at 4, depth 2).  The plain 9-byte stream is at the memory system's rate for its read/write mix with ONE
+// (tools/membench.hip "fused-like": more requests in flight cost bandwidth)
 #ifndef PRCG_WIN_DEPTH_DICT
-#define PRCG_WIN_DEPTH_DICT 2
+#define PRCG_WIN_DEPTH_DICT 1
 #endif
 #ifndef PRCG_WIN_DEPTH_PLAIN
 #define PRCG_WIN_DEPTH_PLAIN 1
@@ -546,13 +548,12 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 constexpr int kWPB = 2;        // waves per workgroup
 constexpr int kWPBDefer = 4;   // ... of the deferred form: one wave on EACH SIMD of the CU, see defer_grid_per_cu
 
-// Workgroups per CU.  Upper bounds: what is truly co-resident (LDS is handed out per 80 KiB half of a
-// CU; the occupancy API knows the register limit) -- a persistent strided grid with queued workgroups
-// grows a serial tail.  Below that bound FEWER waves stream better here: every wave keeps DEPTH whole
-// tiles of coalesced loads in flight, and the two-vector kernels are at the memory system's mixed
-// read/write rate from 8 waves per CU on (profiles/r02_sweeps.md: S3 4 workgroups of 2 waves per CU
-// 4.8 k it/s, 8 per CU 4.5 k, S2 5.2 k vs 3.8 k); the single-vector kernels with the dictionary stream
-// (50 bytes per row) keep gaining up to 16 waves.
+// Workgroups per CU.  Upper bounds: what is truly co-resident (160 KiB of LDS per CU; the occupancy API
+// knows the register limit) -- a persistent strided grid with queued workgroups grows a serial tail (S3
+// dictionary kernel, 8 resident: 6.2 k it/s, 10 launched: 4.7 k).  Below that bound (profiles/r02_sweeps.md):
+// the dictionary kernels, whose stream images come from L2, want every resident wave (16 per CU at <= 128
+// VGPRs); the plain-value kernels are at the memory system's mixed read/write rate with 8 waves per CU and
+// lose with more (S3 plain: 4 workgroups per CU 2.70 k it/s, 6 per CU 2.52 k).
 template <typename K>
 int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
     int dev = 0, cus = 256, occ = 4;
@@ -561,7 +562,7 @@ int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 64 * wpb, 0) != hipSuccess || occ < 1) occ = 4;
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0) {
-            const int by_lds = 2 * (int)((80 * 1024) / fa.sharedSizeBytes);
+            const int by_lds = (int)((160 * 1024) / fa.sharedSizeBytes);
             if (by_lds >= 1 && by_lds < occ) occ = by_lds;
         }
         if (occ > 32 / wpb) occ = 32 / wpb;
@@ -580,7 +581,7 @@ int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
 // largest of them, rcclGenericKernel of RCCL 2.26 (rocprofv3 --kernel-trace): 256 threads = one wave per
 // SIMD, 132 VGPRs, 19,968 bytes of LDS.  With 4-wave workgroups every one of OUR workgroups also puts
 // exactly one wave on each SIMD, so b workgroups per CU leave 512 - b * vgprs registers on every SIMD;
-// LDS is handed out per 80 KiB half.  The bound below keeps room for one such workgroup on every CU
+// 160 KiB of LDS per CU.  The bound below keeps room for one such workgroup on every CU
 // (2-wave workgroups do not: two of them can land on the same SIMD pair and fill its register file --
 // seen as a stalled reduction with the 250-register 128-row geometry).
 int defer_grid_per_cu(const void* kernel) {
@@ -592,14 +593,16 @@ int defer_grid_per_cu(const void* kernel) {
     int best = 1;
     for (int b = 2; b <= 4; ++b) {
         const bool regs_ok = b * vg + kGuestVgprs <= 512;
-        const int lighter_half = b / 2;                          // workgroups in the emptier LDS half
-        const bool lds_ok = ((b + 1) / 2) * lds <= 80 * 1024 && lighter_half * lds + kGuestLds <= 80 * 1024;
+        const bool lds_ok = b * lds + kGuestLds <= 160 * 1024;
         if (regs_ok && lds_ok) best = b;
     }
     return best;
 }
 
-constexpr int kDeferTiles = 6;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
+#ifndef PRCG_DEFER_TILES
+#define PRCG_DEFER_TILES 4
+#endif
+constexpr int kDeferTiles = PRCG_DEFER_TILES;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
 
 template <int NV, int EPI, int M, int PG, int CW, bool DEFER = false>
 int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
@@ -616,13 +619,19 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
-    int tuned = (NV == 1 && vd) ? 8 : 4;
+    int tuned = vd ? 8 : 4;
     if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k));
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
     int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
     const int need = (ntiles + WPB - 1) / WPB;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    if (per_cu < 1) {
+        // every wave takes the same number of tiles: with few tiles per wave (S1: 7813 tiles on 3072 resident waves)
+        // the last, partly filled round of the strided loop would cost a whole tile time
+        const int waves = grid * WPB, rounds = (ntiles + waves - 1) / waves;
+        grid = ((ntiles + rounds - 1) / rounds + WPB - 1) / WPB;
+    }
     if (done)
         hipExtLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, nullptr, done, 0, A, reinterpret_cast<const int4*>(tiles), ntiles,
                               x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
