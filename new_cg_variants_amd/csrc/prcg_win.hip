@@ -545,7 +545,21 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     }
 }
 
-constexpr int kWPB = 2;        // waves per workgroup
+// Waves per workgroup.  Every workgroup of the one-launch iteration sums the previous launch's partial rows in its
+// prologue (one row per workgroup): B workgroups read B rows each, and at 2048 two-wave workgroups that was ~7 us
+// of a 160 us launch (S3), a quarter of a 37 us one (one eighth of S3).  Four-wave workgroups halve B at the same
+// number of resident waves (S3 +4 %, S1 +14 %, S3/8 +25 %, profiles/r02_sweeps.md) -- unless a four-wave
+// workgroup's LDS no longer lets two of them share a CU (the 12-page plain geometry: S2 plain -16 %), then two.
+constexpr int lds_bytes_per_wave(int nv, int pg, int cw, bool vd) {
+    return (vd ? 16 : kWinSlots * 8) + (vd ? kWinSlots : 16) + kWinSlots * (cw / 8) + (vd ? kWinDictMax * 8 : 16) + pg * 64 * 8 * nv;
+}
+constexpr int waves_per_block(int nv, int pg, int cw, bool vd) {
+#ifdef PRCG_WIN_WPB
+    return PRCG_WIN_WPB;
+#else
+    return 4 * lds_bytes_per_wave(nv, pg, cw, vd) <= 80 * 1024 ? 4 : 2;
+#endif
+}
 constexpr int kWPBDefer = 4;   // ... of the deferred form: one wave on EACH SIMD of the CU, see defer_grid_per_cu
 
 // Workgroups per CU.  Upper bounds: what is truly co-resident (160 KiB of LDS per CU; the occupancy API
@@ -604,22 +618,37 @@ int defer_grid_per_cu(const void* kernel) {
 #endif
 constexpr int kDeferTiles = PRCG_DEFER_TILES;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
 
+template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER>
+int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
+                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
+                 int per_cu, hipEvent_t done);
+
 template <int NV, int EPI, int M, int PG, int CW, bool DEFER = false>
 int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu, hipEvent_t done = nullptr)
 {
-    const bool vd = A.vidx8 != nullptr;
+    if (A.vidx8 != nullptr)
+        return launch_win_v<NV, EPI, M, PG, CW, true, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz,
+                                                             per_cu, done);
+    return launch_win_v<NV, EPI, M, PG, CW, false, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz,
+                                                          per_cu, done);
+}
+
+template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER>
+int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
+                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
+                 int per_cu, hipEvent_t done)
+{
     constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 4) : 0;
-    constexpr int WPB = DEFER ? kWPBDefer : kWPB;
-    auto k = vd ? k_win_tiles<NV, EPI, M, PG, CW, true, WPB, PRCG_WIN_DEPTH_DICT, DEF>
-                : k_win_tiles<NV, EPI, M, PG, CW, false, WPB, PRCG_WIN_DEPTH_PLAIN, DEF>;
+    constexpr int WPB = DEFER ? kWPBDefer : waves_per_block(win_nw(NV, EPI), PG, CW, vd);
+    auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
-    int tuned = vd ? 8 : 4;
+    int tuned = (vd ? 16 : 8) / WPB;        // resident waves per CU that stream best (see win_grid)
     if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k));
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
     int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
