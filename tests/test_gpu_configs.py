@@ -158,12 +158,15 @@ def test_window_kernels_on_randomised_bands_and_stencils(amd):
         else:
             A = P.laplace_3d(int(rng.integers(5, 30)), int(rng.integers(5, 30)), int(rng.integers(5, 20)))
         x = rng.standard_normal(A.shape[0])
-        op = amd['device'].DeviceCSR(A)
-        s = op.schedule()
-        seen.add((s['window'], s['col_bytes'], s['value_dict']))
-        products_bitexact(op, A, x, f'case {case}: n={A.shape[0]} nnz={A.nnz} {s}')
-        # and a few one-launch iterations against the two-kernel schedule (SPD not needed for that)
-        op.close()
+        sizes = {}
+        for share in ('1', '0'):           # tiles reading shared stream images / every tile its own
+            op = amd['device'].DeviceCSR(A, knobs={'PRCG_WIN_SHARE': share})
+            s = op.schedule()
+            seen.add((s['window'], s['col_bytes'], s['value_dict']))
+            products_bitexact(op, A, x, f'case {case}: n={A.shape[0]} nnz={A.nnz} share={share} {s}')
+            sizes[share] = op.operator_bytes()
+            op.close()
+        assert 0 < sizes['1'] <= sizes['0'] + 64, sizes
     assert {w for w, _, _ in seen} == {True, False} or all(w for w, _, _ in seen)
     assert {(True, 1, True), (True, 2, True)} <= seen, seen
 
