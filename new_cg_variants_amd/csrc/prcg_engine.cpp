@@ -159,6 +159,7 @@ struct prcg_handle {
     int k = 0;
     uint32_t hist_mask = 0;
     bool have_xtrue = false;
+    DevBuf r2, s2, rt2, st2;     // one-launch predict-and-recompute: the second copies of r, s (r~, s~ with Jacobi)
     DevBuf x, xp, p, p2, rs, rs2, rst, rst2, wu, wt, wv, r, s, rt, st, b, xt, dinv, e_ext;
     DevBuf w, u, tvec;           // cg_cg / gv: w (ghost room), u, t = A w~
     bool fused = false;          // this session runs the one-launch-per-iteration pipelined kernel
@@ -177,6 +178,9 @@ struct prcg_handle {
     bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: the current SpMM input pairs: rs / rs2 ((r,s)), with Jacobi rst / rst2 ((r~,s~))
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
+    bool pr_fused = false;       // non-pipelined predict-and-recompute (pr, m) on a window operator: ONE launch per iteration
+                                 // (window formed as (z - a zs) + b p_old); z, zs, p double-buffered:
+    double* cur_r = nullptr; double* cur_s = nullptr; double* cur_rt = nullptr; double* cur_st = nullptr;
     bool hs_fused = false;       // Hestenes-Stiefel without reduction launches: 2 launches per iteration on window
                                  // operators (update; product with the direction formed in the staged window), else 3
     double* p_cur = nullptr;     // ... the current direction: p / p2 (the product launch writes the other one)
@@ -427,6 +431,7 @@ int record(prcg_t* h, int k) {
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
     if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
     if (h->hs_fused) hs_flush(h);
+    if (h->pr_fused) fused_flush(h);
     if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     const int64_t n = h->n;
     int rc;
@@ -795,6 +800,43 @@ int iterate_hs_fused(prcg_t* h, int k) {
     return PRCG_OK;
 }
 
+// pr_cg.py:146-158 (pr_pcg, m_pcg) in ONE launch per iteration on a window operator (launch_win_pr_one): the
+// partials of launch k-1 are summed by every workgroup of launch k (as in iterate_pipe_fused), a and b follow,
+// the staged window of the new direction is formed from the old r~ (r), s~ (s), p, and the row's own vectors and
+// the five partials are written by the lane that summed the row.  r~ / s~ / p (r / s / p without Jacobi) are
+// double-buffered: other tiles still stage the old values.
+int iterate_pr_fused(prcg_t* h, int k) {
+    const bool jac = h->prec;
+    double*& z_cur = jac ? h->cur_rt : h->cur_r;
+    double*& zs_cur = jac ? h->cur_st : h->cur_s;
+    double* z_a = jac ? h->rt.d() : h->r.d();   double* z_b = jac ? h->rt2.d() : h->r2.d();
+    double* zs_a = jac ? h->st.d() : h->s.d();  double* zs_b = jac ? h->st2.d() : h->s2.d();
+    double* z_new = (z_cur == z_a) ? z_b : z_a;
+    double* zs_new = (zs_cur == zs_a) ? zs_b : zs_a;
+    double* p_new = (h->p_cur == h->p.d()) ? h->p2.d() : h->p.d();
+    FusedPrev f{};
+    if (h->pend_parts > 0 && h->pend_k == k - 1) {
+        f.prev_partials = h->pend_buf; f.nprev = h->pend_parts; f.dots_prev_out = dots_at(h, k - 1);
+    } else {
+        fused_flush(h);
+    }
+    f.dots_old = dots_at(h, k - 1);
+    f.pr.z_old = z_cur; f.pr.zs_old = zs_cur; f.pr.p_old = h->p_cur;
+    f.pr.z_new = z_new; f.pr.zs_new = zs_new; f.pr.p_new = p_new;
+    f.pr.x = h->x.d();
+    f.pr.r = jac ? h->r.d() : nullptr; f.pr.s = jac ? h->s.d() : nullptr; f.pr.d = jac ? h->dinv.d() : nullptr;
+    double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int grid = launch_win_pr_one(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f,
+                                       meurant(h->variant), part_out, coef_at(h, k), h->win_per_cu);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
+    z_cur = z_new; zs_cur = zs_new; h->p_cur = p_new;
+    return PRCG_OK;
+}
+
 PrArgs pr_args(prcg_t* h, int k) {
     PrArgs a{};
     a.n = h->n;
@@ -975,10 +1017,10 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
     switch (which) {
     case PRCG_VEC_X: *base = h->x.d(); return true;
     case PRCG_VEC_P: *base = h->p_cur; return true;
-    case PRCG_VEC_R: *base = h->r.d(); return true;
-    case PRCG_VEC_S: *base = h->s.d(); return true;
-    case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
-    case PRCG_VEC_ST: if (!h->prec || !is_pr(v)) return false; *base = h->st.d(); return true;
+    case PRCG_VEC_R: *base = h->cur_r; return true;
+    case PRCG_VEC_S: *base = h->cur_s; return true;
+    case PRCG_VEC_RT: if (!h->prec) return false; *base = h->cur_rt; return true;
+    case PRCG_VEC_ST: if (!h->prec || !is_pr(v)) return false; *base = h->cur_st; return true;
     default: return false;
     }
 }
@@ -1446,6 +1488,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->variant = variant;
     h->fused = false;
     h->hs_fused = false;
+    h->pr_fused = false;
     h->hs_pend_mu = 0;
     h->small = false;
     h->gather = false;
@@ -1615,13 +1658,22 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
         h->p_cur = h->p.d();
         h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0;
-        HIPCHK(h, h->p2.ensure((h->hs_fused && h->win) ? (size_t)ne * D : 16, h->sc));
         // r (r~) is the staged-window source of the Hestenes-Stiefel product launch: like every vector that feeds a
         // product it has the spare entries behind its end (a window page of the last tile may reach past row n)
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
-        HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->s.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
-        HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
+        HIPCHK(h, h->st.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
+        // one launch per iteration for pr / m on a window operator: second copies of what the window is formed from
+        h->pr_fused = is_pr(variant) && h->want_fused && !h->multi() && h->g == 0 && h->win;
+        HIPCHK(h, h->p2.ensure(((h->hs_fused && h->win) || h->pr_fused) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->r2.ensure((h->pr_fused && !h->prec) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->s2.ensure((h->pr_fused && !h->prec) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->rt2.ensure((h->pr_fused && h->prec) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->st2.ensure((h->pr_fused && h->prec) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->partC.ensure(h->pr_fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
+        h->cur_r = h->r.d(); h->cur_s = h->s.d(); h->cur_rt = h->rt.d(); h->cur_st = h->st.d();
+        h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
         if (h->prec) {
             launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r
@@ -1686,13 +1738,14 @@ int prcg_iterate(prcg_t* h, int iters) {
         else if (h->variant == PRCG_HS) rc = h->hs_fused ? iterate_hs_fused(h, k) : iterate_hs(h, k);
         else if (h->variant == PRCG_CG_CG) rc = iterate_cgcg(h, k);
         else if (h->variant == PRCG_GV) rc = iterate_gv(h, k);
-        else rc = iterate_pr(h, k);
+        else rc = h->pr_fused ? iterate_pr_fused(h, k) : iterate_pr(h, k);
         if (rc) return rc;
         if ((rc = record(h, k))) return rc;
         h->k = k;
     }
     if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
     if (h->hs_fused) hs_flush(h);
+    if (h->pr_fused) fused_flush(h);
     if (h->fused_comm && h->red_pending) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
@@ -1729,7 +1782,7 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
-    return ((h->fused || h->hs_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+    return ((h->fused || h->hs_fused || h->pr_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW

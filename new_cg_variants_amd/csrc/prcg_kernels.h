@@ -33,6 +33,15 @@ struct FusedPrev {
     int nt_int;       // tiles [nt_int, ntiles) touch ghost columns: they are neither computed nor even requested before
                       // the publication has arrived (the ghost rows travel with it)
     const double* dots_old;   // Hestenes-Stiefel product launch: the scalars of iteration k-1 (nu_k1 for b_k = nu_k / nu_k1)
+                              // (one-launch predict-and-recompute: the reduced scalars of k-1 when nprev == 0)
+    // one-launch predict-and-recompute iteration (launch_win_pr_one): the three vectors the window is formed from
+    // (z = r~ or r, zs = s~ or s, the direction p) are read from the *_old arrays and written to the *_new ones
+    // (other tiles still stage the old values); x -- and with Jacobi the plain r, s -- are updated in place
+    struct PrOne {
+        const double* z_old; const double* zs_old; const double* p_old;
+        double* z_new; double* zs_new; double* p_new;
+        double* x; double* r; double* s; const double* d;
+    } pr;
 };
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
 // the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row
@@ -62,7 +71,10 @@ enum SpmvEpilogue {
     kEpiPipeFusedJ = 6,  // ... Jacobi, 'pr' flavours: input (r~,s~); w~ = d w, u~ = d u in registers
     kEpiPipeFusedPJ = 7, // ... Jacobi, 'p' flavours
     kEpiHS = 8,      // window kernels only: the Hestenes-Stiefel product launch (launch_win_hs)
+    kEpiPROne = 9,   // window kernels only: one-launch predict-and-recompute iteration (launch_win_pr_one)
+    kEpiPROneJ = 10, // ... with Jacobi
 };
+constexpr bool epi_pr_one(int e) { return e == kEpiPROne || e == kEpiPROneJ; }
 constexpr bool epi_fused(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedP || e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_prec(int e) { return e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_recompute(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedJ; }
@@ -176,6 +188,17 @@ int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, i
 int launch_win_hs(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* z,
                   const double* p_old, double* p_new, double* s, double* partials, double* coef_out,
                   const FusedPrev& hs, int per_cu);
+// ONE launch per iteration of the non-pipelined predict-and-recompute variants (pr_cg.py:146-158; pr_pcg, m_pcg) on
+// a window operator.  These variants have ONE reduction per iteration, and everything the product needs from the
+// update is a linear combination of old vectors with coefficients known at the head of the launch (a, b from the
+// previous launch's partials -- predicted nu, pr_cg.py:149-150): the staged window of the new direction is FORMED
+// while it is parked, p = (z - a zs) + b p_old (the reference's `rt_k1 - a_k1 * st_k1` then `rt_k + b_k * p_k1`:
+// mul, sub, mul, add, four roundings), s = A p follows, and the row's own x, r, (r~), p, s, (s~) and the five
+// inner-product partials mu = p.s, dl = r.s~, gm = s~.s, nu = r~.r, r.r are written by the lane that summed the row.
+// f.pr: the vectors (see FusedPrev::PrOne; d null without Jacobi); f.prev_partials / nprev / dots_prev_out: as
+// launch_pipe_fused; f.dots_old: the reduced scalars of iteration k-1 when nprev == 0; coef_out: a, b, predicted nu.
+int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                      int meurant, double* partials, double* coef_out, int per_cu);
 
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {

@@ -71,9 +71,12 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 template <int NV> struct RegV;
 template <> struct RegV<1> { using type = double; };
 template <> struct RegV<2> { using type = d2_t; };
+typedef double d3_t __attribute__((ext_vector_type(3)));
+template <> struct RegV<3> { using type = d3_t; };
 // components per staged window entry AS LOADED: the Hestenes-Stiefel product launch loads (z, p_old) and stages
 // p = z + b p_old as one double
-constexpr int win_nw(int nv, int epi) { return epi == kEpiHS ? 2 : nv; }
+// (one-launch predict-and-recompute: (z, zs, p_old) -> p = (z - a zs) + b p_old)
+constexpr int win_nw(int nv, int epi) { return epi == kEpiHS ? 2 : (epi_pr_one(epi) ? 3 : nv); }
 template <int NV, int M, int PG, int CW, bool VD>
 struct WRegs {
     d2_t v[VD ? 1 : kWinSlots / 128];   // plain values: nonzeros alo + st*128 + lane*2 .. +2
@@ -85,12 +88,14 @@ struct WRegs {
     d2_t xp[M];                         // fused iteration: (x,p) of those rows
     d2_t rsx[M];                        // ... Jacobi: the plain (r,s) of those rows
     double dd[M], ww[M], wwt[M];        // ... Jacobi: 1/diag; 'p' flavours: the stored w, w~
+    d3_t zrow[M];                       // one-launch predict-and-recompute: (z, zs, p_old) of those rows; x in xp[].x, (r,s) in rsx[]
 };
 
 template <int NV, int EPI, int M, int PG, int CW, bool VD>
 __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
                                             const typename VecT<NV>::type* __restrict__ X, const double* __restrict__ X2,
-                                            const FusedRowPtrs& fr, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R) {
+                                            const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
+                                            WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -127,6 +132,9 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
     for (int p = 0; p < PG; ++p) {
         if (p < d.np) {                                                     // wave-uniform branch
             if constexpr (EPI == kEpiHS) { R.w[p].x = X[d.pc[p] + lane]; R.w[p].y = X2[d.pc[p] + lane]; }
+            else if constexpr (epi_pr_one(EPI)) {
+                R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane]; R.w[p].z = pr.p_old[d.pc[p] + lane];
+            }
             else R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];
         }
     }
@@ -137,6 +145,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         const int jj = row < d.re ? j * 64 + lane : 0;
         R.s[j] = A.rel[d.srcr + jj];                     // row pointers relative to the tile's first nonzero
         R.e[j] = A.rel[d.srcr + jj + 1];
+        if constexpr (epi_pr_one(EPI)) {
+            R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr];
+            R.xp[j].x = pr.x[rr];
+            if constexpr (EPI == kEpiPROneJ) { R.rsx[j].x = pr.r[rr]; R.rsx[j].y = pr.s[rr]; R.dd[j] = pr.d[rr]; }
+        }
         if constexpr (FUSED) {
             R.xp[j] = reinterpret_cast<const d2_t*>(fr.XP)[rr];
             if constexpr (epi_prec(EPI)) {
@@ -177,6 +190,7 @@ struct WCtx {
     void* yout; int write_mask;
     const double* ep_r; const double* ep_d; double* ep_st;
     FusedRowPtrs fr;
+    FusedPrev::PrOne pr;
     int lane;
 };
 
@@ -218,14 +232,22 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
         if (p < dcur.np) {
             // Hestenes-Stiefel: the direction is formed here, p = z + b p_old (hs_cg.py:60), never gathered
             if constexpr (EPI == kEpiHS) c.sw[p * 64 + lane] = R.w[p].x + cf.bt * R.w[p].y;
+            // predict-and-recompute: r~ -= a s~, then p = r~ + b p_old (pr_cg.py:148,151), formed here
+            else if constexpr (epi_pr_one(EPI)) c.sw[p * 64 + lane] = (R.w[p].x - cf.al * R.w[p].y) + cf.bt * R.w[p].z;
             else reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
         }
     }
     int rs_[M], re_[M];
     FusedRowIn fin[M];
+    d3_t zr[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         rs_[j] = R.s[j]; re_[j] = R.e[j];
+        if constexpr (epi_pr_one(EPI)) {
+            zr[j] = R.zrow[j];
+            fin[j].xp.x = R.xp[j].x;
+            if constexpr (EPI == kEpiPROneJ) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
+        }
         if constexpr (FUSED) {
             fin[j].xp = make_double2(R.xp[j].x, R.xp[j].y);
             if constexpr (epi_prec(EPI)) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
@@ -238,7 +260,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     if (have_next) {
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, R);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R);
     }
 
     // ---- lane i walks row i (and i + 64, ...) ----
@@ -279,6 +301,28 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
             // pair array comes from the staged window, the new pair goes to the other array
             const double2 in_old = c.sw[active ? dcur.own + j * 64 + lane : 0];
             if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, fin[j], in_old, c.fr, cf, acc);
+        } else if constexpr (epi_pr_one(EPI)) {
+            // the row's own update (pr_cg.py:146-148,151) with the same expressions as the staged window, then
+            // s = A p, s~ = d s and the partials of mu, dl, gm, nu, r.r (pr_cg.py:152-157)
+            if (active) {
+                const double xn = fin[j].xp.x + cf.al * zr[j].z;            // x += a p_old
+                const double zn = zr[j].x - cf.al * zr[j].y;                // r~ -= a s~   (r -= a s without Jacobi)
+                const double pn = zn + cf.bt * zr[j].z;                     // p = r~ + b p_old
+                c.pr.x[row] = xn;
+                c.pr.z_new[row] = zn;
+                c.pr.p_new[row] = pn;
+                if constexpr (EPI == kEpiPROneJ) {
+                    const double rn = fin[j].rs.x - cf.al * fin[j].rs.y;    // r -= a s
+                    const double stn = fin[j].d * sum;                      // s~ = M^-1 s
+                    c.pr.r[row] = rn;
+                    c.pr.s[row] = sum;
+                    c.pr.zs_new[row] = stn;
+                    acc[0] += pn * sum; acc[1] += rn * stn; acc[2] += stn * sum; acc[3] += zn * rn; acc[4] += rn * rn;
+                } else {
+                    c.pr.zs_new[row] = sum;
+                    acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
+                }
+            }
         } else if constexpr (EPI == kEpiHS) {
             // s = A p, mu += p_i s_i (hs_cg.py:61-62); the row's own p comes from the staged window and goes to p_new
             const double pn = c.sw[active ? dcur.own + j * 64 + lane : 0];
@@ -345,11 +389,12 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
                                   reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt},
-                     lane};
+                     fz.pr, lane};
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
-    if constexpr (FUSED && DEF == 0) {
+    constexpr bool PR1 = epi_pr_one(EPI);
+    if constexpr ((FUSED || PR1) && DEF == 0) {
         // inner products of the previous iteration: still one row of partials per block of the
         // previous launch -- every block of this launch sums them in the same fixed order
         // (thread t: rows t, t+B, ...; butterfly; waves in order), see prcg_kernels.hip
@@ -377,7 +422,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             __syncthreads();
             cf = predict(dsum, (write_mask >> 2) & 1);
         } else {
-            cf = predict(ep_r, (write_mask >> 2) & 1);
+            cf = predict(PR1 ? fz.dots_old : ep_r, (write_mask >> 2) & 1);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
     }
@@ -415,7 +460,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         pend[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, R[i]);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i]);
             else pend[i] = true;
         }
     }
@@ -478,7 +523,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         for (int i = 0; i < DEPTH; ++i)
             if (pend[i]) {
                 if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, R[i]);
+                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i]);
                 pend[i] = false;
             }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -538,6 +583,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     }
 
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
+    else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
@@ -707,6 +753,18 @@ int launch_win_hs(hipStream_t st, const WinDev& A, const WTile* tiles, int ntile
 {
     if (ntiles <= 0) return 0;
     return launch_win<1, kEpiHS>(geom, st, A, tiles, ntiles, z, s, 3, p_old, nullptr, p_new, partials, coef_out, hs, per_cu);
+}
+
+int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                      int meurant, double* partials, double* coef_out, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    const int mask = 3 | (meurant ? 4 : 0);
+    if (f.pr.d)
+        return launch_win<1, kEpiPROneJ>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, f.pr.d, nullptr, partials,
+                                         coef_out, f, per_cu);
+    return launch_win<1, kEpiPROne>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, nullptr, nullptr, partials,
+                                    coef_out, f, per_cu);
 }
 
 int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,

@@ -42,6 +42,9 @@ class _LazyMatrices(dict):
         self[name] = load_matrix(name)
         return self[name]
 
+    def __contains__(self, name):
+        return dict.__contains__(self, name) or os.path.exists(os.path.join(GOLDEN, f'matrix_{name}.npz'))
+
 
 @pytest.fixture(scope='session')
 def matrices():

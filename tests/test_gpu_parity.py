@@ -456,6 +456,69 @@ def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant, pr
     print(f'{matrix}/{variant}/{prec}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
+@pytest.mark.parametrize('source,variant,prec,knobs', [
+    ('bcsstk03', 'PR', None, {}), ('nos7', 'PR', 'jacobi', {}), ('494_bus', 'M', 'jacobi', {}), ('nos4', 'M', None, {}),
+    ('s3_small', 'PR', None, {}), ('s3_small', 'M', None, {'PRCG_VALDICT': '0'}), ('s1_small', 'PR', 'jacobi', {}),
+    ('lap3d_20', 'PR', None, {'PRCG_VALDICT': '0'})])
+def test_one_launch_predict_and_recompute(amd, matrices, source, variant, prec, knobs):
+    """pr_cg / m_cg (pr_pcg, m_pcg) on a window operator run ONE launch per iteration: the staged window of the new
+    direction is formed as (r~ - a s~) + b p_old while it is parked (pr_cg.py:148,151), s = A p follows, the row's own
+    x, r, r~, p, s, s~ and the five partials come out of the same lane.  Same arithmetic per element as the four-launch
+    schedule (PRCG_FUSED=0: update kernel, product, two reductions), different summation order of the inner
+    products: forced single steps from identical state agree bit for bit in every vector and to 1e-12 in the
+    scalars; free-running solves (iterate calls of any length, recorders in between) agree at convergence level."""
+    L = amd['L']
+    from oracle import ne_oracle as orc
+    if source in matrices:
+        A, z = matrices[source]
+        b, x_true = z['b'], z['x_true']
+    else:
+        A = amd['problems'].laplace_3d(20, 20, 20) if source == 'lap3d_20' else amd['problems'].WORKLOADS[source]['make']()
+        b, _, x_true = amd['problems'].reference_rhs(A, A.shape[0])
+    n = A.shape[0]
+    inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
+    for op in ops:
+        op.begin(getattr(L, variant), b, np.zeros(n), 64, inv_diag=inv_diag)
+    assert ops[0].schedule()['fused'] and ops[0].schedule()['window'] and not ops[1].schedule()['fused']
+    stored = ['x', 'r', 'p', 's'] + (['rt', 'st'] if prec else [])
+    worst = 0.0
+    for k in range(40):
+        st = {v: ops[1].get_vector(v) for v in stored}
+        sc = ops[1].get_scalars(k)
+        for v, a in st.items():
+            ops[0].set_vector(v, a)
+        ops[0].set_scalars(k, sc)
+        ops[0].set_iteration(k)
+        for op in ops:
+            op.iterate(1)
+        for v in stored:
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
+        a, c = ops[0].get_scalars(k + 1)[:5], ops[1].get_scalars(k + 1)[:5]
+        if not np.all(np.isfinite(c)) or np.any(c == 0):
+            break                       # converged to breakdown (0/0): nothing left to compare
+        worst = max(worst, float(np.max(np.abs(a - c) / np.abs(c))))
+        assert np.array_equal(ops[0].get_coefficients(k + 1), ops[1].get_coefficients(k + 1), equal_nan=True)
+    assert k >= 8 and worst <= 1e-12, (k, worst)
+    # free running, chunked, with the error recorder in between
+    total = 400 if source in ('bcsstk03', 'nos4') else 150
+    hist = []
+    for op in ops:
+        op.begin(getattr(L, variant), b, np.zeros(n), total + 1, x_true=x_true, inv_diag=inv_diag, hist_mask=L.HIST_UPDATED_RESIDUAL_2_NORM | L.HIST_ERROR_A_NORM)
+        for chunk in (1, 7, 1, total - 9):
+            op.iterate(chunk)
+        op.sync()
+        hist.append(op.history())
+        op.close()
+    for q in hist[1]:
+        np.testing.assert_allclose(hist[0][q][:6], hist[1][q][:6], rtol=1e-11, err_msg=q)
+    ia, aa = orc.convergence_summary(hist[0]['error_A_norm'])
+    ib, ab = orc.convergence_summary(hist[1]['error_A_norm'])
+    assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 1.0, ((ia, aa), (ib, ab))
+    print(f'{source}/{variant}/{prec}: one launch vs four, 40 forced steps, worst scalar deviation {worst:.2e}; '
+          f'free running {total} iterations: its-to-1e-5 {ia} vs {ib}, log10 min error {aa:.2f} vs {ab:.2f}')
+
+
 @pytest.mark.parametrize('source,prec,knobs', [
     ('s3_small', None, {}), ('s3_small', 'jacobi', {}), ('s3_small', None, {'PRCG_VALDICT': '0'}),
     ('s1_small', None, {}), ('lap3d_20', 'jacobi', {}), ('lap3d_20', None, {'PRCG_VALDICT': '0'}),
