@@ -187,16 +187,28 @@ def main():
     K, W = args.steps, args.warmup
 
     def timed_run(dev):
-        dev.begin(variant, b, x0, PREWARM + W + K + 1, inv_diag=inv_diag)
-        dev.iterate(PREWARM + W)
-        dev.sync()
+        """(elapsed, host enqueue time, kernel timings, residual finite, error).  A library error (a one-launch
+        iteration of a communicator session that waited longer than its bound for the reduction) is RETURNED, not
+        raised: every rank must reach the barriers below, and the decision what to do next is taken collectively."""
+        err = None
+        try:
+            dev.begin(variant, b, x0, PREWARM + W + K + 1, inv_diag=inv_diag)
+            dev.iterate(PREWARM + W)
+            dev.sync()
+        except L.PrcgError as exc:
+            err = str(exc)
         dev.set_profiling(max(1, K // 100))
         comm.Barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dev.iterate(K)
-        t_enq = time.perf_counter() - t0      # host time to enqueue K iterations (no sync inside)
-        dev.sync()
+        t_enq = 0.0
+        if err is None:
+            try:
+                dev.iterate(K)
+                t_enq = time.perf_counter() - t0      # host time to enqueue K iterations (no sync inside)
+                dev.sync()
+            except L.PrcgError as exc:
+                err = str(exc)
         torch.cuda.synchronize()
         comm.Barrier()
         elapsed = time.perf_counter() - t0
@@ -204,7 +216,11 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, t_enq, dev.timings(), bool(np.isfinite(dev.get_scalars(PREWARM + W + K)[L.S_NU]))
+            err = next((e for e in comm.allgather_obj(err) if e), None)
+        if err is not None:
+            return elapsed, t_enq, None, False, err
+        finite = bool(np.isfinite(dev.get_scalars(PREWARM + W + K)[L.S_NU]))
+        return elapsed, t_enq, dev.timings(), finite, None
 
     def product_rates(dev, sched):
         """Standalone SpMV / two-vector SpMM of the resident operator (north_star: effective SpMV HBM GB/s)."""
@@ -223,7 +239,21 @@ def main():
                 'spmm2_ms': ms2, 'spmm2_moved_GBps': m2 / ms2 * 1e-6, 'spmm2_frac_of_peak': m2 / ms2 * 1e-6 / HBM_PEAK_GBS,
                 'spmm2_algorithmic_GBps': b2 / ms2 * 1e-6}
 
-    elapsed, t_enq, tim, finite = timed_run(dev)
+    elapsed, t_enq, tim, finite, run_err = timed_run(dev)
+    fallback = None
+    if run_err is not None:
+        # the one-launch schedule of a communicator session could not be kept fed on this node (its waits are
+        # bounded and reported): every rank rebuilds its operator with the two-kernel schedule and the run is repeated
+        fallback = run_err
+        dev.close()
+        if world == 1 and args.force_comm:
+            dev = one_rank_comm_device({'PRCG_FUSED_COMM': '0'})
+        else:
+            op = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0'})
+            dev = op.dev
+        elapsed, t_enq, tim, finite, run_err = timed_run(dev)
+        if run_err is not None:
+            raise RuntimeError(run_err)
     sched = dev.schedule()
     spmv = product_rates(dev, sched) if world == 1 else None
 
@@ -233,7 +263,7 @@ def main():
     plain = None
     if world == 1 and not args.force_comm and sched['value_dict'] and not args.no_plain_values:
         dev2 = DeviceCSR(A_rows.tocsr(), device=local_rank, knobs={'PRCG_VALDICT': '0'})
-        e2, _, tim2, fin2 = timed_run(dev2)
+        e2, _, tim2, fin2, _err2 = timed_run(dev2)
         sched2 = dev2.schedule()
         plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2), dev2.operator_bytes())
         dev2.close()
@@ -244,7 +274,9 @@ def main():
     if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant.startswith('pipe_'):
         try:
             dev3 = one_rank_comm_device()
-            e3, q3, tim3, fin3 = timed_run(dev3)
+            e3, q3, tim3, fin3, err3 = timed_run(dev3)
+            if err3:
+                raise RuntimeError(err3)
             s3 = dev3.schedule()
             multi = {'what': 'same workload and steps through the schedule every rank of an N>1 run executes, driven by a 1-rank RCCL '
                              'communicator: ' + ('one launch per iteration that waits in-kernel for the reduction the communication '
@@ -319,6 +351,7 @@ def main():
                        'partition': f'row blocks x{world}' + (' (nnz-balanced)' if world > 1 and args.workload in ('s4', 'queen') else ''), 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
                        'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6,
                        'operator_setup_s': t_setup, 'prewarm_steps': PREWARM,
+                       'schedule_fallback': fallback,
                        'schedule': {k: v for k, v in sched.items()}},
             'roofline': roof,
         }

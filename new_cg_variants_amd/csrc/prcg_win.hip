@@ -29,6 +29,9 @@
 namespace prcg {
 namespace {
 
+#ifndef PRCG_WAIT_SPINS
+#define PRCG_WAIT_SPINS (1u << 23)   // polls (~1 us apart) before a waiting wave gives up and flags the session
+#endif
 #ifndef PRCG_WIN_UNROLL
 #define PRCG_WIN_UNROLL 8
 #endif
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // sticky: never wait twice
             while (!timed_out && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fz.want) < 0) {
                 __builtin_amdgcn_s_sleep(32);                                 // ~1 us between polls
-                if (++spins > (1u << 23)) timed_out = true;                  // ~10 s: a stalled peer, not a slow one
+                if (++spins > PRCG_WAIT_SPINS) timed_out = true;             // ~10 s: a stalled peer, not a slow one
             }
             if (timed_out && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             double dp[4];

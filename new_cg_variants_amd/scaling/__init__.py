@@ -80,7 +80,7 @@ class SelfComm:
 class RowBlockOperator:
     """The rank's row block on its GPU, halo plan and RCCL communicator included."""
 
-    def __init__(self, comm, A_rows, device=None, rccl_path=None):
+    def __init__(self, comm, A_rows, device=None, rccl_path=None, knobs=None):
         self.comm = comm
         rank, size = comm.Get_rank(), comm.Get_size()
         n_local, n = A_rows.shape
@@ -118,7 +118,7 @@ class RowBlockOperator:
         else:
             A_local = A_rows.tocsr()
             self.ghost_ids = np.zeros(0, dtype=np.int64)
-        self.dev = DeviceCSR(A_local, device=device, comm_init=comm_init, halo=halo)
+        self.dev = DeviceCSR(A_local, device=device, comm_init=comm_init, halo=halo, knobs=knobs)
 
 
 def _as_operator(comm, A):
