@@ -144,6 +144,11 @@ def _timed(comm, op, variant, b, max_iter):
     times = {'tot': 0., 'c_ip': 0., 'c_mv': 0., 'w_mv': 0., 'w_ip': 0., 'w_vec': 0.} if rank == 0 else None
     # x0 = 0, r0 = p0 = b; one extra history slot because the reference's loop body runs
     # max_iter times (pipe_pr_cg.py:58), not max_iter - 1
+    # (HIP loads a kernel's code object on its first launch -- tens of milliseconds per variant: two untimed
+    #  iterations of a throw-away session touch every kernel of the loop before the clock starts)
+    dev.begin(variant, b, np.zeros_like(b), 4)
+    dev.iterate(2)
+    dev.sync()
     dev.begin(variant, b, np.zeros_like(b), max_iter + 1)
     comm.Barrier()
     t0 = time.perf_counter()
