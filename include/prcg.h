@@ -185,6 +185,16 @@ int prcg_iteration(const prcg_t* h);
                                       for the reduced inner products of the previous iteration */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
+/* A preconditioner that is not a diagonal scaling: `fn(ctx, n, v, out)` must write M^-1 v to out (host buffers,
+ * n doubles each; return 0).  It stands for the `preconditioner` callable of the reference's *_pcg functions
+ * (numerical_experiments/cg_variants/hs_cg.py:70, pr_cg.py:93, pipe_pr_cg.py:109, cg_cg.py:74, gv_cg.py:87), which
+ * is the caller's code there too.  Sessions begun with inv_diag == NULL while a function is set call it wherever
+ * the reference calls `preconditioner(...)`: the vector goes to the host, the result comes back -- two PCIe copies
+ * and a stream synchronisation per application (1 per iteration for hs / cg_cg / gv / pr / m and the 'p' pipelined
+ * flavours, 2 for the 'pr' pipelined flavours), on the schedules in which every tilde vector is a stored vector.
+ * Single GPU.  fn == NULL removes it.  Jacobi stays on the device: pass inv_diag to prcg_solve_begin instead. */
+typedef int (*prcg_prec_fn)(void* ctx, int64_t n, const double* v, double* out);
+int prcg_set_preconditioner(prcg_t* h, prcg_prec_fn fn, void* ctx);
 int prcg_schedule(const prcg_t* h);
 /* Bytes of the operator AS THE DEVICE STREAMS IT (the lossless re-encodings of the caller's CSR built at
  * prcg_set_csr: narrow column / window indices, value-dictionary indices, relative row pointers, tile

@@ -61,6 +61,7 @@ _SIGNATURES = {
     'prcg_iterate': (C.c_int, [_P, C.c_int]),
     'prcg_sync': (C.c_int, [_P]),
     'prcg_iteration': (C.c_int, [_P]),
+    'prcg_set_preconditioner': (C.c_int, [_P, _P, _P]),
     'prcg_schedule': (C.c_int, [_P]),
     'prcg_operator_bytes': (C.c_int64, [_P]),
     'prcg_set_iteration': (C.c_int, [_P, C.c_int]),
@@ -80,6 +81,8 @@ _SIGNATURES = {
     'prcg_plan_window_images': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.c_int, _P]),
     'prcg_tile_caps': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
+
+PREC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))   # prcg_prec_fn
 
 _lib = None
 

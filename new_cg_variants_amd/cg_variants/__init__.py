@@ -69,24 +69,25 @@ def clear_operator_cache():
 
 
 def _diagonal_of(preconditioner, n):
-    """Recover d with M^-1 v = d * v, or None for the identity.  The probe is exact for
-    a diagonal scaling: M^-1 applied to ones IS d, bit for bit."""
+    """(d, None) with M^-1 v = d * v for a diagonal scaling (d None: the identity), or (None, preconditioner)
+    for anything else.  The probe is exact for a diagonal scaling: M^-1 applied to ones IS d, bit for bit.
+    A diagonal runs on the device; any other callable is called on the host wherever the reference calls
+    `preconditioner(...)` -- it is the caller's code there too (prcg.h: prcg_set_preconditioner)."""
     if preconditioner is None:
-        return None
+        return None, None
     d = getattr(preconditioner, 'inv_diag', None)
     if d is not None:
-        return L.f64(d)
+        return L.f64(d), None
     ones = np.ones(n)
     d = np.asarray(preconditioner(ones), dtype=np.float64)
     if d.shape != (n,):
-        raise NotImplementedError('preconditioner must map (n,) to (n,)')
+        raise ValueError('preconditioner must map (n,) to (n,)')
     probe = np.random.default_rng(12345).standard_normal(n)
     if not np.array_equal(np.asarray(preconditioner(probe)), d * probe):
-        raise NotImplementedError(
-            'only diagonal (Jacobi) preconditioners run on the device; no host fallback exists')
+        return None, preconditioner
     if np.all(d == 1.0):
-        return None
-    return np.ascontiguousarray(d)
+        return None, None
+    return np.ascontiguousarray(d), None
 
 
 class Jacobi:
@@ -124,7 +125,7 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
         A = A.tocsr()
     n = A.shape[0]
     op = _operator(A, device)
-    inv_diag = _diagonal_of(preconditioner, n)
+    inv_diag, prec_fn = _diagonal_of(preconditioner, n)
 
     mask = 0
     foreign = []          # callables we must call ourselves, every iteration
@@ -145,7 +146,7 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
         kwargs['x_true'] = x_true
 
     output = {'name': name, 'max_iter': max_iter}
-    op.begin(variant, b, x0, max_iter, x_true=x_true, inv_diag=inv_diag, hist_mask=mask)
+    op.begin(variant, b, x0, max_iter, x_true=x_true, inv_diag=inv_diag, hist_mask=mask, preconditioner=prec_fn)
 
     def call_host(k):
         env = {'output': output, 'k': k, 'max_iter': max_iter, 'A': A, 'b': b, 'x0': x0, 'n': n,
@@ -155,7 +156,7 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
         if not foreign:
             return
         op.sync()
-        for v in _state_vectors(variant, inv_diag is not None):
+        for v in _state_vectors(variant, inv_diag is not None or prec_fn is not None):
             env[_STATE_NAMES[v]] = op.get_vector(v)
         sc = op.get_scalars(k)
         env.update(nu_k=sc[L.S_NU], mu_k=sc[L.S_MU], del_k=sc[L.S_DELTA], gam_k=sc[L.S_GAMMA])

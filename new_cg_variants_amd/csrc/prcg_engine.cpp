@@ -178,6 +178,11 @@ struct prcg_handle {
     bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: the current SpMM input pairs: rs / rs2 ((r,s)), with Jacobi rst / rst2 ((r~,s~))
     DevBuf partC;                // fused: second partials buffer (ping-pong with partB)
+    // host-callback preconditioner (prcg_set_preconditioner): M^-1 v is computed by the caller's function on host
+    // copies of v; sessions that use it run the schedules in which every tilde vector is a stored vector
+    prcg_prec_fn cb = nullptr; void* cb_ctx = nullptr; bool cb_session = false;
+    std::vector<double> cb_in, cb_out;
+    DevBuf cb_stage, ut;         // staging for strided operands; u~ = M^-1 u of the pipelined variants
     bool pr_fused = false;       // non-pipelined predict-and-recompute (pr, m) on a window operator: ONE launch per iteration
                                  // (window formed as (z - a zs) + b p_old); z, zs, p double-buffered:
     double* cur_r = nullptr; double* cur_s = nullptr; double* cur_rt = nullptr; double* cur_st = nullptr;
@@ -424,6 +429,7 @@ double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride
 
 void fused_flush(prcg_t* h);
 void hs_flush(prcg_t* h);
+int apply_prec(prcg_t* h, const double* src, int sstride, double* dst, int dstride);
 
 // ---- history recorders for the state of iteration k (compute stream) -------------------
 int record(prcg_t* h, int k) {
@@ -490,6 +496,11 @@ int pipe_spmm_and_reduce(prcg_t* h, int k, int grid_upd, bool profile) {
         if (profile) prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
         LAUNCHCHK(h, eng_spmm2(h, h->sc, 0, in_ext, h->wu.d(), mask));
         if (profile) prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        if (h->cb_session) {
+            // u~ = preconditioner(u); w~ = preconditioner(w) in the flavours that recompute w (pipe_pr_cg.py:178-182)
+            if ((rc = apply_prec(h, h->wu.d() + 1, 2, h->ut.d(), 1))) return rc;
+            if (pipe_recompute(h->variant) && (rc = apply_prec(h, h->wu.d(), 2, h->wt.d(), 1))) return rc;
+        }
         return PRCG_OK;
     }
     if (h->gather) {
@@ -577,7 +588,8 @@ PipeUpdateArgs pipe_args(prcg_t* h, int k) {
     a.xp = h->xp.d();
     a.rs = h->rs.d(); a.rst = h->prec ? h->rst.d() : nullptr;
     a.wu = h->wu.d(); a.wt = h->wt.d();
-    a.d = h->prec ? h->dinv.d() : nullptr;
+    a.d = (h->prec && !h->cb_session) ? h->dinv.d() : nullptr;
+    a.ut = h->cb_session ? h->ut.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.coef_out = coef_at(h, k);
     a.partials = h->partA.d();
@@ -724,7 +736,7 @@ HsArgs hs_args(prcg_t* h, int k) {
     HsArgs a{};
     a.n = h->n;
     a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
-    a.p = h->p_cur; a.s = h->s.d(); a.d = h->prec ? h->dinv.d() : nullptr;
+    a.p = h->p_cur; a.s = h->s.d(); a.d = (h->prec && !h->cb_session) ? h->dinv.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.dots_cur = dots_at(h, k);
     a.coef_out = coef_at(h, k);
@@ -741,7 +753,15 @@ int iterate_hs(prcg_t* h, int k) {
     LAUNCHCHK(h, g1);
     prof_end(h, h->ev_upd, h->n_ev_upd, on);
     launch_reduce_final(h->sc, h->partA.d(), g1, dots_at(h, k), PRCG_S_NU, PRCG_S_NU, 2);
-    int rc = allreduce(h, dots_at(h, k) + PRCG_S_NU, 2, h->sc);          // reduction 1: nu
+    int rc;
+    if (h->cb_session) {
+        // r~ = preconditioner(r) on the host (hs_pcg :118), then nu = r~.r as an inner product of its own
+        if ((rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;
+        const int g2 = launch_dot(h->sc, h->rt.d(), h->r.d(), h->n, h->partB.d(), 0);
+        LAUNCHCHK(h, g2);
+        launch_reduce_final(h->sc, h->partB.d(), g2, dots_at(h, k), 0, PRCG_S_NU, 1);
+    }
+    rc = allreduce(h, dots_at(h, k) + PRCG_S_NU, 2, h->sc);              // reduction 1: nu
     if (rc) return rc;
     LAUNCHCHK(h, launch_hs_update_p(h->sc, a));
     int nparts = 0;
@@ -853,8 +873,21 @@ PrArgs pr_args(prcg_t* h, int k) {
 int pr_spmv_and_reduce(prcg_t* h, int k, int grid_upd) {
     // s = A p; s~ = M^-1 s; mu, delta, gamma ride on the SpMV (pr_cg.py:152-157)
     int nparts = 0;
-    int rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
-                             h->prec ? h->st.d() : nullptr, &nparts);
+    int rc;
+    if (h->cb_session) {
+        // s = A p; s~ = preconditioner(s) on the host; mu, delta, gamma as inner products of their own
+        if ((rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiNone, nullptr, nullptr, nullptr, &nparts))) return rc;
+        if ((rc = apply_prec(h, h->s.d(), 1, h->st.d(), 1))) return rc;
+        int g = launch_dot(h->sc, h->p.d(), h->s.d(), h->n, h->partB.d(), 0);
+        LAUNCHCHK(h, g);
+        LAUNCHCHK(h, launch_dot(h->sc, h->r.d(), h->st.d(), h->n, h->partB.d(), 1));
+        LAUNCHCHK(h, launch_dot(h->sc, h->st.d(), h->s.d(), h->n, h->partB.d(), 2));
+        launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), PRCG_S_NU, PRCG_S_NU, 2);
+        launch_reduce_final(h->sc, h->partB.d(), g, dots_at(h, k), 0, 0, 3);
+        return allreduce(h, dots_at(h, k), 5, h->sc);
+    }
+    rc = overlapped_spmv(h, k, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
+                         h->prec ? h->st.d() : nullptr, &nparts);
     if (rc) return rc;
     launch_reduce_final(h->sc, h->partA.d(), grid_upd, dots_at(h, k), PRCG_S_NU, PRCG_S_NU, 2);
     launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, 0, 3);
@@ -881,7 +914,7 @@ CgArgs cg_args(prcg_t* h, int k) {
     a.u = h->variant == PRCG_GV ? h->u.d() : nullptr;
     a.t = h->tvec.d();
     a.z = h->prec ? h->rt.d() : h->r.d();
-    a.d = h->prec ? h->dinv.d() : nullptr;
+    a.d = (h->prec && !h->cb_session) ? h->dinv.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.dots_cur = dots_at(h, k);
     a.dots_cur_w = dots_at(h, k);
@@ -899,7 +932,9 @@ int iterate_cgcg(prcg_t* h, int k) {
     prof_end(h, h->ev_upd, h->n_ev_upd, on);
     double* z = h->prec ? h->rt.d() : h->r.d();
     int nparts = 0;
-    int rc = overlapped_spmv(h, k, z, h->w.d(), kEpiCG, h->r.d(), nullptr, nullptr, &nparts);   // w = A r~; nu, eta
+    int rc;
+    if (h->cb_session && (rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;   // r~ = preconditioner(r)  cg_cg.py:118
+    rc = overlapped_spmv(h, k, z, h->w.d(), kEpiCG, h->r.d(), nullptr, nullptr, &nparts);   // w = A r~; nu, eta
     if (rc) return rc;
     launch_reduce_final(h->sc, h->partB.d(), nparts, dots_at(h, k), 0, 0, 5);
     if ((rc = allreduce(h, dots_at(h, k), 5, h->sc))) return rc;
@@ -916,6 +951,7 @@ int iterate_gv(prcg_t* h, int k) {
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_upd, h->n_ev_upd, on);
     int rc;
+    if (h->cb_session && (rc = apply_prec(h, h->w.d(), 1, h->wt.d(), 1))) return rc;  // w~ = preconditioner(w)  gv_cg.py:161
     const bool side = h->multi();
     if (side) {
         HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
@@ -976,6 +1012,27 @@ int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
 int d2h(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->sc));
     HIPCHK(h, hipStreamSynchronize(h->sc));
+    return PRCG_OK;
+}
+
+// dst = M^-1 src: the inverse diagonal on the device, or the caller's function on the host (the reference's
+// `preconditioner(v)`, figure_gen.py:42-44 -- there, too, it is the caller's Python callable).
+int apply_prec(prcg_t* h, const double* src, int sstride, double* dst, int dstride) {
+    const int64_t n = h->n;
+    if (!h->cb_session) {
+        launch_mul(h->sc, dst, dstride, h->dinv.d(), 1, src, sstride, n);
+        return PRCG_OK;
+    }
+    h->cb_in.resize((size_t)n); h->cb_out.resize((size_t)n);
+    const double* dsrc = src;
+    if (sstride != 1) { launch_copy(h->sc, h->cb_stage.d(), 1, src, sstride, n); dsrc = h->cb_stage.d(); }
+    int rc = d2h(h, h->cb_in.data(), dsrc, n);
+    if (rc) return rc;
+    if (h->cb(h->cb_ctx, n, h->cb_in.data(), h->cb_out.data()) != 0)
+        return fail(h, PRCG_EINVAL, "the preconditioner callback reported a failure");
+    if (dstride == 1) return h2d(h, dst, h->cb_out.data(), n);
+    if ((rc = h2d(h, h->cb_stage.d(), h->cb_out.data(), n))) return rc;
+    launch_copy(h->sc, dst, dstride, h->cb_stage.d(), 1, n);
     return PRCG_OK;
 }
 
@@ -1092,6 +1149,13 @@ void prcg_destroy(prcg_t* h) {
     if (h->sm) (void)hipStreamDestroy(h->sm);
     if (h->sh) (void)hipStreamDestroy(h->sh);
     delete h;
+}
+
+int prcg_set_preconditioner(prcg_t* h, prcg_prec_fn fn, void* ctx) {
+    if (!h) return PRCG_EINVAL;
+    h->cb = fn;
+    h->cb_ctx = ctx;
+    return PRCG_OK;
 }
 
 int prcg_set_option(prcg_t* h, const char* key, const char* value) {
@@ -1492,7 +1556,10 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->hs_pend_mu = 0;
     h->small = false;
     h->gather = false;
-    h->prec = inv_diag != nullptr;
+    h->cb_session = h->cb != nullptr && inv_diag == nullptr;
+    h->prec = inv_diag != nullptr || h->cb_session;
+    CHECK(h, !(h->cb_session && h->multi()), "a host-callback preconditioner runs on one GPU only");
+    if (h->cb_session) HIPCHK(h, h->cb_stage.ensure((size_t)h->n * sizeof(double), h->sc));
     h->max_iter = max_iter;
     h->hist_mask = hist_mask;
     h->have_xtrue = x_true != nullptr;
@@ -1520,7 +1587,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
 
     if (is_pipe(variant)) {
-        h->fused = h->want_fused && !h->multi() && h->g == 0;
+        h->fused = h->want_fused && !h->multi() && h->g == 0 && !h->cb_session;
         // with a communicator: the same kernel in its deferred form (window operators only)
         h->fused_comm = false;
         h->red_pending = false;
@@ -1549,6 +1616,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         if (h->prec) h->rs_cur = h->rst.d();
         HIPCHK(h, h->wu.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->wt.ensure(h->prec ? (size_t)n * D : 16, h->sc));
+        HIPCHK(h, h->ut.ensure(h->cb_session ? (size_t)n * D : 16, h->sc));
         double* RS = h->rs.d();
         double* WU = h->wu.d();
         double* XP = h->xp.d();
@@ -1565,17 +1633,18 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             launch_copy(sc, WU + 1, 2, t1, 1, n);                           // u = A w        :28
         } else {
             double* RST = h->rst.d();
-            launch_mul(sc, RST, 2, h->dinv.d(), 1, RS, 2, n);               // r~ = M^-1 r    :124
+            if ((rc = apply_prec(h, RS, 2, RST, 2))) return rc;            // r~ = M^-1 r    :124
             launch_copy(sc, XP + 1, 2, RST, 2, n);                          // p = r~         :125
             launch_copy(sc, tmp, 1, RST, 2, n);
             if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
             launch_copy(sc, RS + 1, 2, t1, 1, n);                           // s = A p        :127
-            launch_mul(sc, RST + 1, 2, h->dinv.d(), 1, t1, 1, n);           // s~ = M^-1 s    :128
+            if ((rc = apply_prec(h, t1, 1, RST + 1, 2))) return rc;        // s~ = M^-1 s    :128
             launch_copy(sc, WU, 2, t1, 1, n);                               // w = s          :129
             launch_copy(sc, h->wt.d(), 1, RST + 1, 2, n);                   // w~ = s~        :130
             launch_copy(sc, tmp, 1, RST + 1, 2, n);
             if ((rc = dist_spmv(h, tmp, t1, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;
             launch_copy(sc, WU + 1, 2, t1, 1, n);                           // u = A s~       :131
+            if (h->cb_session && (rc = apply_prec(h, WU + 1, 2, h->ut.d(), 1))) return rc;   // u~ = M^-1 u  :132
         }
         if (h->fused && !pipe_recompute(variant)) launch_copy(sc, h->wv.d(), 1, WU, 2, n);   // the stored w of the 'p' flavours
         PipeUpdateArgs a = pipe_args(h, 0);
@@ -1624,7 +1693,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->u.ensure((size_t)n * D, h->sc));
         HIPCHK(h, h->tvec.ensure((size_t)n * D, h->sc));
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x      cg_cg.py:23
-        if (h->prec) launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r   :89
+        if (h->prec && (rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;   // r~ = M^-1 r   :89
         double* z = h->prec ? h->rt.d() : h->r.d();
         launch_copy(sc, h->p.d(), 1, z, 1, n);                              // p = r~           :25 / :91
         int grid = 0;
@@ -1638,7 +1707,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         } else {
             // gv_cg.py:26-33 / gv_pcg :96-109
             if ((rc = dist_spmv(h, z, h->w.d(), kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;   // w = A r~
-            if (h->prec) launch_mul(sc, h->wt.d(), 1, h->dinv.d(), 1, h->w.d(), 1, n);                         // w~
+            if (h->prec && (rc = apply_prec(h, h->w.d(), 1, h->wt.d(), 1))) return rc;                         // w~
             launch_copy(sc, h->s.d(), 1, h->w.d(), 1, n);                                                      // s = w
             if (h->prec) launch_copy(sc, h->st.d(), 1, h->wt.d(), 1, n);                                       // s~ = w~
             double* zt = h->prec ? h->wt.d() : h->w.d();
@@ -1657,7 +1726,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         // HS and non-pipelined PR share the layout x, r, (r~), p(+ghosts), s, (s~)
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
         h->p_cur = h->p.d();
-        h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0;
+        h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0 && !h->cb_session;
         // r (r~) is the staged-window source of the Hestenes-Stiefel product launch: like every vector that feeds a
         // product it has the spare entries behind its end (a window page of the last tile may reach past row n)
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
@@ -1665,7 +1734,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->st.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         // one launch per iteration for pr / m on a window operator: second copies of what the window is formed from
-        h->pr_fused = is_pr(variant) && h->want_fused && !h->multi() && h->g == 0 && h->win;
+        h->pr_fused = is_pr(variant) && h->want_fused && !h->multi() && h->g == 0 && h->win && !h->cb_session;
         HIPCHK(h, h->p2.ensure(((h->hs_fused && h->win) || h->pr_fused) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->r2.ensure((h->pr_fused && !h->prec) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->s2.ensure((h->pr_fused && !h->prec) ? (size_t)ne * D : 16, h->sc));
@@ -1676,7 +1745,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
         if (h->prec) {
-            launch_mul(sc, h->rt.d(), 1, h->dinv.d(), 1, h->r.d(), 1, n);   // r~ = M^-1 r
+            if ((rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;   // r~ = M^-1 r
             launch_copy(sc, h->p.d(), 1, h->rt.d(), 1, n);                  // p = r~
         } else {
             launch_copy(sc, h->p.d(), 1, h->r.d(), 1, n);                   // p = r
@@ -1686,6 +1755,11 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             const int g1 = launch_hs_init_dots(sc, a);                      // nu = r.r~      hs_cg.py:25
             LAUNCHCHK(h, g1);
             launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), PRCG_S_NU, PRCG_S_NU, 2);
+            if (h->cb_session) {        // nu = r~.r with the r~ the callback returned
+                const int g2 = launch_dot(sc, h->rt.d(), h->r.d(), n, h->partB.d(), 0);
+                LAUNCHCHK(h, g2);
+                launch_reduce_final(sc, h->partB.d(), g2, dots_at(h, 0), 0, PRCG_S_NU, 1);
+            }
             if ((rc = allreduce(h, dots_at(h, 0) + PRCG_S_NU, 2, sc))) return rc;
             int grid = 0;
             if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiDotXY, nullptr, nullptr, nullptr, &grid))) return rc;
@@ -1696,11 +1770,15 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             const int g1 = launch_pr_init_dots(sc, a);                      // nu = r~.r      pr_cg.py:109
             LAUNCHCHK(h, g1);
             int grid = 0;
-            if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
-                                h->prec ? h->st.d() : nullptr, &grid))) return rc;        // s, s~, mu, dl, gm
-            launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), PRCG_S_NU, PRCG_S_NU, 2);
-            launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, 0, 3);
-            if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+            if (h->cb_session) {
+                if ((rc = pr_spmv_and_reduce(h, 0, g1))) return rc;                       // (s~ from the callback)
+            } else {
+                if ((rc = dist_spmv(h, h->p.d(), h->s.d(), kEpiPR, h->r.d(), h->prec ? h->dinv.d() : nullptr,
+                                    h->prec ? h->st.d() : nullptr, &grid))) return rc;    // s, s~, mu, dl, gm
+                launch_reduce_final(sc, h->partA.d(), g1, dots_at(h, 0), PRCG_S_NU, PRCG_S_NU, 2);
+                launch_reduce_final(sc, h->partB.d(), grid, dots_at(h, 0), 0, 0, 3);
+                if ((rc = allreduce(h, dots_at(h, 0), 5, sc))) return rc;
+            }
         }
     }
     if ((rc = record(h, 0))) return rc;

@@ -222,6 +222,7 @@ struct PipeUpdateArgs {
     double* wu;       // pairs (w,u)
     double* wt;       // w~ (preconditioned 'p' flavours only)
     const double* d;  // inverse diagonal (preconditioned only)
+    const double* ut; // non-null: u~ = M^-1 u (and w~ in wt) were computed elsewhere (host-callback preconditioner)
     const double* dots_prev;   // kNumScalars doubles: mu, dl, gm, nu of iteration k-1
     double* coef_out;          // alpha, beta, nu_pred of this iteration
     double* partials;          // [grid][kPartialStride]

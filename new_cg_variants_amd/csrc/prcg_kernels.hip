@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
         if (base >= n) break;
         // ---- loads of both elements first ----
         double2 xp[2], rs[2], wu[2], rst[2];
-        double dv[2], wt[2];
+        double dv[2], wt[2], utv[2];
         bool ok[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -389,8 +389,13 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
             if constexpr (PREC) {
                 rst[e] = RST[il];
                 if constexpr (!DOTS_ONLY) {
-                    dv[e] = D[il];
-                    wt[e] = recompute_w ? 0.0 : WT[il];
+                    if (a.ut) {              // preconditioner applied elsewhere (host callback): u~ and w~ are vectors
+                        dv[e] = 0.0; utv[e] = a.ut[il]; wt[e] = WT[il];
+                    } else {
+                        dv[e] = D[il];
+                        utv[e] = 0.0;
+                        wt[e] = recompute_w ? 0.0 : WT[il];
+                    }
                 }
             }
         }
@@ -413,8 +418,8 @@ __global__ __launch_bounds__(kBlock) void k_pipe_update(PipeUpdateArgs a, int tr
                 const double rn = rs[e].x - c.al * rs[e].y;             // r -= a s
                 const double wn = wu[e].x - c.al * wu[e].y;             // w -= a u
                 if constexpr (PREC) {
-                    const double ut = dv[e] * wu[e].y;                  // u~ = M^-1 u
-                    const double wtv = recompute_w ? dv[e] * wu[e].x : wt[e];   // w~
+                    const double ut = a.ut ? utv[e] : dv[e] * wu[e].y;  // u~ = M^-1 u
+                    const double wtv = a.ut ? wt[e] : (recompute_w ? dv[e] * wu[e].x : wt[e]);   // w~
                     const double rtn = rst[e].x - c.al * rst[e].y;      // r~ -= a s~
                     const double wtn = wtv - c.al * ut;                 // w~ -= a u~
                     const double pn = rtn + c.bt * xp[e].y;             // p = r~ + b p
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_gv_update1(CgArgs a, int trips) {
                 if constexpr (PREC) {
                     zn = zn - al * a.st_[ie];
                     a.rt[ie] = zn;
-                    a.wt[ie] = a.d[ie] * wn;
+                    if (a.d) a.wt[ie] = a.d[ie] * wn;        // (null: w~ = M^-1 w is applied by the caller afterwards)
                 } else {
                     zn = rn;
                 }
@@ -1100,14 +1105,15 @@ int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode) {
 
 int launch_pipe_update(hipStream_t st, const PipeUpdateArgs& a) {
     const Chunking c = chunking(a.n);
-    if (a.d) hipLaunchKernelGGL((k_pipe_update<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
-    else     hipLaunchKernelGGL((k_pipe_update<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    // preconditioned: the inverse diagonal, or u~ / w~ as vectors (host-callback preconditioner)
+    if (a.d || a.ut) hipLaunchKernelGGL((k_pipe_update<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else             hipLaunchKernelGGL((k_pipe_update<false, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 int launch_pipe_dots(hipStream_t st, const PipeUpdateArgs& a) {
     const Chunking c = chunking(a.n);
-    if (a.d) hipLaunchKernelGGL((k_pipe_update<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
-    else     hipLaunchKernelGGL((k_pipe_update<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    if (a.d || a.ut) hipLaunchKernelGGL((k_pipe_update<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    else             hipLaunchKernelGGL((k_pipe_update<false, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 
@@ -1151,7 +1157,7 @@ int launch_cg_update_ps(hipStream_t st, const CgArgs& a) {
 }
 int launch_gv_update1(hipStream_t st, const CgArgs& a, bool dots_only) {
     const Chunking c = chunking(a.n);
-    if (a.d) {
+    if (a.rt) {      // preconditioned (a.d null: w~ = M^-1 w is applied by the caller afterwards)
         if (dots_only) hipLaunchKernelGGL((k_gv_update1<true, true>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
         else hipLaunchKernelGGL((k_gv_update1<true, false>), dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
     } else {

@@ -133,11 +133,33 @@ class DeviceCSR:
         return WU, ms.value
 
     # -- solver session ------------------------------------------------------------------------
-    def begin(self, variant, b, x0, max_iter, x_true=None, inv_diag=None, hist_mask=0):
+    def begin(self, variant, b, x0, max_iter, x_true=None, inv_diag=None, hist_mask=0, preconditioner=None):
+        """inv_diag: Jacobi on the device.  preconditioner: any callable v -> M^-1 v (what the reference's *_pcg
+        functions take); it runs on the host wherever the reference calls it (prcg.h: prcg_set_preconditioner)."""
         b, x0 = L.f64(b), L.f64(x0)
         assert b.shape == (self.n,) and x0.shape == (self.n,)
+        assert inv_diag is None or preconditioner is None
         xt = None if x_true is None else L.f64(x_true)
         dv = None if inv_diag is None else L.f64(inv_diag)
+        if preconditioner is not None:
+            n = self.n
+
+            def call(_ctx, count, v, out):
+                try:
+                    res = np.asarray(preconditioner(np.ctypeslib.as_array(v, shape=(count,)).copy()), dtype=np.float64)
+                    if res.shape != (count,):
+                        return 2
+                    np.ctypeslib.as_array(out, shape=(count,))[:] = res
+                    return 0
+                except Exception:          # noqa: BLE001 -- reported through the C return code
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._prec_fn = L.PREC_FN(call)            # keep the trampoline alive for the whole session
+            self._check(self._lib.prcg_set_preconditioner(self._h, C.cast(self._prec_fn, C.c_void_p), None))
+        else:
+            self._prec_fn = None
+            self._check(self._lib.prcg_set_preconditioner(self._h, None, None))
         self._check(self._lib.prcg_solve_begin(self._h, int(variant), L.ptr(b), L.ptr(x0), int(max_iter),
                                                L.ptr(xt), L.ptr(dv), int(hist_mask)))
         self.max_iter, self.hist_mask = int(max_iter), int(hist_mask)

@@ -456,6 +456,41 @@ def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant, pr
     print(f'{matrix}/{variant}/{prec}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
+@pytest.mark.parametrize('method', ['hs_pcg', 'cg_pcg', 'gv_pcg', 'pr_pcg', 'm_pcg', 'pipe_pr_pcg', 'pipe_p_pcg',
+                                    'pipe_pr_m_pcg', 'pipe_p_m_pcg'])
+def test_host_callback_preconditioner(amd, matrices, method):
+    """`method(A, b, x0, max_iter, preconditioner=callable)` with a preconditioner that is NOT a diagonal scaling
+    (a tridiagonal solve): the callable runs on the host wherever the reference calls `preconditioner(...)`, the rest
+    of the iteration on the device.  Against the oracle with the same callable: the first iterations to 1e-11
+    (different summation orders of the inner products), the convergence statistics beyond."""
+    from oracle import ne_oracle as orc
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    A, z = matrices['nos7']
+    n = A.shape[0]
+    T = sp.diags([A.diagonal(-1), A.diagonal(), A.diagonal(1)], [-1, 0, 1], format='csc')   # SPD tridiagonal part
+    lu = spla.splu(T)
+    calls = []
+
+    def prec(v):
+        calls.append(1)
+        return lu.solve(np.asarray(v, dtype=np.float64))
+    max_iter = 260
+    cbs = [amd['cbs'].updated_residual_2_norm, amd['cbs'].error_A_norm]
+    out = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), max_iter, callbacks=cbs, x_true=z['x_true'], preconditioner=prec)
+    per_it = (len(calls) - 2) / (max_iter - 1)                                   # (two probe calls of the wrapper)
+    ref = getattr(orc, method)(A, z['b'], np.zeros(n), max_iter, preconditioner=lambda v: lu.solve(v),
+                               callbacks=['updated_residual_2_norm', 'error_A_norm'], x_true=z['x_true'])
+    for q in ('updated_residual_2_norm', 'error_A_norm'):
+        np.testing.assert_allclose(out[q][:6], ref[q][:6], rtol=1e-11, err_msg=f'{method}/{q}')
+    ia, aa = orc.convergence_summary(out['error_A_norm'])
+    ib, ab = orc.convergence_summary(ref['error_A_norm'])
+    assert ib > 0 and abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 1.5, ((ia, aa), (ib, ab))
+    assert 0.9 <= per_it <= 2.3, per_it
+    print(f'{method}: tridiagonal preconditioner on the host, {per_it:.2f} applications per iteration; '
+          f'its-to-1e-5 {ia} (oracle {ib}), log10 min error {aa:.2f} ({ab:.2f})')
+
+
 @pytest.mark.parametrize('source,variant,prec,knobs', [
     ('bcsstk03', 'PR', None, {}), ('nos7', 'PR', 'jacobi', {}), ('494_bus', 'M', 'jacobi', {}), ('nos4', 'M', None, {}),
     ('s3_small', 'PR', None, {}), ('s3_small', 'M', None, {'PRCG_VALDICT': '0'}), ('s1_small', 'PR', 'jacobi', {}),
