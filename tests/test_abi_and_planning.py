@@ -312,3 +312,26 @@ def test_window_stream_images_are_shared_losslessly(name, rows):
     else:
         assert cw_images > 0.9 * tiles, res[1]
     print(f'{name}: {tiles} tiles, {cw_images} window-index images ({cw_elems} of {A.nnz} elements stored), {rel_images} row-pointer images')
+
+
+def test_preconditioner_routing_diagonal_on_device_anything_else_by_callback():
+    """figure_gen.py:42-44 passes a Python callable.  A diagonal scaling is recognised by an exact probe and becomes
+    the device's inverse diagonal; the identity becomes "no preconditioner"; anything else is handed to the
+    host-callback path as it is (never approximated, never rejected)."""
+    from new_cg_variants_amd import cg_variants as cgv
+    n = 50
+    rng = np.random.default_rng(2)
+    d = rng.random(n) + 0.5
+    got, fn = cgv._diagonal_of(lambda v: d * v, n)
+    assert fn is None and np.array_equal(got, d)
+    assert cgv._diagonal_of(lambda v: v, n) == (None, None)
+    assert cgv._diagonal_of(None, n) == (None, None)
+    T = np.diag(d) + 0.1 * np.diag(np.ones(n - 1), 1) + 0.1 * np.diag(np.ones(n - 1), -1)
+    tri = lambda v: np.linalg.solve(T, v)                                       # noqa: E731
+    got, fn = cgv._diagonal_of(tri, n)
+    assert got is None and fn is tri
+    jac = cgv.Jacobi(__import__('scipy.sparse', fromlist=['diags']).diags(1 / d).tocsr())
+    got, fn = cgv._diagonal_of(jac, n)
+    assert fn is None and np.array_equal(got, 1 / (1 / d))
+    with pytest.raises(ValueError):
+        cgv._diagonal_of(lambda v: v[:-1], n)
