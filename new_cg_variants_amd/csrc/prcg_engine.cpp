@@ -186,6 +186,10 @@ struct prcg_handle {
     bool pr_fused = false;       // non-pipelined predict-and-recompute (pr, m) on a window operator: ONE launch per iteration
                                  // (window formed as (z - a zs) + b p_old); z, zs, p double-buffered:
     double* cur_r = nullptr; double* cur_s = nullptr; double* cur_rt = nullptr; double* cur_st = nullptr;
+    double* cur_w = nullptr;     // ... Ghysels-Vanroose: w double-buffered the same way (w / w2)
+    DevBuf w2;
+    bool cg_fused = false;       // Chronopoulos-Gear / Ghysels-Vanroose on a window operator: two launches (product with the window formed as
+                                 // r - a s; p, s update that sums the product's partials itself); r double-buffered (cur_r)
     bool hs_fused = false;       // Hestenes-Stiefel without reduction launches: 2 launches per iteration on window
                                  // operators (update; product with the direction formed in the staged window), else 3
     double* p_cur = nullptr;     // ... the current direction: p / p2 (the product launch writes the other one)
@@ -907,13 +911,13 @@ int iterate_pr(prcg_t* h, int k) {
 CgArgs cg_args(prcg_t* h, int k) {
     CgArgs a{};
     a.n = h->n;
-    a.x = h->x.d(); a.r = h->r.d(); a.rt = h->prec ? h->rt.d() : nullptr;
-    a.w = h->w.d(); a.wt = h->prec ? h->wt.d() : nullptr;
+    a.x = h->x.d(); a.r = h->cur_r; a.rt = h->prec ? h->rt.d() : nullptr;
+    a.w = h->cur_w; a.wt = h->prec ? h->wt.d() : nullptr;
     a.p = h->p.d(); a.s = h->s.d();
     a.st_ = (h->prec && h->variant == PRCG_GV) ? h->st.d() : nullptr;
     a.u = h->variant == PRCG_GV ? h->u.d() : nullptr;
     a.t = h->tvec.d();
-    a.z = h->prec ? h->rt.d() : h->r.d();
+    a.z = h->prec ? h->rt.d() : h->cur_r;
     a.d = (h->prec && !h->cb_session) ? h->dinv.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
     a.dots_cur = dots_at(h, k);
@@ -921,6 +925,54 @@ CgArgs cg_args(prcg_t* h, int k) {
     a.coef_out = coef_at(h, k);
     a.partials = h->partA.d();
     return a;
+}
+
+// Chronopoulos-Gear on a window operator in TWO launches (was four): the product launch forms its window as the new
+// residual r - a s (times d), writes x, r, r~, w and the partials of eta, nu; the p, s update sums them in its prologue
+// (same tree as k_reduce_final), derives b and mu and leaves the complete scalars of iteration k behind.
+int iterate_cgcg_fused(prcg_t* h, int k) {
+    double* r_new = (h->cur_r == h->r.d()) ? h->r2.d() : h->r.d();
+    FusedPrev f{};
+    f.dots_old = dots_at(h, k - 1);
+    f.pr.z_old = h->cur_r; f.pr.zs_old = h->s.d(); f.pr.p_old = h->p.d();
+    f.pr.z_new = r_new; f.pr.zs_new = h->prec ? h->rt.d() : nullptr;
+    f.pr.x = h->x.d(); f.pr.d = h->prec ? h->dinv.d() : nullptr;
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int grid = launch_win_cg_w(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->w.d(),
+                                     h->partB.d(), coef_at(h, k), h->win_per_cu);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    h->cur_r = r_new;
+    on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    LAUNCHCHK(h, launch_cg_update_ps(h->sc, cg_args(h, k), h->partB.d(), grid));
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    return PRCG_OK;
+}
+
+// Ghysels-Vanroose in two launches, the same way: the window is the new w formed as w - a u (times d).
+int iterate_gv_fused(prcg_t* h, int k) {
+    double* w_new = (h->cur_w == h->w.d()) ? h->w2.d() : h->w.d();
+    FusedPrev f{};
+    f.dots_old = dots_at(h, k - 1);
+    f.pr.z_old = h->cur_w; f.pr.zs_old = h->u.d(); f.pr.p_old = h->p.d();
+    f.pr.z_new = w_new; f.pr.zs_new = h->prec ? h->wt.d() : nullptr;
+    f.pr.x = h->x.d(); f.pr.r = h->r.d(); f.pr.s = h->s.d();
+    f.pr.d = h->prec ? h->dinv.d() : nullptr;
+    f.pr.rt = h->prec ? h->rt.d() : nullptr; f.pr.st = h->prec ? h->st.d() : nullptr;
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int grid = launch_win_gv_w(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->tvec.d(),
+                                     h->partB.d(), coef_at(h, k), h->win_per_cu);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    h->cur_w = w_new;
+    on = false;
+    prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
+    LAUNCHCHK(h, launch_cg_update_ps(h->sc, cg_args(h, k), h->partB.d(), grid));
+    prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    return PRCG_OK;
 }
 
 // Chronopoulos-Gear (cg_cg.py:59-68): ONE reduction per iteration, after the SpMV it depends on
@@ -1061,9 +1113,9 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         switch (which) {
         case PRCG_VEC_X: *base = h->x.d(); return true;
         case PRCG_VEC_P: *base = h->p.d(); return true;
-        case PRCG_VEC_R: *base = h->r.d(); return true;
+        case PRCG_VEC_R: *base = h->cur_r; return true;
         case PRCG_VEC_S: *base = h->s.d(); return true;
-        case PRCG_VEC_W: *base = h->w.d(); return true;
+        case PRCG_VEC_W: *base = h->cur_w; return true;
         case PRCG_VEC_U: if (v != PRCG_GV) return false; *base = h->u.d(); return true;
         case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
         case PRCG_VEC_WT: if (!h->prec || v != PRCG_GV) return false; *base = h->wt.d(); return true;
@@ -1552,6 +1604,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->variant = variant;
     h->fused = false;
     h->hs_fused = false;
+    h->cg_fused = false;
     h->pr_fused = false;
     h->hs_pend_mu = 0;
     h->small = false;
@@ -1570,7 +1623,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     HIPCHK(h, h->b.ensure((size_t)n * D, h->sc));
     HIPCHK(h, h->xt.ensure((size_t)n * D, h->sc));
     HIPCHK(h, h->e_ext.ensure((size_t)ne * D, h->sc));
-    HIPCHK(h, h->dinv.ensure((size_t)n * D, h->sc));
+    HIPCHK(h, h->dinv.ensure((size_t)ne * D, h->sc));     // (a window source of the Chronopoulos-Gear product launch)
     HIPCHK(h, h->dots.ensure((size_t)(max_iter + 1) * kNS * D, h->sc));
     HIPCHK(h, h->coef.ensure((size_t)(max_iter + 1) * kCoefStride * D, h->sc));
     int rc;
@@ -1685,12 +1738,17 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
         h->p_cur = h->p.d();
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
+        h->cur_r = h->r.d();
+        h->cg_fused = h->want_fused && !h->multi() && h->g == 0 && h->win && !h->cb_session;
+        HIPCHK(h, h->r2.ensure((h->cg_fused && variant == PRCG_CG_CG) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->w2.ensure((h->cg_fused && variant == PRCG_GV) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->w.ensure((size_t)ne * D, h->sc));
+        h->cur_w = h->w.d();
         HIPCHK(h, h->wt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
-        HIPCHK(h, h->s.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->s.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
-        HIPCHK(h, h->u.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->u.ensure((size_t)ne * D, h->sc));      // (a window source of the Ghysels-Vanroose product launch)
         HIPCHK(h, h->tvec.ensure((size_t)n * D, h->sc));
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x      cg_cg.py:23
         if (h->prec && (rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;   // r~ = M^-1 r   :89
@@ -1814,8 +1872,8 @@ int prcg_iterate(prcg_t* h, int iters) {
         int rc;
         if (is_pipe(h->variant)) rc = iterate_pipe(h, k);
         else if (h->variant == PRCG_HS) rc = h->hs_fused ? iterate_hs_fused(h, k) : iterate_hs(h, k);
-        else if (h->variant == PRCG_CG_CG) rc = iterate_cgcg(h, k);
-        else if (h->variant == PRCG_GV) rc = iterate_gv(h, k);
+        else if (h->variant == PRCG_CG_CG) rc = h->cg_fused ? iterate_cgcg_fused(h, k) : iterate_cgcg(h, k);
+        else if (h->variant == PRCG_GV) rc = h->cg_fused ? iterate_gv_fused(h, k) : iterate_gv(h, k);
         else rc = h->pr_fused ? iterate_pr_fused(h, k) : iterate_pr(h, k);
         if (rc) return rc;
         if ((rc = record(h, k))) return rc;
@@ -1860,7 +1918,7 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
-    return ((h->fused || h->hs_fused || h->pr_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+    return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW

@@ -41,6 +41,7 @@ struct FusedPrev {
         const double* z_old; const double* zs_old; const double* p_old;
         double* z_new; double* zs_new; double* p_new;
         double* x; double* r; double* s; const double* d;
+        double* rt; const double* st;      // Ghysels-Vanroose with Jacobi: r~ (updated in place) and s~ of the row
     } pr;
 };
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
@@ -73,8 +74,16 @@ enum SpmvEpilogue {
     kEpiHS = 8,      // window kernels only: the Hestenes-Stiefel product launch (launch_win_hs)
     kEpiPROne = 9,   // window kernels only: one-launch predict-and-recompute iteration (launch_win_pr_one)
     kEpiPROneJ = 10, // ... with Jacobi
+    kEpiCGW = 11,    // window kernels only: Chronopoulos-Gear product launch, window formed as r - a s (launch_win_cg_w)
+    kEpiCGWJ = 12,   // ... with Jacobi: d (r - a s)
+    kEpiGVW = 13,    // window kernels only: Ghysels-Vanroose product launch, window formed as w - a u (launch_win_gv_w)
+    kEpiGVWJ = 14,   // ... with Jacobi: d (w - a u)
 };
 constexpr bool epi_pr_one(int e) { return e == kEpiPROne || e == kEpiPROneJ; }
+constexpr bool epi_cg_w(int e) { return e == kEpiCGW || e == kEpiCGWJ; }
+constexpr bool epi_gv_w(int e) { return e == kEpiGVW || e == kEpiGVWJ; }
+// the launches that form their window from several old vectors and update the row's own vectors (FusedPrev::PrOne)
+constexpr bool epi_rowset(int e) { return epi_pr_one(e) || epi_cg_w(e) || epi_gv_w(e); }
 constexpr bool epi_fused(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedP || e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_prec(int e) { return e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_recompute(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedJ; }
@@ -199,6 +208,20 @@ int launch_win_hs(hipStream_t st, const WinDev& A, const WTile* tiles, int ntile
 // launch_pipe_fused; f.dots_old: the reduced scalars of iteration k-1 when nprev == 0; coef_out: a, b, predicted nu.
 int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
                       int meurant, double* partials, double* coef_out, int per_cu);
+// First of the TWO launches of a Chronopoulos-Gear iteration on a window operator (cg_cg.py:59-63, cg_pcg :116-121):
+// a = nu_k1 / mu_k1 (f.dots_old), the staged window is the NEW residual formed while it is parked, r - a s (times d
+// with Jacobi: r~ = M^-1 r), w = A r~ follows; the lane that summed row i writes x += a p, r (to f.pr.z_new: other
+// tiles still stage the old r), r~ (f.pr.zs_new, Jacobi) and w, with the partials eta = w.r~ (slot 1), nu = r.r~ (3),
+// r.r (4).  The second launch is launch_cg_update_ps with `prev`: it sums those partials in its prologue.
+// f.pr: z_old = r, zs_old = s, p_old = p, z_new = the other r buffer, zs_new = r~ (Jacobi), x, d (Jacobi or null).
+int launch_win_cg_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                    double* w_out, double* partials, double* coef_out, int per_cu);
+// The same for Ghysels-Vanroose (gv_cg.py:65-75, gv_pcg :152-164): the staged window is the new w formed as w - a u
+// (times d: w~ = M^-1 w), t = A w~ follows; the lane that summed row i writes x += a p, r -= a s, (r~ -= a s~), w (to
+// f.pr.z_new), (w~ to f.pr.zs_new), t, and the partials eta = w.r~ (1), nu = r.r~ (3), r.r (4).
+// f.pr: z_old = w, zs_old = u, p_old = p, z_new = the other w buffer, zs_new = w~, x, r, s, d, rt, st.
+int launch_win_gv_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                    double* t_out, double* partials, double* coef_out, int per_cu);
 
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {
@@ -265,7 +288,9 @@ struct CgArgs {   // Chronopoulos-Gear / Ghysels-Vanroose vector kernels
     const double* d;
     const double* dots_prev; const double* dots_cur; double* dots_cur_w; double* coef_out; double* partials;
 };
-int launch_cg_update_ps(hipStream_t st, const CgArgs& a);                 // p,s,(s~),(u); mu by recurrence
+// prev / nprev: eta, nu, r.r of this iteration still as block partials (slots 1, 3, 4) of launch_win_cg_w: every
+// block sums them in the order of k_reduce_final, block 0 stores them to a.dots_cur_w
+int launch_cg_update_ps(hipStream_t st, const CgArgs& a, const double* prev = nullptr, int nprev = 0);   // p,s,(s~),(u); mu by recurrence
 int launch_gv_update1(hipStream_t st, const CgArgs& a, bool dots_only);   // x,r,(r~),w,(w~); partials eta(1), nu(3), rr(4)
 
 // out[dst_first..+count) = fixed-order sum over blocks b of partials[b][src_first..+count)

@@ -557,10 +557,18 @@ __global__ __launch_bounds__(kBlock) void k_pr_update(PrArgs a, int trips) {
 // ---- competitor baselines: Chronopoulos-Gear (cg_cg.py:59-68) and Ghysels-Vanroose
 //      (gv_cg.py:65-81).  mu is a RECURRENCE here, not an inner product:
 //      mu_k = eta_k - (b_k / a_k1) nu_k, computed by thread 0 and stored with the scalars. ----
-__global__ __launch_bounds__(kBlock) void k_cg_update_ps(CgArgs a, int trips) {
+__global__ __launch_bounds__(kBlock) void k_cg_update_ps(CgArgs a, int trips, const double* __restrict__ prev, int nprev) {
     // dots_prev: nu_k1 (slot 3), mu_k1 (slot 0); dots_cur: nu_k (3), eta_k (1)
     const double al = a.dots_prev[3] / a.dots_prev[0];          // a_k1
-    const double nu = a.dots_cur[3], eta = a.dots_cur[1];
+    double nu, eta;
+    if (nprev > 0) {
+        double m[5];
+        sum_prev_partials<5, kWaves>(prev, nprev, 0, m);        // the product launch's block partials
+        nu = m[3]; eta = m[1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.dots_cur_w[1] = m[1]; a.dots_cur_w[3] = m[3]; a.dots_cur_w[4] = m[4]; }
+    } else {
+        nu = a.dots_cur[3]; eta = a.dots_cur[1];
+    }
     const double bt = nu / a.dots_prev[3];                      // b_k
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.coef_out[0] = al; a.coef_out[1] = bt;
@@ -1150,9 +1158,9 @@ int launch_pr_init_dots(hipStream_t st, const PrArgs& a) {
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 
-int launch_cg_update_ps(hipStream_t st, const CgArgs& a) {
+int launch_cg_update_ps(hipStream_t st, const CgArgs& a, const double* prev, int nprev) {
     const Chunking c = chunking(a.n);
-    hipLaunchKernelGGL(k_cg_update_ps, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips);
+    hipLaunchKernelGGL(k_cg_update_ps, dim3(c.grid), dim3(kBlock), 0, st, a, c.trips, prev, nprev);
     return PRCG_LAUNCH_OK() ? c.grid : -1;
 }
 int launch_gv_update1(hipStream_t st, const CgArgs& a, bool dots_only) {

@@ -79,7 +79,10 @@ template <> struct RegV<3> { using type = d3_t; };
 // components per staged window entry AS LOADED: the Hestenes-Stiefel product launch loads (z, p_old) and stages
 // p = z + b p_old as one double
 // (one-launch predict-and-recompute: (z, zs, p_old) -> p = (z - a zs) + b p_old)
-constexpr int win_nw(int nv, int epi) { return epi == kEpiHS ? 2 : (epi_pr_one(epi) ? 3 : nv); }
+// (Chronopoulos-Gear product launch: (r, s[, d]) -> r~ = [d] (r - a s))
+constexpr int win_nw(int nv, int epi) {
+    return (epi == kEpiHS || epi == kEpiCGW || epi == kEpiGVW) ? 2 : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ) ? 3 : nv);
+}
 template <int NV, int M, int PG, int CW, bool VD>
 struct WRegs {
     d2_t v[VD ? 1 : kWinSlots / 128];   // plain values: nonzeros alo + st*128 + lane*2 .. +2
@@ -138,6 +141,10 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             else if constexpr (epi_pr_one(EPI)) {
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane]; R.w[p].z = pr.p_old[d.pc[p] + lane];
             }
+            else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) {
+                R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane];
+                if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) R.w[p].z = pr.d[d.pc[p] + lane];
+            }
             else R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];
         }
     }
@@ -148,10 +155,13 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         const int jj = row < d.re ? j * 64 + lane : 0;
         R.s[j] = A.rel[d.srcr + jj];                     // row pointers relative to the tile's first nonzero
         R.e[j] = A.rel[d.srcr + jj + 1];
-        if constexpr (epi_pr_one(EPI)) {
+        if constexpr (epi_rowset(EPI)) {
             R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr];
             R.xp[j].x = pr.x[rr];
             if constexpr (EPI == kEpiPROneJ) { R.rsx[j].x = pr.r[rr]; R.rsx[j].y = pr.s[rr]; R.dd[j] = pr.d[rr]; }
+            if constexpr (EPI == kEpiCGWJ) R.dd[j] = pr.d[rr];
+            if constexpr (epi_gv_w(EPI)) { R.rsx[j].x = pr.r[rr]; R.rsx[j].y = pr.s[rr]; }
+            if constexpr (EPI == kEpiGVWJ) { R.dd[j] = pr.d[rr]; R.ww[j] = pr.rt[rr]; R.wwt[j] = pr.st[rr]; }
         }
         if constexpr (FUSED) {
             R.xp[j] = reinterpret_cast<const d2_t*>(fr.XP)[rr];
@@ -237,6 +247,10 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
             if constexpr (EPI == kEpiHS) c.sw[p * 64 + lane] = R.w[p].x + cf.bt * R.w[p].y;
             // predict-and-recompute: r~ -= a s~, then p = r~ + b p_old (pr_cg.py:148,151), formed here
             else if constexpr (epi_pr_one(EPI)) c.sw[p * 64 + lane] = (R.w[p].x - cf.al * R.w[p].y) + cf.bt * R.w[p].z;
+            // Chronopoulos-Gear: r -= a s, r~ = M^-1 r (cg_cg.py:60, cg_pcg :117-118), formed here
+            // (Ghysels-Vanroose: w -= a u, w~ = M^-1 w, gv_cg.py:67 / :155,161 -- the same form)
+            else if constexpr (EPI == kEpiCGW || EPI == kEpiGVW) c.sw[p * 64 + lane] = R.w[p].x - cf.al * R.w[p].y;
+            else if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) c.sw[p * 64 + lane] = R.w[p].z * (R.w[p].x - cf.al * R.w[p].y);
             else reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
         }
     }
@@ -246,10 +260,13 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         rs_[j] = R.s[j]; re_[j] = R.e[j];
-        if constexpr (epi_pr_one(EPI)) {
+        if constexpr (epi_rowset(EPI)) {
             zr[j] = R.zrow[j];
             fin[j].xp.x = R.xp[j].x;
             if constexpr (EPI == kEpiPROneJ) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
+            if constexpr (EPI == kEpiCGWJ) fin[j].d = R.dd[j];
+            if constexpr (epi_gv_w(EPI)) fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y);
+            if constexpr (EPI == kEpiGVWJ) { fin[j].d = R.dd[j]; fin[j].w = R.ww[j]; fin[j].wt = R.wwt[j]; }
         }
         if constexpr (FUSED) {
             fin[j].xp = make_double2(R.xp[j].x, R.xp[j].y);
@@ -325,6 +342,38 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
                     c.pr.zs_new[row] = sum;
                     acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
                 }
+            }
+        } else if constexpr (epi_cg_w(EPI)) {
+            // the row's own x += a p, r -= a s, r~ = d r (cg_cg.py:59-60, :117-118), w = A r~ and the partials of
+            // eta = w.r~, nu = r.r~, r.r (:61-63)
+            if (active) {
+                const double xn = fin[j].xp.x + cf.al * zr[j].z;
+                const double rn = zr[j].x - cf.al * zr[j].y;
+                double zn = rn;
+                if constexpr (EPI == kEpiCGWJ) { zn = fin[j].d * rn; c.pr.zs_new[row] = zn; }
+                c.pr.x[row] = xn;
+                c.pr.z_new[row] = rn;
+                reinterpret_cast<double*>(c.yout)[row] = sum;
+                acc[3] += rn * zn; acc[1] += sum * zn; acc[4] += rn * rn;
+            }
+        } else if constexpr (epi_gv_w(EPI)) {
+            // the row's own x += a p, r -= a s, r~ -= a s~, w -= a u, w~ = d w (gv_cg.py:65-67 / :152-161), t = A w~ and
+            // the partials of eta = w.r~, nu = r.r~, r.r (:74-75 / :163-164)
+            if (active) {
+                const double xn = fin[j].xp.x + cf.al * zr[j].z;
+                const double rn = fin[j].rs.x - cf.al * fin[j].rs.y;
+                const double wn = zr[j].x - cf.al * zr[j].y;
+                double zn = rn;
+                c.pr.x[row] = xn;
+                c.pr.r[row] = rn;
+                c.pr.z_new[row] = wn;
+                if constexpr (EPI == kEpiGVWJ) {
+                    zn = fin[j].w - cf.al * fin[j].wt;                      // r~ -= a s~
+                    c.pr.rt[row] = zn;
+                    c.pr.zs_new[row] = fin[j].d * wn;                       // w~ = M^-1 w
+                }
+                reinterpret_cast<double*>(c.yout)[row] = sum;
+                acc[1] += wn * zn; acc[3] += rn * zn; acc[4] += rn * rn;
             }
         } else if constexpr (EPI == kEpiHS) {
             // s = A p, mu += p_i s_i (hs_cg.py:61-62); the row's own p comes from the staged window and goes to p_new
@@ -430,6 +479,10 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
     }
 
+    if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) {
+        cf.al = fz.dots_old[3] / fz.dots_old[0];                            // a_k1 = nu_k1 / mu_k1   cg_cg.py:58
+        if (blockIdx.x == 0 && threadIdx.x == 0) aux[0] = cf.al;
+    }
     if constexpr (EPI == kEpiHS) {
         // nu_k = <r~,r> of the update launch just before: still its block partials (slots 3, 4)
         double nu;
@@ -587,6 +640,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
+    else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
@@ -768,6 +822,28 @@ int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int n
                                          coef_out, f, per_cu);
     return launch_win<1, kEpiPROne>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, nullptr, nullptr, partials,
                                     coef_out, f, per_cu);
+}
+
+int launch_win_cg_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                    double* w_out, double* partials, double* coef_out, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    if (f.pr.d)
+        return launch_win<1, kEpiCGWJ>(geom, st, A, tiles, ntiles, f.pr.z_old, w_out, 3, nullptr, f.pr.d, nullptr, partials, coef_out, f,
+                                       per_cu);
+    return launch_win<1, kEpiCGW>(geom, st, A, tiles, ntiles, f.pr.z_old, w_out, 3, nullptr, nullptr, nullptr, partials, coef_out, f,
+                                  per_cu);
+}
+
+int launch_win_gv_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
+                    double* t_out, double* partials, double* coef_out, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    if (f.pr.d)
+        return launch_win<1, kEpiGVWJ>(geom, st, A, tiles, ntiles, f.pr.z_old, t_out, 3, nullptr, f.pr.d, nullptr, partials, coef_out, f,
+                                       per_cu);
+    return launch_win<1, kEpiGVW>(geom, st, A, tiles, ntiles, f.pr.z_old, t_out, 3, nullptr, nullptr, nullptr, partials, coef_out, f,
+                                  per_cu);
 }
 
 int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,
