@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='s3',
                     help='s1 s2 s3 s4 s4b s3_8th s1_small s3_small; queen if QUEEN_4147_MTX names the MatrixMarket file')
-    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg'],
+    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg', 'cg_cg', 'gv_cg'],
                     help='pipe_pr_pcg = the pipelined variant with the Jacobi preconditioner (figure_gen.py:42-44)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-comm', action='store_true',
@@ -182,7 +182,8 @@ def main():
         op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
         dev = op.dev
     t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
-    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P}[args.variant]
+    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P,
+               'cg_cg': L.CG_CG, 'gv_cg': L.GV}[args.variant]
     inv_diag = (1.0 / A_rows.tocsr()[:, lo:hi].diagonal()) if args.variant == 'pipe_pr_pcg' else None
     K, W = args.steps, args.warmup
 
@@ -356,7 +357,8 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe'}[args.variant]
+            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe', 'cg_cg': 'cg_cg',
+                   'gv_cg': 'gv'}[args.variant]
             out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None

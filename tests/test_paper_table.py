@@ -44,6 +44,32 @@ def test_table_fixture_is_complete():
         assert len(r['iters']) == len(r['log10_min_rel_error_A']) == len(r['columns']) == 7
 
 
+def inside_oracle_spread(matrix, prec, method, its):
+    """The one convergence rule of tests/test_gpu_parity.py for a cell that is further than 6 % from the published
+    count: iterations-to-1e-5 inside the spread the reference's own loop shows under six summation orders of its inner
+    products (+- 2 %).  Computed only for such cells (the oracle needs seconds per run on the small matrices)."""
+    from oracle import ne_oracle as orc
+    from test_gpu_parity import SUMMATION_ORDERS
+    row = next(r for r in rows() if r['matrix'] == matrix and r['preconditioner'] == prec)
+    if row['n'] > 5000:
+        return False
+    z = np.load(os.path.join(GOLDEN, f'tablemat_{matrix}.npz'))
+    n = int(z['n'])
+    A = sp.csr_matrix((z['data'], z['indices'], z['indptr']), shape=(n, n))
+    x_true = np.ones(n) / np.sqrt(n)
+    b = A @ x_true
+    d = 1 / A.diagonal()
+    fn = (lambda v: d * v) if prec == 'jacobi' else (lambda v: v)
+    counts = []
+    for _, dot in SUMMATION_ORDERS:
+        o = getattr(orc, method)(A, b, np.zeros(n), min(row['max_iter'], CAP), preconditioner=fn, callbacks=['error_A_norm'],
+                                 x_true=x_true, dot=dot)
+        counts.append(orc.convergence_summary(o['error_A_norm'])[0])
+    lo, hi = min(counts), max(counts)
+    print(f'{matrix}/{prec}/{method}: {its} iterations on the device; the oracle under six summation orders {lo}..{hi}')
+    return min(counts) > 0 and lo - max(2, 0.02 * lo) <= its <= hi + max(2, 0.02 * hi)
+
+
 @pytest.mark.gpu
 def test_device_reproduces_the_published_convergence_table():
     from new_cg_variants_amd.experiments import figure_run as fr
@@ -65,7 +91,7 @@ def test_device_reproduces_the_published_convergence_table():
                 cells += 1
                 dev = abs(its - pub_its) / pub_its
                 worst_its = max(worst_its, dev)
-                if abs(its - pub_its) > max(3, 0.06 * pub_its):
+                if abs(its - pub_its) > max(3, 0.06 * pub_its) and not inside_oracle_spread(r['matrix'], r['preconditioner'], m, its):
                     bad.append((r['matrix'], r['preconditioner'], m, 'its', its, pub_its))
             elif pub_its is None:
                 if its != 0 and r['acc'][j] is not None and r['acc'][j] < -5.6:
