@@ -353,3 +353,56 @@ def test_queen_workload_runs_on_the_device(amd, monkeypatch):
     np.testing.assert_allclose(got['updated_residual_2_norm'][:12], want['updated_residual_2_norm'][:12], rtol=1e-12)
     assert got['error_A_norm'][25] < 1e-8 * got['error_A_norm'][0]
     monkeypatch.delitem(problems.WORKLOADS, 'queen', raising=False)
+
+
+@pytest.mark.gpu
+def test_window_formation_launches_on_randomised_spd_bands_and_grids(amd):
+    """The launches that FORM their staged window from old vectors (Hestenes-Stiefel, predict-and-recompute,
+    Chronopoulos-Gear, Ghysels-Vanroose) and the one-launch pipelined iteration, on operators that decide the window
+    geometry the awkward way: row counts that are no multiple of the tile, 1 .. 30 half bandwidths with random gaps,
+    grids of odd sizes, pages that reach the end of the vectors.  30 iterations of every family, with and without
+    Jacobi, against the same solve with one kernel per step (PRCG_FUSED=0): same arithmetic per element, so the
+    iterates agree to rounding; and nothing may fault (every window source carries spare entries behind its end)."""
+    L = amd['L']
+    P = amd['problems']
+    rng = np.random.default_rng(2024)
+    cases = []
+    for k, n in ((1, 67), (2, 200), (5, 1999), (7, 4097), (12, 777), (30, 2500)):
+        offs = np.arange(1, k + 1)
+        keep = rng.random((n, k)) < 0.7
+        rows = np.repeat(np.arange(n), k).reshape(n, k)
+        cols = rows + offs[None, :]
+        ok = keep & (cols < n)
+        vals = rng.standard_normal((n, k))
+        U = sp.csr_matrix((vals[ok], (rows[ok], cols[ok])), shape=(n, n))
+        S = U + U.T
+        A = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 1.0 + rng.random(n))).tocsr()
+        A.sort_indices()
+        cases.append((f'band k={k} n={n}', A))
+    cases.append(('lap2d 37x29', P.laplace_2d(37, 29)))
+    cases.append(('lap3d 9x11x7', P.laplace_3d(9, 11, 7)))
+    worst = 0.0
+    for name, A in cases:
+        n = A.shape[0]
+        b = A @ (np.ones(n) / np.sqrt(n))
+        for prec in (None, 1 / A.diagonal()):
+            ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_FUSED': f, 'PRCG_SMALL': '0'}) for f in ('1', '0')]
+            for variant in ('HS', 'PR', 'M', 'CG_CG', 'GV', 'PIPE_PR', 'PIPE_P_M'):
+                xs = []
+                for op in ops:
+                    op.begin(getattr(L, variant), b, np.zeros(n), 32, inv_diag=prec, hist_mask=1)
+                    op.iterate(7)
+                    op.iterate(23)
+                    op.sync()
+                    xs.append((op.get_vector('x'), op.history()['updated_residual_2_norm'], op.schedule()['fused']))
+                assert xs[0][2] == ops[0].schedule()['window'] or variant.startswith('PIPE') or variant == 'HS', (name, variant)
+                assert not xs[1][2]
+                assert np.all(np.isfinite(xs[1][0])), (name, variant)
+                scale = np.max(np.abs(xs[1][0]))
+                dev = float(np.max(np.abs(xs[0][0] - xs[1][0])) / scale)
+                worst = max(worst, dev)
+                assert dev <= 1e-9, (name, variant, prec is not None, dev)
+                np.testing.assert_allclose(xs[0][1][:8], xs[1][1][:8], rtol=1e-10, err_msg=f'{name} {variant}')
+            for op in ops:
+                op.close()
+    print(f'{len(cases)} operators x 7 variants x 2 preconditioners: worst deviation of x after 30 iterations {worst:.1e}')
