@@ -1,0 +1,34 @@
+// Sanitizer harness (CPU only): the window planning pipeline of prcg_set_csr -- plan_window_tiles,
+// plan_window_dict, share_window_streams -- behind one C entry point, built with ASan/UBSan by
+// tools/run_plan_asan.py and driven over every golden matrix and the synthetic operators.
+#include "../new_cg_variants_amd/csrc/prcg_plan.h"
+
+#include <cstring>
+using namespace prcg;
+
+extern "C" int plan_all(long n, long ncols, const int* indptr, const int* indices, const double* data, int rows, int share) {
+    WinPlan wp;
+    plan_window_tiles(n, ncols, indptr, indices, nullptr, rows, 1009, rows == 64 ? 4 : 12, wp);
+    if (!wp.ok0 || !wp.ok1) return 0;
+    std::vector<WTile> wall(wp.t0);
+    wall.insert(wall.end(), wp.t1.begin(), wp.t1.end());
+    const long nnz = indptr[n];
+    std::vector<uint8_t> wvidx((size_t)nnz + 32, 0);
+    std::vector<double> wvdict;
+    const bool vd = plan_window_dict(wall, data, 256, wvidx, wvdict);
+    std::vector<uint8_t> vstore;
+    std::vector<uint16_t> rstore, cstore;
+    share_window_streams<uint16_t>(wall, indptr, wp.cw.data(), vd ? wvidx.data() : nullptr, share != 0, cstore, vstore, rstore);
+    std::vector<uint8_t> c8w(wp.cw.size()), c8s;
+    for (size_t q = 0; q < wp.cw.size(); ++q) c8w[q] = (uint8_t)wp.cw[q];
+    share_window_streams<uint8_t>(wall, indptr, c8w.data(), vd ? wvidx.data() : nullptr, share != 0, c8s, vstore, rstore);
+    // every descriptor must stay inside the stores
+    for (const auto& t : wall) {
+        const int pad = t.lo & 15, len = t.hi - t.lo;
+        if (t.src_c < 0 || (size_t)t.src_c + pad + len > c8s.size()) return -2;
+        if (vd && (t.src_v < 0 || (size_t)t.src_v + pad + len > vstore.size())) return -3;
+        if (t.src_r < 0 || (size_t)t.src_r + (t.re - t.rb) + 1 > rstore.size()) return -4;
+        if (vd && (t.vd_first < 0 || (size_t)t.vd_first + t.vd_count > wvdict.size())) return -5;
+    }
+    return 1 + (vd ? 1 : 0);
+}
