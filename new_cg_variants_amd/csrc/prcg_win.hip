@@ -13,7 +13,14 @@
 //     row order without FMA; nothing is written back to LDS, no cross-lane step;
 //   * the row's epilogue (store, fused vector update, inner-product partials) follows in the
 //     same lane; for the one-launch pipelined iteration (x,p) of the row was requested a tile
-//     ahead and (r,s) of the row is read from the staged window.
+//     ahead and (r,s) of the row is read from the staged window;
+//   * the 1- and 2-byte streams (window indices, value-dictionary indices, relative row pointers)
+//     are read from the tile's IMAGE, which tiles with byte-identical streams share (prcg_plan.h:
+//     share_window_streams): a band or a stencil finds them in L2, not in HBM;
+//   * the non-pipelined variants FORM their staged window from old vectors while it is parked
+//     (Hestenes-Stiefel p = z + b p_old, predict-and-recompute p = (r~ - a s~) + b p_old,
+//     Chronopoulos-Gear r - a s, Ghysels-Vanroose w - a u): the vector a product needs is never
+//     written and gathered again first.
 //
 // Every global load of the loop is issued a whole tile before its data is needed and there is
 // no dependent second round trip, which is what the latency-bound CSR-adaptive form suffered
@@ -406,8 +413,8 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
 // Template: NV vectors (1: SpMV, 2: the pipelined SpMM on (r,s) pairs), EPI row epilogue,
 // M rows per lane (tile = up to 64*M rows), PG pages, CW bits per window index, VD value
 // dictionary, WPB waves per workgroup (waves are independent: no workgroup barrier in the loop),
-// DEPTH register images = tiles in flight per wave (few resident waves, each with a deep queue of
-// coalesced loads, stream better than many shallow ones: profiles/r02_sweeps.md).
+// DEPTH register images = tiles in flight per wave (see PRCG_WIN_DEPTH_* above: one image per wave and every
+// resident wave for the dictionary streams, whose images come from L2; one for the plain stream, which is HBM bound).
 // DEF > 0 (communicator sessions): the inner products that update k needs are still being reduced across
 // the ranks when this launch starts.  Each wave therefore computes the products of its first DEF tiles
 // (the part of the iteration that only needs the old vectors) with the sums parked in LDS, then waits
@@ -498,6 +505,8 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         if (blockIdx.x == 0 && threadIdx.x == 0) aux[1] = cf.bt;
     }
 
+    // (the first tiles are requested AFTER the prologue: vmcnt is in order, so partial rows requested behind the
+    //  images would wait for the images' HBM latency -- measured 1-4 % slower the other way round)
     const int nblk = gridDim.x;
     const int W = nblk * WPB;
     int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
