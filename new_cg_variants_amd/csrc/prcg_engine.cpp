@@ -679,7 +679,6 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     f.meurant = meurant(h->variant); f.recompute_w = rec;
     f.prev = FusedPrev{};
     f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
-    if (getenv("PRCG_DEBUG_NOWAIT")) f.prev.want = 0u;     // timing experiment only: results are wrong
     f.deferred = 1;
     f.prev.nt_int = h->nwt_int;
     // ONE launch over all tiles: the boundary tiles come last in the table and are touched only after the wave has
