@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: pipelined predict-and-recompute CG iterations/second on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|s2|s1] [--variant pipe_pr_cg|hs_cg|pr_cg]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s3|s2|s1|...] [--variant pipe_pr_cg|hs_cg|...]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 one rank per GPU.  torch.distributed (gloo) carries only the control plane (RCCL unique
 id, barriers, max-over-ranks of the time); every per-iteration byte -- the halo of the
-SpMM input and the single 5-double all-reduce -- moves over RCCL/xGMI inside libprcg.so.
+SpMM input and the single reduction -- moves over xGMI inside libprcg.so.
 
 A "step" is one CG iteration (fused update + two-vector SpMM + reduction) on the
 synthetic workload, inputs resident in HBM before the clock starts, no convergence test
@@ -15,7 +15,15 @@ synthetic workload, inputs resident in HBM before the clock starts, no convergen
 The workload is fixed as N grows (strong scaling): S3 = the reference's ex2b banded
 model matrix at n = 1e7, 15 diagonals, ~150 M nonzeros, split into row blocks.
 
-Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md section 6).
+Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md section 6).  At N = 1 the
+line also carries (all timed in this run, same K and W):
+  value_general_csr            the same loop with the value dictionary off: the rate of an operator whose values
+                               do not repeat (8 B per nonzero actually move) -- the transferable number
+  roofline.plain_values        ... its launch time, bytes and fractions
+  roofline.multi_rank_schedule the schedule every rank of an N>1 run executes, on this one GPU: whole S3 with a
+                               1-rank communicator, and one rank's share of an 8-GPU run (S3/8 with a loopback halo)
+  workloads                    BASELINE.json's other configurations: S1 (config 3), S2 at N=1 (config 4), the two
+                               stand-ins for Queen_4147 (config 5), each with its plain-values twin where a dictionary applies
 """
 import argparse
 import json
@@ -101,6 +109,8 @@ def cpu_baseline(A, b, x0, family, seconds=15.0):
 
 
 PREWARM = 300      # untimed iterations before any clock starts: the chip's clocks are up, whatever --warmup says
+VARIANTS = ['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg', 'cg_cg', 'gv_cg']
+FAMILY = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe', 'cg_cg': 'cg_cg', 'gv_cg': 'gv'}
 
 
 def main():
@@ -110,7 +120,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='s3',
                     help='s1 s2 s3 s4 s4b s3_8th s1_small s3_small; queen if QUEEN_4147_MTX names the MatrixMarket file')
-    ap.add_argument('--variant', default='pipe_pr_cg', choices=['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg', 'cg_cg', 'gv_cg'],
+    ap.add_argument('--variant', default='pipe_pr_cg', choices=VARIANTS,
                     help='pipe_pr_pcg = the pipelined variant with the Jacobi preconditioner (figure_gen.py:42-44)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-comm', action='store_true',
@@ -119,7 +129,9 @@ def main():
     ap.add_argument('--no-plain-values', action='store_true',
                     help='skip the second timed run with the value dictionary off')
     ap.add_argument('--no-multi-rank-leg', action='store_true',
-                    help='skip the extra N=1 run of the multi-rank schedule (1-rank communicator)')
+                    help='skip the extra N=1 runs of the multi-rank schedule (1-rank communicator, S3/8 slice)')
+    ap.add_argument('--no-workloads', action='store_true',
+                    help="skip the extra N=1 runs of BASELINE.json's other configurations (S1, S2, s4b, s4)")
     args = ap.parse_args()
 
     # stdout is a protocol here (exactly one JSON line on rank 0): libraries that chat on
@@ -152,42 +164,17 @@ def main():
     else:
         comm = scaling.SelfComm()
 
-    # ---- the rank's row block of the synthetic operator, right-hand side as the reference --
-    wl = problems.WORKLOADS[args.workload]
-    n = wl['n']
-    if world > 1 and args.workload in ('s4', 'queen'):
-        # irregular degrees: split where the nonzeros balance, not the rows (the generator / file gives
-        # every rank the whole row pointer anyway)
-        offsets = partition.nnz_balanced_offsets(wl['make']().indptr, world)
-    else:
-        offsets = partition.even_offsets(n, world)
-    lo, hi = int(offsets[rank]), int(offsets[rank + 1])
-    A_rows = wl['make'](rows=(lo, hi))
-    b, x0, x_true = problems.reference_rhs(A_rows, n)
-    nnz_local = int(A_rows.nnz)
-    nnz_total = sum(comm.allgather_obj(nnz_local))
-    n_local = hi - lo
-
-    def one_rank_comm_device(knobs=None):
-        uid = np.zeros((2, 128), dtype=np.uint8)
-        path = L.default_rccl_path()
-        for i in range(2):
-            L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid[i])))
-        return DeviceCSR(A_rows.tocsr(), device=local_rank, comm_init=(0, 1, uid[:1].tobytes(), path), knobs=knobs)
-
-    t_setup = time.perf_counter()
-    if world == 1 and args.force_comm:
-        dev = one_rank_comm_device()
-    else:
-        op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
-        dev = op.dev
-    t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
-    variant = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P,
-               'cg_cg': L.CG_CG, 'gv_cg': L.GV}[args.variant]
-    inv_diag = (1.0 / A_rows.tocsr()[:, lo:hi].diagonal()) if args.variant == 'pipe_pr_pcg' else None
     K, W = args.steps, args.warmup
+    VAR = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P,
+           'cg_cg': L.CG_CG, 'gv_cg': L.GV}
 
-    def timed_run(dev):
+    def one_rank_comm_device(A, halo=None, knobs=None):
+        uid = np.zeros((1, 128), dtype=np.uint8)
+        path = L.default_rccl_path()
+        L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid[0])))
+        return DeviceCSR(A, device=local_rank, comm_init=(0, 1, uid.tobytes(), path), halo=halo, knobs=knobs)
+
+    def timed_run(dev, variant, b, x0, inv_diag=None):
         """(elapsed, host enqueue time, kernel timings, residual finite, error).  A library error (a one-launch
         iteration of a communicator session that waited longer than its bound for the reduction) is RETURNED, not
         raised: every rank must reach the barriers below, and the decision what to do next is taken collectively."""
@@ -198,7 +185,9 @@ def main():
             dev.sync()
         except L.PrcgError as exc:
             err = str(exc)
-        dev.set_profiling(max(1, K // 100))
+        # HIP events bracket every 4th launch at most (two marker packets cost ~7 us of queue time around a 150 us
+        # launch: bracketing every launch of a 20-step run made it 7 % slower than a 500-step one)
+        dev.set_profiling(max(4, K // 100))
         comm.Barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -223,7 +212,7 @@ def main():
         finite = bool(np.isfinite(dev.get_scalars(PREWARM + W + K)[L.S_NU]))
         return elapsed, t_enq, dev.timings(), finite, None
 
-    def product_rates(dev, sched):
+    def product_rates(dev, sched, n, nnz):
         """Standalone SpMV / two-vector SpMM of the resident operator (north_star: effective SpMV HBM GB/s)."""
         xin = np.random.default_rng(0).standard_normal(n)
         dev.matvec(xin, reps=30)
@@ -231,16 +220,71 @@ def main():
         rs = np.stack([xin, xin[::-1]], axis=1)
         dev.matmat2(rs, reps=10)
         _, ms2 = dev.matmat2(rs, reps=50)
-        b1, b2 = spmv_bytes(n, nnz_total), spmm2_bytes(n, nnz_total)
+        b1, b2 = spmv_bytes(n, nnz), spmm2_bytes(n, nnz)
         opb = dev.operator_bytes()
-        m1, m2 = moved_bytes(b1, n, nnz_total, opb), moved_bytes(b2, n, nnz_total, opb)
+        m1, m2 = moved_bytes(b1, n, nnz, opb), moved_bytes(b2, n, nnz, opb)
         return {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'], 'window_kernels': sched['window'],
                 'spmv_ms': ms1, 'spmv_moved_GBps': m1 / ms1 * 1e-6, 'spmv_frac_of_peak': m1 / ms1 * 1e-6 / HBM_PEAK_GBS,
                 'spmv_algorithmic_GBps': b1 / ms1 * 1e-6,
                 'spmm2_ms': ms2, 'spmm2_moved_GBps': m2 / ms2 * 1e-6, 'spmm2_frac_of_peak': m2 / ms2 * 1e-6 / HBM_PEAK_GBS,
                 'spmm2_algorithmic_GBps': b2 / ms2 * 1e-6}
 
-    elapsed, t_enq, tim, finite, run_err = timed_run(dev)
+    def launch_bytes(vname, sched, n, nnz):
+        """(algorithmic bytes of the dominant launch per SURVEY 8d, its name)"""
+        if sched['fused'] and vname.startswith('pipe_'):
+            # + (r,s) read and written beside (r~,s~) and the diagonal with Jacobi; + w read and written in the 'p' flavours
+            kb = fused_bytes(n, nnz) + (40 * n if vname == 'pipe_pr_pcg' else 0) + (16 * n if vname == 'pipe_p_cg' else 0)
+            return kb, ('one-launch pipelined iteration: two-vector SpMM + next vector update + inner products '
+                        '(' + ('k_win_tiles<2,fused>' if sched['window'] else 'k_spmv_tiles<2,fused>') + ')')
+        if vname.startswith('pipe_'):
+            return spmm2_bytes(n, nnz), 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
+        if sched['fused'] and vname == 'pr_cg':
+            return spmv_bytes(n, nnz) + 48 * n, 'one-launch predict-and-recompute iteration (k_win_tiles<1,PROne>)'
+        return spmv_bytes(n, nnz), 'SpMV launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
+
+    def summarize(vname, dev, elapsed, tim, finite, n, nnz):
+        """value + launch time + must-move bytes + fractions of one timed run on one GPU"""
+        sched = dev.schedule()
+        kb, kname = launch_bytes(vname, sched, n, nnz)
+        opb = dev.operator_bytes()
+        mv = moved_bytes(kb, n, nnz, opb)
+        ms = tim['spmv_ms']
+        return {'value': K / elapsed, 'unit': 'iters/s', 'ms_per_step': elapsed / K * 1e3, 'kernel': kname, 'avg_launch_ms': ms,
+                'launches_sampled': tim['spmv_samples'], 'update_kernel_ms': tim['update_ms'],
+                'bytes_must_move': mv, 'moved_GBps': mv / ms * 1e-6 if ms > 0 else 0.0,
+                'frac': mv / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                'bytes_algorithmic': kb, 'algorithmic_frac': kb / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                'operator_bytes': opb, 'operator_bytes_per_nonzero': opb / max(nnz, 1),
+                'window_kernels': sched['window'], 'value_dictionary': sched['value_dict'], 'col_bytes': sched['col_bytes'],
+                'one_launch': sched['fused'], 'residual_finite': finite}
+
+    # ---- the rank's row block of the synthetic operator, right-hand side as the reference --
+    wl = problems.WORKLOADS[args.workload]
+    n = wl['n']
+    if world > 1 and args.workload in ('s4', 'queen'):
+        # irregular degrees: split where the nonzeros balance, not the rows (the generator / file gives
+        # every rank the whole row pointer anyway)
+        offsets = partition.nnz_balanced_offsets(wl['make']().indptr, world)
+    else:
+        offsets = partition.even_offsets(n, world)
+    lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+    A_rows = wl['make'](rows=(lo, hi))
+    b, x0, x_true = problems.reference_rhs(A_rows, n)
+    nnz_local = int(A_rows.nnz)
+    nnz_total = sum(comm.allgather_obj(nnz_local))
+    n_local = hi - lo
+
+    t_setup = time.perf_counter()
+    if world == 1 and args.force_comm:
+        dev = one_rank_comm_device(A_rows.tocsr())
+    else:
+        op = scaling.RowBlockOperator(comm, A_rows, device=local_rank)
+        dev = op.dev
+    t_setup = time.perf_counter() - t_setup     # tiling, stream encodings, upload (outside the timed region)
+    variant = VAR[args.variant]
+    inv_diag = (1.0 / A_rows.tocsr()[:, lo:hi].diagonal()) if args.variant == 'pipe_pr_pcg' else None
+
+    elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
     fallback = None
     if run_err is not None:
         # the one-launch schedule of a communicator session could not be kept fed on this node (its waits are
@@ -248,15 +292,15 @@ def main():
         fallback = run_err
         dev.close()
         if world == 1 and args.force_comm:
-            dev = one_rank_comm_device({'PRCG_FUSED_COMM': '0'})
+            dev = one_rank_comm_device(A_rows.tocsr(), knobs={'PRCG_FUSED_COMM': '0'})
         else:
             op = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0'})
             dev = op.dev
-        elapsed, t_enq, tim, finite, run_err = timed_run(dev)
+        elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
         if run_err is not None:
             raise RuntimeError(run_err)
     sched = dev.schedule()
-    spmv = product_rates(dev, sched) if world == 1 else None
+    spmv = product_rates(dev, sched, n, nnz_total) if world == 1 else None
 
     # An operator whose values do not repeat (an assembled FEM matrix) streams the doubles themselves: time
     # that path too, same matrix, value dictionary off.  This leg IS what SURVEY.md 8d's algorithmic bytes
@@ -264,46 +308,89 @@ def main():
     plain = None
     if world == 1 and not args.force_comm and sched['value_dict'] and not args.no_plain_values:
         dev2 = DeviceCSR(A_rows.tocsr(), device=local_rank, knobs={'PRCG_VALDICT': '0'})
-        e2, _, tim2, fin2, _err2 = timed_run(dev2)
+        e2, _, tim2, fin2, _err2 = timed_run(dev2, variant, b, x0, inv_diag)
         sched2 = dev2.schedule()
-        plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2), dev2.operator_bytes())
+        plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2, n, nnz_total), dev2.operator_bytes())
         dev2.close()
 
-    # What the schedule every rank of an N>1 run executes costs on ONE GPU: the same loop with a 1-rank
-    # RCCL communicator (two streams, events, merged all-gather / all-reduce per iteration).
+    # What the schedule every rank of an N>1 run executes costs on ONE GPU: (a) the same loop with a 1-rank
+    # communicator; (b) one rank's share of an 8-GPU run: one eighth of S3 with a loopback halo (boundary tiles, ghost
+    # rows, the whole exchange chain) beside the plain one-launch schedule on the same slice.
     multi = None
     if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant.startswith('pipe_'):
-        try:
-            dev3 = one_rank_comm_device()
-            e3, q3, tim3, fin3, err3 = timed_run(dev3)
+        def comm_leg(A, halo, bb, xx0, dd):
+            d3 = one_rank_comm_device(A, halo)
+            e3, q3, tim3, fin3, err3 = timed_run(d3, variant, bb, xx0, dd)
             if err3:
+                d3.close()
                 raise RuntimeError(err3)
-            s3 = dev3.schedule()
-            multi = {'what': 'same workload and steps through the schedule every rank of an N>1 run executes, driven by a 1-rank RCCL '
-                             'communicator: ' + ('one launch per iteration that waits in-kernel for the reduction the communication '
-                             'stream performs meanwhile (pack, ncclAllGather, unpack + publish)' if s3['fused_comm'] else
-                             'update kernel + SpMM per iteration, reduction and exchange on the communication stream'),
-                     'one_launch': s3['fused_comm'],
-                     'value': K / e3, 'unit': 'iters/s', 'ms_per_step': e3 / K * 1e3, 'spmm_ms': tim3['spmv_ms'],
-                     'update_ms': tim3['update_ms'], 'merged_allgather': s3['gather'], 'residual_finite': fin3,
-                     'host_enqueue_us_per_step': q3 / K * 1e6}
-            dev3.close()
+            s3 = d3.schedule()
+            out = {'one_launch': s3['fused_comm'], 'merged_exchange': s3['gather'], 'peer_stores': s3.get('peer', False),
+                   'value': K / e3, 'unit': 'iters/s', 'us_per_iteration': e3 / K * 1e6,
+                   'launch_us': tim3['spmv_ms'] * 1e3, 'update_us': tim3['update_ms'] * 1e3, 'residual_finite': fin3,
+                   'host_enqueue_us_per_step': q3 / K * 1e6}
+            d3.close()
+            return out
+        try:
+            multi = {'what': 'the schedule every rank of an N>1 run executes, timed on this one GPU with a 1-rank communicator '
+                             '(same steps and warm-up as the headline)'}
+            multi['s3'] = comm_leg(A_rows.tocsr(), None, b, x0, inv_diag)
+            # compatibility with earlier rounds' records
+            multi.update({k: multi['s3'][k] for k in ('one_launch', 'value', 'unit', 'host_enqueue_us_per_step')})
+            multi['ms_per_step'] = multi['s3']['us_per_iteration'] * 1e-3
+            if args.workload == 's3':
+                wl8 = problems.WORKLOADS['s3_8th']
+                A8 = wl8['make']()
+                b8, x8, _ = problems.reference_rhs(A8, wl8['n'])
+                d8 = (1.0 / A8.diagonal()) if inv_diag is not None else None
+                A8_loop, halo8, _ = partition.loopback_problem(A8, 7)       # 14 ghost rows: what a rank of the band receives
+                dp = DeviceCSR(A8, device=local_rank)
+                ep, qp, timp, finp, _ = timed_run(dp, variant, b8, x8, d8)
+                dp.close()
+                leg = comm_leg(A8_loop, halo8, b8, x8, d8)
+                multi['s3_8th'] = {'what': 'one rank\'s share of S3 on 8 GPUs (n = 1.25e6) on this GPU: the plain one-launch schedule, and the '
+                                           'communicator schedule with a loopback halo (7 ghost rows per side, boundary tiles, the whole '
+                                           'exchange chain); a real 8-rank exchange adds xGMI latency to the second',
+                                   'plain_us_per_iteration': ep / K * 1e6, 'plain_host_enqueue_us_per_step': qp / K * 1e6,
+                                   'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg,
+                                   'single_gpu_us_per_iteration': elapsed / K * 1e6,
+                                   'speedup_ceiling_at_8_ranks': (elapsed / K * 1e6) / leg['us_per_iteration'] if leg['us_per_iteration'] > 0 else None}
         except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it
-            multi = {'error': str(exc)[:200]}
+            multi = dict(multi or {}, error=str(exc)[:300])
+
+    # BASELINE.json's other configurations on this GPU (configs 3, 4 at N=1, 5 through its stand-ins)
+    others = None
+    if world == 1 and not args.force_comm and not args.no_workloads and args.workload == 's3' and args.variant == 'pipe_pr_cg':
+        others = {}
+        for name, cfg in (('s1', 'BASELINE config 3'), ('s2', 'BASELINE config 4 at N=1'),
+                          ('s4b', 'BASELINE config 5, FEM-like stand-in for Queen_4147'),
+                          ('s4', 'BASELINE config 5, random-offset irregular stand-in (SURVEY 8d)')):
+            try:
+                w2 = problems.WORKLOADS[name]
+                A2 = w2['make']()
+                b2, x2, _ = problems.reference_rhs(A2, w2['n'])
+                d2 = DeviceCSR(A2, device=local_rank)
+                e, _, tm, fin, er = timed_run(d2, variant, b2, x2)
+                if er:
+                    raise RuntimeError(er)
+                rec = dict(summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz)), config=cfg, workload=w2['desc'],
+                           n=w2['n'], nnz=int(A2.nnz))
+                has_dict = d2.schedule()['value_dict']
+                d2.close()
+                if has_dict:
+                    d2 = DeviceCSR(A2, device=local_rank, knobs={'PRCG_VALDICT': '0'})
+                    e, _, tm, fin, er = timed_run(d2, variant, b2, x2)
+                    if not er:
+                        rec['plain_values'] = summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz))
+                    d2.close()
+                others[name] = rec
+                del A2
+            except Exception as exc:
+                others[name] = {'error': str(exc)[:300]}
 
     if rank == 0:
         fused = sched['fused']
-        if fused:
-            # + (r,s) read and written beside (r~,s~) and the diagonal with Jacobi; + w read and written in the 'p' flavours
-            kbytes = fused_bytes(n_local, nnz_local) + (40 * n_local if inv_diag is not None else 0) + (16 * n_local if args.variant == 'pipe_p_cg' else 0)
-            kname = ('one-launch pipelined iteration: two-vector SpMM + next vector update + inner products '
-                     '(' + ('k_win_tiles<2,fused>' if sched['window'] else 'k_spmv_tiles<2,fused>') + ')')
-        elif args.variant.startswith('pipe_'):
-            kbytes = spmm2_bytes(n_local, nnz_local)
-            kname = 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
-        else:
-            kbytes = spmv_bytes(n_local, nnz_local)
-            kname = 'SpMV, interior launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
+        kbytes, kname = launch_bytes(args.variant, sched, n_local, nnz_local)
         ms = tim['spmv_ms']
         opb = dev.operator_bytes()
         moved = moved_bytes(kbytes, n_local, nnz_local, opb)
@@ -325,10 +412,12 @@ def main():
                               'bytes_per_launch': kbytes, 'GBps': kbytes / ms * 1e-6 if ms > 0 else 0.0,
                               'frac_of_peak': kbytes / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0}}
         assert roof['frac'] <= 1.0, 'a physical fraction cannot exceed 1: the byte count is wrong'
+        value_general = None
         if plain is not None:
             e2, tim2, fin2, sched2, spmv2, opb2 = plain
             ms2 = tim2['spmv_ms']
             mv2 = moved_bytes(kbytes, n_local, nnz_local, opb2)
+            value_general = K / e2
             roof['plain_values'] = {
                 'what': 'same matrix and loop with the value dictionary off (PRCG_VALDICT=0): the rate of an operator '
                         f"whose values do not repeat; {sched2['col_bytes']} B column stream + 8 B value per nonzero",
@@ -348,6 +437,11 @@ def main():
             'value': K / elapsed, 'unit': 'iters/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'value_general_csr': value_general,
+            'value_general_csr_note': ('iterations/s of the SAME loop on the SAME matrix with the value dictionary off: every nonzero moves its '
+                                       '8-byte value, as for an assembled matrix whose values do not repeat.  `value` rides on S3\'s repeated '
+                                       'coefficients (one constant off the diagonal: 15 MB of operator instead of 1.2 GB); this is the number '
+                                       'that transfers to other matrices') if value_general is not None else None,
             'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
                        'partition': f'row blocks x{world}' + (' (nnz-balanced)' if world > 1 and args.workload in ('s4', 'queen') else ''), 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
                        'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6,
@@ -356,10 +450,10 @@ def main():
                        'schedule': {k: v for k, v in sched.items()}},
             'roofline': roof,
         }
+        if others:
+            out['workloads'] = others
         if world == 1 and not args.no_cpu_baseline:
-            fam = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe', 'cg_cg': 'cg_cg',
-                   'gv_cg': 'gv'}[args.variant]
-            out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, fam, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, FAMILY[args.variant], args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
         sys.stdout.flush()

@@ -270,6 +270,17 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
 int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int n_peers,
                      const int32_t* peer_rank, const int64_t* recv_ptr, int64_t slot_doubles,
                      int32_t* ghost_src);
+/* Diagnostic (tests): how the resident operator is laid out for the one-launch iteration, i.e. everything the summation
+ * order of its inner products depends on.  out[0..8) = {1 if window operator, window geometry id, rows per window tile,
+ * number of tiles T, workgroups of the last one-launch iteration (0: none yet), waves per workgroup of that launch,
+ * interior tiles, 0}, then T pairs (first row, end row) in table order.  Returns the number of int64 written, -needed
+ * if capacity is too small, -1 on a bad argument.  tests/device_order.py rebuilds the launch's reduction tree from it. */
+int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity);
+/* Capacity rule of every vector a matrix-product launch reads (window pages are whole 64-column blocks, the narrow
+ * column encodings decode a few out-of-tile bytes per tile): n_rows + n_ghost entries of `components` doubles plus
+ * 65,536 spare entries must lie between the pointer and the end of its allocation.  The engine evaluates this at
+ * every launch and returns PRCG_EINVAL instead of launching (a short source used to be a memory fault).  1 = ok. */
+int prcg_window_source_ok(int64_t n_rows, int64_t n_ghost, int components, int64_t bytes_available);
 /* the tile caps the device kernels were compiled for */
 void prcg_tile_caps(int* cap_nnz, int* cap_rows);
 

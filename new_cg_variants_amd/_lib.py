@@ -80,6 +80,8 @@ _SIGNATURES = {
                                      C.POINTER(C.c_int)]),
     'prcg_plan_window_images': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.c_int, _P]),
     'prcg_tile_caps': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'prcg_window_source_ok': (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int64]),
+    'prcg_debug_layout': (C.c_int64, [_P, _P, C.c_int64]),
 }
 
 PREC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))   # prcg_prec_fn

@@ -20,7 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -194,6 +196,7 @@ struct prcg_handle {
                                  // operators (update; product with the direction formed in the staged window), else 3
     double* p_cur = nullptr;     // ... the current direction: p / p2 (the product launch writes the other one)
     int hs_pend_mu = 0;          // ... mu of iteration pend_k exists only as this many block partials in partB
+    int last_grid = 0;           // workgroups of the last one-launch iteration (prcg_debug_layout)
     int pend_parts = 0;          // fused: dots[pend_k] exist only as this many block partials ...
     int pend_k = -1;             // ... of iteration pend_k, in pend_buf
     double* pend_buf = nullptr;
@@ -232,6 +235,18 @@ struct prcg_handle {
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
     bool multi() const { return comm != nullptr; }
+
+    bool debug_short_sources = false;    // PRCG_DEBUG_SHORT_SOURCES=1 (TESTS ONLY): Hestenes-Stiefel sessions allocate r without
+                                         // the spare entries a window source needs -- the launch must be refused, not fault
+    // every vector a window launch may stage (the pointer handed to the launch lies inside one of them)
+    const DevBuf* owner(const void* q) const {
+        const DevBuf* all[] = {&tmp_ext, &t1, &x, &xp, &p, &p2, &rs, &rs2, &rst, &rst2, &wu, &wt, &wv, &r, &r2, &s, &s2, &rt, &rt2,
+                               &st, &st2, &b, &xt, &dinv, &e_ext, &w, &w2, &u, &tvec, &ut, &cb_stage};
+        const char* c = static_cast<const char*>(q);
+        for (const DevBuf* d : all)
+            if (d->p && c >= static_cast<const char*>(d->p) && c < static_cast<const char*>(d->p) + d->bytes) return d;
+        return nullptr;
+    }
 };
 
 namespace {
@@ -264,7 +279,9 @@ int fail(prcg_t* h, int code, const char* fmt, ...) {
 
 #define LAUNCHCHK(h, grid)                                                                    \
     do {                                                                                      \
-        if ((grid) < 0) return fail(h, PRCG_EHIP, "kernel launch failed (%s:%d)", __FILE__, __LINE__); \
+        const int g__ = (grid);                                                               \
+        if (g__ == -2) return PRCG_EINVAL;        /* refused by check_sources: message set */  \
+        if (g__ < 0) return fail(h, PRCG_EHIP, "kernel launch failed (%s:%d)", __FILE__, __LINE__); \
     } while (0)
 
 #define CHECK(h, cond, ...)                                                                   \
@@ -283,10 +300,31 @@ int pick_tile_steps(int override_, int64_t n = 0, int64_t nnz = 0) {
     return kDefaultTileSteps;
 }
 
+// A window launch stages whole 64-column pages of its source vectors and the narrow column encodings of the
+// CSR-adaptive kernels decode a few out-of-tile bytes per tile: every such source must hold its n + g entries AND
+// kGatherPad spare ones behind them (prcg_window_source_ok).  Checked at every launch from the size of the
+// allocation the pointer lies in -- a short source is an error code, not a memory fault.
+int check_sources(prcg_t* h, std::initializer_list<std::pair<const void*, int>> srcs) {
+    for (const auto& sc : srcs) {
+        if (!sc.first) continue;
+        const DevBuf* d = h->owner(sc.first);
+        const int64_t avail = d ? (int64_t)(static_cast<const char*>(d->p) + d->bytes - static_cast<const char*>(sc.first)) : -1;
+        if (!d || !prcg_window_source_ok(h->n, h->g, sc.second, avail))
+            return fail(h, PRCG_EINVAL, "a matrix-product source vector holds %lld bytes, fewer than the %lld a launch over %lld rows + "
+                        "%lld ghosts may touch (%d components, %d spare entries): launch refused",
+                        (long long)avail, (long long)((h->n + h->g + kGatherPad) * (int64_t)sc.second * 8), (long long)h->n,
+                        (long long)h->g, sc.second, kGatherPad);
+    }
+    return PRCG_OK;
+}
+#define SRCCHK(h, ...) do { if (check_sources(h, {__VA_ARGS__})) return -2; } while (0)              // inside a launch helper (returns a grid)
+#define SRCCHK2(h, ...) do { if (check_sources(h, {__VA_ARGS__})) return PRCG_EINVAL; } while (0)   // inside an iterate_* function
+
 // The matrix products of the engine: window kernels when the operator qualified, else the
 // CSR-adaptive tile kernels.  which: 0 = every tile, 1 = interior tiles, 2 = tiles touching ghosts.
 int eng_spmv(prcg_t* h, hipStream_t st, int which, const double* x, double* y, SpmvEpilogue epi, const double* ep_r,
              const double* ep_d, double* ep_st, double* partials) {
+    SRCCHK(h, {x, 1});
     if (h->win) {
         const int first = which == 2 ? h->nwt_int : 0;
         const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
@@ -299,6 +337,7 @@ int eng_spmv(prcg_t* h, hipStream_t st, int which, const double* x, double* y, S
     return launch_spmv(st, A, h->tile_ptr(first), nt, h->steps, x, y, epi, ep_r, ep_d, ep_st, partials, h->kn);
 }
 int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu, int mask) {
+    SRCCHK(h, {rs, 2});
     if (h->win) {
         const int first = which == 2 ? h->nwt_int : 0;
         const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
@@ -310,6 +349,7 @@ int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu
     return launch_spmm2(st, A, h->tile_ptr(first), nt, h->steps, rs, wu, mask, h->kn);
 }
 int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f, int which = 0) {
+    SRCCHK(h, {f.in_old, 2});
     if (h->win) {
         const int first = which == 2 ? h->nwt_int : 0;
         const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
@@ -645,7 +685,7 @@ int iterate_pipe_fused(prcg_t* h, int k) {
     const int grid = eng_fused(h, h->sc, f);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
-    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
+    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out; h->last_grid = grid;
     h->rs_cur = rs_new;
     return PRCG_OK;
 }
@@ -690,6 +730,7 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int g1 = eng_fused(h, h->sc, f, 0);
     LAUNCHCHK(h, g1);
+    h->last_grid = g1;
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     const int g2 = 0;
     if (ext_signal) {
@@ -805,6 +846,7 @@ int iterate_hs_fused(prcg_t* h, int k) {
         hs.prev_partials = h->partA.d(); hs.nprev = g1;
         hs.dots_prev_out = dots_at(h, k); hs.dots_old = dots_at(h, k - 1);
         double* p_new = (h->p_cur == h->p.d()) ? h->p2.d() : h->p.d();
+        SRCCHK2(h, {h->prec ? h->rt.d() : h->r.d(), 1}, {h->p_cur, 1});
         prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
         grid = launch_win_hs(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom,
                              h->prec ? h->rt.d() : h->r.d(), h->p_cur, p_new, h->s.d(), h->partB.d(), coef_at(h, k), hs,
@@ -850,12 +892,13 @@ int iterate_pr_fused(prcg_t* h, int k) {
     f.pr.r = jac ? h->r.d() : nullptr; f.pr.s = jac ? h->s.d() : nullptr; f.pr.d = jac ? h->dinv.d() : nullptr;
     double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
     bool on = false;
+    SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.p_old, 1});
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_win_pr_one(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f,
                                        meurant(h->variant), part_out, coef_at(h, k), h->win_per_cu);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
-    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out;
+    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out; h->last_grid = grid;
     z_cur = z_new; zs_cur = zs_new; h->p_cur = p_new;
     return PRCG_OK;
 }
@@ -937,6 +980,7 @@ int iterate_cgcg_fused(prcg_t* h, int k) {
     f.pr.z_new = r_new; f.pr.zs_new = h->prec ? h->rt.d() : nullptr;
     f.pr.x = h->x.d(); f.pr.d = h->prec ? h->dinv.d() : nullptr;
     bool on = false;
+    SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.d, 1});
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_win_cg_w(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->w.d(),
                                      h->partB.d(), coef_at(h, k), h->win_per_cu);
@@ -961,6 +1005,7 @@ int iterate_gv_fused(prcg_t* h, int k) {
     f.pr.d = h->prec ? h->dinv.d() : nullptr;
     f.pr.rt = h->prec ? h->rt.d() : nullptr; f.pr.st = h->prec ? h->st.d() : nullptr;
     bool on = false;
+    SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.d, 1});
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_win_gv_w(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f, h->tvec.d(),
                                      h->partB.d(), coef_at(h, k), h->win_per_cu);
@@ -1047,13 +1092,14 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
     else if (k == "PRCG_WIN_MAX_MEAN") { if (v >= 1) h->win_max_mean = (int)v; }
     else if (k == "PRCG_WIN_ROWS") h->win_rows_override = (v == 64 || v == 128) ? (int)v : 0;
+    else if (k == "PRCG_DEBUG_SHORT_SOURCES") h->debug_short_sources = v != 0;
     else return false;
     return true;
 }
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1104,7 +1150,9 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         case PRCG_VEC_U: if (h->fused) return false; *base = h->wu.d() + 1; *stride = 2; return true;
         case PRCG_VEC_RT: if (!h->prec) return false; *base = (h->fused ? h->rs_cur : h->rst.d()); *stride = 2; return true;
         case PRCG_VEC_ST: if (!h->prec) return false; *base = (h->fused ? h->rs_cur : h->rst.d()) + 1; *stride = 2; return true;
-        case PRCG_VEC_WT: if (!h->prec || pipe_recompute(v)) return false; *base = h->wt.d(); return true;
+        // host-callback preconditioner sessions: w~ and u~ are stored state (what the callback returned), in every flavour
+        case PRCG_VEC_WT: if (!h->prec || (pipe_recompute(v) && !h->cb_session)) return false; *base = h->wt.d(); return true;
+        case PRCG_VEC_UT: if (!h->cb_session) return false; *base = h->ut.d(); return true;
         default: return false;
         }
     }
@@ -1786,7 +1834,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0 && !h->cb_session;
         // r (r~) is the staged-window source of the Hestenes-Stiefel product launch: like every vector that feeds a
         // product it has the spare entries behind its end (a window page of the last tile may reach past row n)
-        HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
+        HIPCHK(h, h->r.ensure((size_t)(h->debug_short_sources ? n : ne) * D, h->sc));
         HIPCHK(h, h->s.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->st.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
@@ -2151,6 +2199,37 @@ int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int 
     if (rank < 0 || doubles_per_table < 1 || !tables || n_peers < 0 || slot_doubles < 8 || (slot_doubles & 1)) return -1;
     if (n_peers > 0 && (!peer_rank || !recv_ptr || !ghost_src)) return -1;
     return plan_gather_sources(rank, doubles_per_table, tables, n_peers, peer_rank, recv_ptr, slot_doubles, ghost_src);
+}
+
+int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity) {
+    if (!h || !h->have_csr || !out) return -1;
+    const int64_t nt = h->win ? (int64_t)h->nwt_int + h->nwt_bnd : (int64_t)h->nt_int + h->nt_bnd;
+    const int64_t need = 8 + 2 * nt;
+    if (capacity < need) return -need;
+    out[0] = h->win ? 1 : 0;
+    out[1] = h->win ? h->win_geom : -1;
+    out[2] = h->win ? h->win_rows : 0;
+    out[3] = nt;
+    out[4] = h->last_grid;                                                        // workgroups of the last one-launch iteration
+    out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm) : 4;
+    out[6] = h->win ? h->nwt_int : h->nt_int;
+    out[7] = 0;
+    std::vector<int32_t> rows((size_t)nt * 2);
+    if (h->win) {
+        std::vector<WTile> t((size_t)nt);
+        if (nt && hipMemcpy(t.data(), h->wtiles.p, (size_t)nt * sizeof(WTile), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (int64_t i = 0; i < nt; ++i) { out[8 + 2 * i] = t[(size_t)i].rb; out[9 + 2 * i] = t[(size_t)i].re; }
+    } else {
+        std::vector<Tile> t((size_t)nt);
+        if (nt && hipMemcpy(t.data(), h->tiles.p, (size_t)nt * sizeof(Tile), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        for (int64_t i = 0; i < nt; ++i) { out[8 + 2 * i] = t[(size_t)i].row_begin; out[9 + 2 * i] = t[(size_t)i].row_end; }
+    }
+    return need;
+}
+
+int prcg_window_source_ok(int64_t n_rows, int64_t n_ghost, int components, int64_t bytes_available) {
+    if (n_rows < 0 || n_ghost < 0 || components < 1) return 0;
+    return bytes_available >= (n_rows + n_ghost + (int64_t)kGatherPad) * components * (int64_t)sizeof(double) ? 1 : 0;
 }
 
 void prcg_tile_caps(int* cap_nnz, int* cap_rows) {

@@ -185,6 +185,8 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
                      int write_mask, int per_cu);
 int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
                           int per_cu);
+// waves per workgroup of that launch (the inner products' summation order depends on it: prcg_debug_layout)
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred);
 // Second of the TWO launches of a Hestenes-Stiefel iteration on a window operator (hs_cg.py:57-61,
 // hs_pcg :120-124).  The first (launch_hs_update_xr with `prev`) left nu_k = <r~,r> as block partials;
 // every workgroup of this launch sums them in the same fixed order, b_k = nu_k / nu_k1, and the window of

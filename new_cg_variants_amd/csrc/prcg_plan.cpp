@@ -3,6 +3,8 @@
 #include "prcg_plan.h"
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cstring>
 #include <thread>
 #include <unordered_map>
@@ -263,6 +265,7 @@ StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indpt
                                  std::vector<uint16_t>& rel_store) {
     StreamStats st;
     ImageIndex ic, iv, ir;
+    std::map<std::array<int, 8>, int> ids;
     cw_store.clear(); vidx_store.clear(); rel_store.clear();
     std::vector<uint16_t> rel;
     for (auto& t : tiles) {
@@ -272,7 +275,12 @@ StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indpt
         rel.resize((size_t)(t.re - t.rb) + 1);
         for (int r = t.rb; r <= t.re; ++r) rel[(size_t)(r - t.rb)] = (uint16_t)(indptr[r] - t.lo);
         t.src_r = (int)place_image(rel_store, ir, rel.data(), (int)rel.size(), 0, 1, share, &st.rel_images);
-        t.spare = 0;
+        // image id: tiles that read the same bytes for all three streams, with the same table and the same shape, carry
+        // the same non-zero number (the dictionary kernels keep a tile's decoded rows in registers while it repeats)
+        const std::array<int, 8> key{t.src_c, t.src_v, t.src_r, t.vd_first, t.vd_count, len, t.re - t.rb, t.maxlen};
+        auto it = ids.find(key);
+        if (it == ids.end()) it = ids.emplace(key, (int)ids.size() + 1).first;
+        t.spare = it->second;
     }
     // the kernels' 16-byte loads of the last image may run past its end; a lane of a short tile reads rel[0], rel[1]
     cw_store.resize(cw_store.size() + 32, CW(0));

@@ -30,7 +30,7 @@ struct alignas(16) WTile {
     int page_col[kWinMaxPages];          // first column of each page
     // where the kernel reads the tile's encoded streams (share_window_streams): 16-aligned start of the
     // window-index image / of the value-index image (elements), start of the relative row pointers
-    int src_c, src_v, src_r, spare;
+    int src_c, src_v, src_r, spare;      // spare: image id (share_window_streams), equal for tiles that read identical streams
 };
 #endif
 struct WinPlan {

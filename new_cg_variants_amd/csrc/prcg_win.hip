@@ -42,6 +42,12 @@ namespace {
 #ifndef PRCG_WIN_UNROLL
 #define PRCG_WIN_UNROLL 8
 #endif
+#ifndef PRCG_WIN_UNIFORM_ROWS
+#define PRCG_WIN_UNIFORM_ROWS 1  // 0: no scalar-value / scalar-offset row walk (A/B builds)
+#endif
+#ifndef PRCG_WIN_ROW_CACHE
+#define PRCG_WIN_ROW_CACHE 1      // 0: the dictionary kernels re-read their shared stream images for every tile (A/B builds)
+#endif
 constexpr int kU = PRCG_WIN_UNROLL;
 
 // wave-uniform view of one tile descriptor
@@ -49,6 +55,7 @@ template <int PG>
 struct WDesc {
     int rb, re, lo, hi, np, own, maxlen, vdf, vdc;
     int srcc, srcv, srcr;      // where the tile's (possibly shared) stream images start: window indices, value indices, row pointers
+    int img;                   // image id: equal (and non-zero) for tiles that read identical streams, table and shape
     int pc[PG];
 };
 
@@ -63,7 +70,7 @@ __device__ __forceinline__ WDesc<PG> read_desc(const int4* __restrict__ wt, int 
     d.maxlen = __builtin_amdgcn_readfirstlane(b.y);
     d.vdf = __builtin_amdgcn_readfirstlane(b.z); d.vdc = __builtin_amdgcn_readfirstlane(b.w);
     d.srcc = __builtin_amdgcn_readfirstlane(e.x); d.srcv = __builtin_amdgcn_readfirstlane(e.y);
-    d.srcr = __builtin_amdgcn_readfirstlane(e.z);
+    d.srcr = __builtin_amdgcn_readfirstlane(e.z); d.img = __builtin_amdgcn_readfirstlane(e.w);
 #pragma unroll
     for (int q = 0; q < (PG + 3) / 4; ++q) {
         const int4 p = wt[t * 6 + 2 + q];
@@ -104,11 +111,41 @@ struct WRegs {
     d3_t zrow[M];                       // one-launch predict-and-recompute: (z, zs, p_old) of those rows; x in xp[].x, (r,s) in rsx[]
 };
 
+// Row cache of the dictionary kernels.  Tiles whose stream images are SHARED (prcg_plan.h: share_window_streams --
+// a band keeps 3 images for 156,250 tiles) hand a wave the same bytes tile after tile: the window indices and the
+// value-dictionary indices of the lane's own row(s) are then kept in registers, packed, across tiles, and a tile
+// whose image equals the previous one's neither requests nor parks its index streams, row pointers and dictionary
+// again, nor reads an index byte from LDS in the row walk (the wave's dependent chain index byte -> operand was what
+// bound these kernels, profiles/r02_sweeps.md I).  With at most two distinct values in the tile's table the two
+// entries are wave-uniform scalars and the value is a select, no LDS read.  Same products, same order.
+// (64-row tiles with 1-byte window indices only: the 128-row stencil geometries rarely see the same image twice in a
+//  row -- S2's images repeat every 729 tiles -- and lose occupancy to the cache registers: S2 -17 %, S1 -5 % when tried)
+constexpr int win_row_cache_len(int m, int cw, bool vd) { return (vd && PRCG_WIN_ROW_CACHE && cw == 8 && m == 1) ? 16 : 0; }
+template <int M, int RL, int CW>
+struct RowCache {
+    unsigned c[M][RL > 0 ? RL * (CW / 8) / 4 : 1];   // window indices of row (rb + j*64 + lane), nonzero u at byte / half-word u
+    unsigned v[M][RL > 0 ? RL / 4 : 1];              // value-dictionary indices, one byte each
+    int len[M];                                       // length of that row (0: lane has no row)
+    int img;                                          // which image the cache holds (WTile::spare; 0: none) -- wave-uniform
+    double d0, d1;                                    // the table's entries when vdc <= 2
+    // "uniform rows" (wave-uniform; a band or a stencil away from its edges): all 64 lanes own a full row, nonzero u of
+    // every row has the same value index and sits at window index (lane + cbase[u]) -- value and window offset of
+    // nonzero u are then SCALARS: no per-lane index extraction, no value select
+    bool uni;
+    unsigned cbase[RL > 0 ? RL / 4 : 1];              // lane 0's packed window indices = the offsets cbase[u]
+    unsigned vmask;                                   // bit u: value index of nonzero u (vdc <= 2)
+};
+template <int PG, int M, int RL, int CW>
+__device__ __forceinline__ bool same_image(const RowCache<M, RL, CW>& rc, const WDesc<PG>& d) {
+    if constexpr (RL == 0) return false;
+    return d.img != 0 && d.img == rc.img;
+}
+
 template <int NV, int EPI, int M, int PG, int CW, bool VD>
 __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
                                             const typename VecT<NV>::type* __restrict__ X, const double* __restrict__ X2,
                                             const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
-                                            WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R) {
+                                            WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -116,6 +153,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
     // branch-free: a lane whose chunk lies past the image re-reads its first chunk (hot line)
     const int len = (d.lo & 15) + (d.hi - d.lo);
     const int o16 = lane * 16 < len ? lane * 16 : 0;
+    if (!skip_img) {                                                        // wave-uniform
     if constexpr (VD) {
         R.vi = *reinterpret_cast<const u4_t*>(A.vidx8 + d.srcv + o16);
 #pragma unroll
@@ -141,6 +179,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             R.c[k] = *reinterpret_cast<const u4_t*>(A.cw16 + d.srcc + (q < len ? q : 0));
         }
     }
+    }
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
         if (p < d.np) {                                                     // wave-uniform branch
@@ -160,8 +199,10 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         const int row = d.rb + j * 64 + lane;
         const int rr = row < d.re ? row : d.rb;
         const int jj = row < d.re ? j * 64 + lane : 0;
-        R.s[j] = A.rel[d.srcr + jj];                     // row pointers relative to the tile's first nonzero
-        R.e[j] = A.rel[d.srcr + jj + 1];
+        if (!skip_img) {
+            R.s[j] = A.rel[d.srcr + jj];                 // row pointers relative to the tile's first nonzero
+            R.e[j] = A.rel[d.srcr + jj + 1];
+        }
         if constexpr (epi_rowset(EPI)) {
             R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr];
             R.xp[j].x = pr.x[rr];
@@ -218,11 +259,18 @@ struct WCtx {
 // freed registers, then lane i walks row i (and i + 64, ...).
 // STASH: only the products -- the row sums go to `stash` (this wave's LDS, [M][64] pairs), the epilogue
 // follows later (deferred form of the one-launch iteration).
-template <int NV, int EPI, int M, int PG, int CW, bool VD, bool STASH = false>
-__device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
+__device__ __forceinline__ double uniform_double(double v) {       // the same value in every lane -> scalar registers
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// `same_cur`: the tile's index streams, row pointers and dictionary were neither requested nor need parking -- its image
+// is the one the row cache `rc` holds (see RowCache).  Returns whether the tile requested here (dnext) is in that case.
+template <int NV, int EPI, int M, int PG, int CW, bool VD, int RL, bool STASH = false>
+__device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
-                                         double (&acc)[5], const Coefs& cf, double2* stash = nullptr,
-                                         bool acquire_first = false)
+                                         double (&acc)[5], const Coefs& cf, RowCache<M, RL, CW>& rc, bool same_cur,
+                                         double2* stash = nullptr, bool acquire_first = false)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -231,6 +279,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     const int pad = dcur.lo & 15;          // the staged stream starts at the 16-aligned nonzero below the tile's first
     // ---- park the tile's image in LDS (this is where the wave waits for ITS loads only: the
     //      loads of the tiles requested after it stay in flight) ----
+    if (!same_cur) {                                                        // wave-uniform
     if constexpr (VD) {
         *reinterpret_cast<u4_t*>(c.svi + lane * 16) = R.vi;
 #pragma unroll
@@ -246,6 +295,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(c.sc + (k * 512 + lane * 8) * 2) = R.c[k];
+    }
     }
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
@@ -283,15 +333,75 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
     }
     wave_lds_sync();
 
+    // ---- the row cache: after this tile it holds this tile's image (if its rows fit) ----
+    bool fill = false, next_same = false;
+    if constexpr (RL > 0) {
+        if (!same_cur) {
+            fill = dcur.maxlen <= RL && dcur.img != 0;
+            rc.img = fill ? dcur.img : 0;
+        }
+    }
+
     // ---- request the tile DEPTH ahead (the image registers are free again) ----
     if (have_next) {
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R);
+        next_same = same_image<PG>(rc, dnext);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same);
     }
 
-    // ---- lane i walks row i (and i + 64, ...) ----
     const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
+    if constexpr (RL > 0) {
+        if (fill) {
+            // the lane's own row(s): index bytes out of the parked streams, once per IMAGE instead of once per tile
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const bool active = dcur.rb + j * 64 + lane < dcur.re;
+                const int o = rs_[j] + pad;
+                const int len = active ? re_[j] - rs_[j] : 0;
+                rc.len[j] = len;
+#pragma unroll
+                for (int w = 0; w < RL * (CW / 8) / 4; ++w) rc.c[j][w] = 0u;
+#pragma unroll
+                for (int w = 0; w < RL / 4; ++w) rc.v[j][w] = 0u;
+#pragma unroll
+                for (int u = 0; u < RL; ++u) {
+                    int idx = o + u;
+                    idx = idx < last ? idx : last;
+                    unsigned cb, vb = c.svi[idx];
+                    if constexpr (CW == 8) cb = c.sc[idx]; else cb = reinterpret_cast<const unsigned short*>(c.sc)[idx];
+                    if (u >= len) { cb = 0u; vb = 0u; }
+                    if constexpr (CW == 8) rc.c[j][u >> 2] |= cb << (8 * (u & 3)); else rc.c[j][u >> 1] |= cb << (16 * (u & 1));
+                    rc.v[j][u >> 2] |= vb << (8 * (u & 3));
+                }
+            }
+            rc.d0 = uniform_double(c.sd[0]);
+            rc.d1 = uniform_double(c.sd[1]);
+            if constexpr (M == 1 && CW == 8) {
+                bool ok = rc.len[0] == dcur.maxlen;
+                unsigned vm = 0u;
+#pragma unroll
+                for (int w = 0; w < RL / 4; ++w) rc.cbase[w] = __builtin_amdgcn_readfirstlane(rc.c[0][w]);
+#pragma unroll
+                for (int u = 0; u < RL; ++u) {
+                    if (u < dcur.maxlen) {                                 // wave-uniform
+                        const int ci = (rc.c[0][u >> 2] >> (8 * (u & 3))) & 255, c0 = (rc.cbase[u >> 2] >> (8 * (u & 3))) & 255;
+                        const int vi = (rc.v[0][u >> 2] >> (8 * (u & 3))) & 255;
+                        const int v0 = __builtin_amdgcn_readfirstlane(vi);
+                        ok = ok && ci == c0 + lane && vi == v0;
+                        vm |= (unsigned)(v0 & 1) << u;
+                    }
+                }
+                rc.vmask = vm;
+                rc.uni = PRCG_WIN_UNIFORM_ROWS && dcur.vdc <= 2 && dcur.re - dcur.rb == 64 && __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+            } else {
+                rc.uni = false;
+            }
+        }
+    }
+    const bool cached = RL > 0 && (same_cur || fill);                  // wave-uniform
+
+    // ---- lane i walks row i (and i + 64, ...) ----
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int row = dcur.rb + j * 64 + lane;
@@ -300,7 +410,55 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
         const int o = rs_[j] + pad;
         const int len = active ? re_[j] - rs_[j] : 0;
         V sum; vzero(sum);
-        for (int j0 = 0; j0 < dcur.maxlen; j0 += kU) {
+        if constexpr (RL > 0) {
+            if (cached) {
+                // indices from registers; the value is a select between the table's two entries, or one LDS read
+                const int clen = rc.len[j];
+                if (rc.uni) {
+                    // every lane: a full row, scalar value, window entry lane + scalar offset
+#pragma unroll
+                    for (int u = 0; u < RL; ++u) {
+                        if (u < dcur.maxlen) {                             // wave-uniform
+                            const int cb = (rc.cbase[u >> 2] >> (8 * (u & 3))) & 255;
+                            const double a = ((rc.vmask >> u) & 1u) ? rc.d1 : rc.d0;
+                            const V g = c.sw[cb + lane];
+                            vacc(sum, vmul(a, g));
+                        }
+                    }
+                } else if (dcur.vdc <= 2) {
+#pragma unroll
+                    for (int q4 = 0; q4 < RL; q4 += 4) {
+                        if (q4 < dcur.maxlen) {                            // wave-uniform
+#pragma unroll
+                            for (int u = q4; u < q4 + 4; ++u) {
+                                int ci;
+                                if constexpr (CW == 8) ci = (rc.c[j][u >> 2] >> (8 * (u & 3))) & 255; else ci = (rc.c[j][u >> 1] >> (16 * (u & 1))) & 65535;
+                                const int vi = (rc.v[j][u >> 2] >> (8 * (u & 3))) & 255;
+                                const double a = vi ? rc.d1 : rc.d0;
+                                const V g = c.sw[ci];
+                                if (u < clen) vacc(sum, vmul(a, g));
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < RL; q4 += 4) {
+                        if (q4 < dcur.maxlen) {
+#pragma unroll
+                            for (int u = q4; u < q4 + 4; ++u) {
+                                int ci;
+                                if constexpr (CW == 8) ci = (rc.c[j][u >> 2] >> (8 * (u & 3))) & 255; else ci = (rc.c[j][u >> 1] >> (16 * (u & 1))) & 65535;
+                                const int vi = (rc.v[j][u >> 2] >> (8 * (u & 3))) & 255;
+                                const double a = c.sd[vi];
+                                const V g = c.sw[ci];
+                                if (u < clen) vacc(sum, vmul(a, g));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (int j0 = 0; j0 < (cached ? 0 : dcur.maxlen); j0 += kU) {
             int ci[kU];
             double a[kU];
             V g[kU];
@@ -395,6 +553,7 @@ __device__ __forceinline__ void win_step(const WinDev& A, const WCtx<NV>& c, WRe
         }
     }
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
+    return next_same;
 }
 
 // tiles in flight per wave (measured, profiles/r02_sweeps.md).  With shared stream images the dictionary kernels
@@ -458,27 +617,11 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         // previous launch -- every block of this launch sums them in the same fixed order
         // (thread t: rows t, t+B, ...; butterfly; waves in order), see prcg_kernels.hip
         if (fz.nprev > 0) {
-            __shared__ double redp[WPB][5];
-            __shared__ double dsum[5];
-            double tot[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-            for (int j = threadIdx.x; j < fz.nprev; j += 64 * WPB) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) tot[q] += fz.prev_partials[(size_t)j * kPartialStride + q];
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const double v = wave_sum(tot[q]);
-                if (lane == 0) redp[wv][q] = v;
-            }
-            __syncthreads();
-            if (threadIdx.x < 5) {
-                double v = redp[0][threadIdx.x];
-#pragma unroll
-                for (int w = 1; w < WPB; ++w) v += redp[w][threadIdx.x];
-                dsum[threadIdx.x] = v;
-                if (blockIdx.x == 0) fz.dots_prev_out[threadIdx.x] = v;
-            }
-            __syncthreads();
+            // (the 256-thread tree of k_reduce_final whatever this workgroup's size: the sums do not depend on whether an
+            //  iteration's partials were reduced here or by the reduction launch that ends a prcg_iterate call)
+            double dsum[5];
+            sum_prev_partials<5, WPB>(fz.prev_partials, fz.nprev, 0, dsum);
+            if (blockIdx.x == 0 && threadIdx.x < 5) fz.dots_prev_out[threadIdx.x] = dsum[threadIdx.x];
             cf = predict(dsum, (write_mask >> 2) & 1);
         } else {
             cf = predict(PR1 ? fz.dots_old : ep_r, (write_mask >> 2) & 1);
@@ -514,6 +657,11 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
     WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
     WDesc<PG> d[DEPTH], dn = {};
+    // row cache (one image in flight per wave only: the cache then describes the tile processed just before)
+    constexpr int RL = DEPTH == 1 ? win_row_cache_len(M, CW, VD) : 0;
+    RowCache<M, RL, CW> rc;
+    rc.img = 0;
+    bool same[DEPTH];
     // deferred form: tiles from `safe` on read ghost rows that arrive with the publication -- their loads are
     // postponed (pend) until the wave has seen it
     const int safe = DEF > 0 ? (fz.nt_int < ntiles ? fz.nt_int : ntiles) : ntiles;
@@ -523,6 +671,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     for (int i = 0; i < DEPTH; ++i) {
         d[i] = WDesc<PG>{};
         pend[i] = false;
+        same[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
             if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i]);
@@ -546,8 +695,8 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                     d[i] = dn;
                     pend[i] = tnext < ntiles && !have_next;
                     rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re;
-                    win_step<NV, EPI, M, PG, CW, VD, true>(A, c, R[i], dcur, have_next, d[i], acc, cf,
-                                                           s_stash[wv] + (turn * DEPTH + i) * M * 64);
+                    same[i] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i],
+                                                                         s_stash[wv] + (turn * DEPTH + i) * M * 64);
                     if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
                     t += W;
                     ++n_def;
@@ -578,6 +727,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                 const WRegs<win_nw(NV, EPI), M, PG, CW, VD> r0 = R[0]; R[0] = R[1]; R[1] = r0;
                 const WDesc<PG> d0 = d[0]; d[0] = d[1]; d[1] = d0;
                 const bool p0 = pend[0]; pend[0] = pend[1]; pend[1] = p0;
+                const bool s0 = same[0]; same[0] = same[1]; same[1] = s0;
             }
         }
         static_assert(DEPTH <= 2, "ring rotation after the deferred phase is written for one or two images");
@@ -588,7 +738,8 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         for (int i = 0; i < DEPTH; ++i)
             if (pend[i]) {
                 if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i]);
+                same[i] = same_image<PG>(rc, d[i]);
+                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], same[i]);
                 pend[i] = false;
             }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -638,7 +789,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                 const bool have_next = tnext < ntiles;
                 d[i] = dn;
                 const bool acq = DEF > 0 && have_next && tnext >= safe && !acquired;
-                win_step<NV, EPI, M, PG, CW, VD>(A, c, R[i], dcur, have_next, d[i], acc, cf, nullptr, acq);
+                same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], nullptr, acq);
                 if (acq) acquired = true;
                 // descriptor of the tile after that one: loaded now, looked at one step later
                 if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
@@ -797,6 +948,17 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
 }
 
 }  // namespace
+
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred) {
+    if (deferred) return kWPBDefer;
+    switch (geom) {
+    case 0: return waves_per_block(2, 2, 8, value_dict);
+    case 1: return waves_per_block(2, 4, 8, value_dict);
+    case 2: return waves_per_block(2, 8, 16, value_dict);
+    case 3: return waves_per_block(2, 12, 16, value_dict);
+    default: return 0;
+    }
+}
 
 int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* x, double* y,
                     SpmvEpilogue epi, const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu)

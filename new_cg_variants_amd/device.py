@@ -182,6 +182,17 @@ class DeviceCSR:
                 'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
                 'window': bool(s & 4096), 'fused_comm': bool(s & 8192)}
 
+    def layout(self):
+        """Diagnostic (prcg.h: prcg_debug_layout): what the summation order of the one-launch iteration's inner
+        products depends on -- tile rows in table order, workgroups and waves per workgroup of the last launch."""
+        need = -int(self._lib.prcg_debug_layout(self._h, L.ptr(np.zeros(1, dtype=np.int64)), 0))
+        out = np.zeros(max(need, 8), dtype=np.int64)
+        got = int(self._lib.prcg_debug_layout(self._h, L.ptr(out), out.size))
+        if got < 8:
+            raise RuntimeError('prcg_debug_layout failed')
+        return {'window': bool(out[0]), 'geometry': int(out[1]), 'rows_per_tile': int(out[2]), 'tiles': out[8:got].reshape(-1, 2).copy(),
+                'grid': int(out[4]), 'waves_per_block': int(out[5]), 'interior_tiles': int(out[6])}
+
     def operator_bytes(self):
         """Bytes of the operator as the device streams it (prcg.h: prcg_operator_bytes)."""
         return int(self._lib.prcg_operator_bytes(self._h))

@@ -102,3 +102,26 @@ def split_serial(A, nranks, offsets=None):
         halo = plan_halo(local[r][1], offsets, r, lambda _w: wants_all)
         out.append((local[r][0], local[r][1], halo))
     return offsets, out
+
+
+def loopback_problem(A, k):
+    """One rank's view of a row-block run, on ONE GPU: rewrite A as if it were cut at row n/2 into two
+    row blocks whose halo is exchanged with ... itself.  Columns in [n/2-k, n/2) seen from rows >= n/2
+    and columns in [n/2, n/2+k) seen from rows < n/2 are reached through ghost slots fed by a self
+    exchange.  A_loop @ [x ; x[ghost_ids]] == A @ x with the nonzeros of every row in unchanged order.
+    Returns (A_loop, halo plan, nonzeros that go through a ghost slot).  Used by the tests and by
+    bench.py's multi-rank-schedule leg (boundary tiles + ghost rows with a 1-rank communicator)."""
+    A = A.tocsr()
+    n = A.shape[0]
+    h = n // 2
+    ghost_ids = np.arange(h - k, h + k)
+    slot = -np.ones(n, dtype=np.int64)
+    slot[ghost_ids] = n + np.arange(ghost_ids.size)
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    cols = A.indices.astype(np.int64).copy()
+    via_ghost = ((cols >= h - k) & (cols < h) & (rows >= h)) | ((cols >= h) & (cols < h + k) & (rows < h))
+    cols[via_ghost] = slot[cols[via_ghost]]
+    A_loop = sp.csr_matrix((A.data, cols.astype(np.int32), A.indptr), shape=(n, n + ghost_ids.size))
+    halo = {'peers': np.array([0], dtype=np.int32), 'send_ptr': np.array([0, ghost_ids.size], dtype=np.int64),
+            'send_idx': ghost_ids.astype(np.int32), 'recv_ptr': np.array([0, ghost_ids.size], dtype=np.int64)}
+    return A_loop, halo, int(via_ghost.sum())

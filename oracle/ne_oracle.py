@@ -392,15 +392,16 @@ FAMILIES = {
 
 
 def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
-        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None, square=_pow2):
+        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None, square=_pow2, dot0=None):
     """Free-running solve with the reference's loop shape: recorders fire on the
     initial state (index 0) and after each of the ``max_iter - 1`` iterations
-    (NE/cg_variants/hs_cg.py:33-36,39,64-65).  ``tap(state)`` sees every state."""
+    (NE/cg_variants/hs_cg.py:33-36,39,64-65).  ``tap(state)`` sees every state.  ``dot0``: inner-product
+    routine of the initial state only (the device sums that one with another kernel's tree)."""
     start, advance, has_flavour = FAMILIES[family]
     out = {'name': name or family, 'max_iter': max_iter}
     for q in recorders:
         out[q] = np.zeros(max_iter)
-    st = start(A, b, x0, prec=prec, dot=dot)
+    st = start(A, b, x0, prec=prec, dot=dot0 or dot)
 
     def record():
         for q in recorders:
@@ -427,7 +428,7 @@ def _public(family, flavour, ref_name, preconditioned):
         out = run(family, A, b, x0, max_iter, flavour=flavour, prec=prec,
                   recorders=tuple(callbacks), x_true=kwargs.get('x_true'),
                   dot=kwargs.get('dot', np.dot), tap=kwargs.get('tap'), name=ref_name,
-                  square=kwargs.get('square', _pow2))
+                  square=kwargs.get('square', _pow2), dot0=kwargs.get('dot0'))
         return out
     f.__name__ = ref_name
     return f

@@ -10,6 +10,18 @@ block_reduce_store, k_reduce_final) sum a product array in a fixed order:
 
 Plugging ``device_dot`` into the oracle (``dot=``) makes the oracle's free-running
 trajectory comparable with the device's bit for bit.
+
+``OneLaunchTree`` is the same for the ONE-LAUNCH iteration (prcg_win.hip: k_win_tiles<2,fused>, the schedule
+bench.py times and every solve uses by default): its inner products are summed
+
+  lane l of wave (block b, wave v): rows rb + j*64 + l (j = 0..M-1) of tiles  slot, slot + W, slot + 2W, ...
+                                    with slot = xcd_remap(b) * WPB + v,  W = grid * WPB  (in that order)
+  wave  : xor butterfly             block : waves 0..WPB-1 in order  ->  one partial per workgroup
+  final : the 256-thread tree over the workgroups' partials (thread t: partials t, t+256, ...; butterfly;
+          4 waves in order) -- by every workgroup of the NEXT launch in its prologue (sum_prev_partials) or
+          by k_reduce_final when a prcg_iterate call ends: the same tree either way
+
+built from DeviceCSR.layout() (prcg.h: prcg_debug_layout: tile rows, grid, waves per workgroup).
 """
 import numpy as np
 
@@ -69,3 +81,71 @@ def device_sum(prod):
 
 def device_dot(a, b):
     return device_sum(np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64))
+
+
+def xcd_remap(b, nb):
+    """prcg_device.hpp: xcd_remap -- workgroup b of nb -> position in the XCD-contiguous work order."""
+    xcd, idx = b & 7, b >> 3
+    q, r = nb >> 3, nb & 7
+    base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+    return base + idx
+
+
+def _final_tree(partial):
+    """the 256-thread tree over one partial per workgroup (k_reduce_final / sum_prev_partials)"""
+    grid = partial.shape[0]
+    rounds = (grid + FINAL_THREADS - 1) // FINAL_THREADS
+    pp = np.zeros(rounds * FINAL_THREADS)
+    pp[:grid] = partial
+    pp = pp.reshape(rounds, FINAL_THREADS)
+    t = np.zeros(FINAL_THREADS)
+    for j in range(rounds):
+        t = t + pp[j]
+    wf = _butterfly(t.reshape(FINAL_THREADS // 64, 64))
+    out = wf[0]
+    for w in range(1, FINAL_THREADS // 64):
+        out = out + wf[w]
+    return float(out)
+
+
+class OneLaunchTree:
+    """The summation order of the inner products of the one-launch pipelined iteration on a window operator."""
+
+    def __init__(self, layout):
+        assert layout['window'] and layout['grid'] > 0, layout
+        tiles = np.asarray(layout['tiles'], dtype=np.int64)
+        grid, wpb = int(layout['grid']), int(layout['waves_per_block'])
+        M = int(layout['rows_per_tile']) // 64
+        nt = tiles.shape[0]
+        W = grid * wpb
+        per_wave = (nt + W - 1) // W
+        # idx[b, v, step, lane] = row summed by that lane at that step, -1: none
+        idx = -np.ones((grid, wpb, per_wave * M, 64), dtype=np.int64)
+        lane = np.arange(64)
+        for b in range(grid):
+            for v in range(wpb):
+                slot = xcd_remap(b, grid) * wpb + v
+                for i, t in enumerate(range(slot, nt, W)):
+                    rb, re = tiles[t]
+                    for j in range(M):
+                        rows = rb + j * 64 + lane
+                        idx[b, v, i * M + j] = np.where(rows < re, rows, -1)
+        self.idx = idx
+        self.grid, self.wpb = grid, wpb
+        covered = np.sort(idx[idx >= 0])
+        assert np.array_equal(covered, np.arange(tiles[:, 0].min(), tiles[:, 1].max())), 'every row summed exactly once'
+
+    def sum(self, prod):
+        prod = np.asarray(prod, dtype=np.float64)
+        ext = np.concatenate([prod, [0.0]])            # index -1 -> +0.0 (adding it changes nothing: acc starts at +0.0)
+        acc = np.zeros(self.idx.shape[:2] + (64,))
+        for step in range(self.idx.shape[2]):
+            acc = acc + ext[self.idx[:, :, step, :]]
+        waves = _butterfly(acc)                        # (grid, wpb)
+        partial = waves[:, 0]
+        for v in range(1, self.wpb):
+            partial = partial + waves[:, v]
+        return _final_tree(partial)
+
+    def dot(self, a, b):
+        return self.sum(np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64))

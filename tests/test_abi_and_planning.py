@@ -56,6 +56,19 @@ def test_product_does_not_import_the_oracle():
                 assert 'ne_oracle' not in src and 'mp_oracle' not in src, f
 
 
+def test_window_source_capacity_rule():
+    """What the engine evaluates before every matrix-product launch (prcg_engine.cpp: check_sources): a source vector
+    must hold n + g entries plus 65,536 spare ones, per component -- a deliberately short buffer is refused."""
+    ok = L.lib().prcg_window_source_ok
+    n, g, pad = 1000, 14, 65536
+    assert ok(n, g, 1, (n + g + pad) * 8) == 1
+    assert ok(n, g, 1, (n + g + pad) * 8 - 1) == 0
+    assert ok(n, g, 1, n * 8) == 0                          # the round-2 fault: a source allocated without spare entries
+    assert ok(n, g, 1, 16) == 0                             # an unused vector's placeholder
+    assert ok(n, g, 2, (n + g + pad) * 8) == 0 and ok(n, g, 2, (n + g + pad) * 16) == 1
+    assert ok(-1, 0, 1, 1 << 40) == 0 and ok(n, g, 0, 1 << 40) == 0 and ok(n, g, 1, -5) == 0
+
+
 def check_tiles(indptr, tiles, n0, cap_nnz, cap_rows, row_class=None):
     n = len(indptr) - 1
     covered = np.zeros(n, dtype=np.int32)

@@ -157,27 +157,7 @@ def test_one_launch_schedule_with_a_communicator(workload, prec):
         op.close()
 
 
-def loopback_problem(A, k):
-    """Rewrite A as if it were cut at row n/2 into two row blocks whose halo is exchanged
-    with ... itself: columns in [n/2-k, n/2) seen from rows >= n/2 and columns in
-    [n/2, n/2+k) seen from rows < n/2 are reached through ghost slots fed by a self
-    send/recv.  A_loop @ [x ; x[ghost_ids]] == A @ x with the nonzeros of every row in
-    unchanged order."""
-    import scipy.sparse as sp
-    A = A.tocsr()
-    n = A.shape[0]
-    h = n // 2
-    ghost_ids = np.arange(h - k, h + k)
-    slot = -np.ones(n, dtype=np.int64)
-    slot[ghost_ids] = n + np.arange(ghost_ids.size)
-    rows = np.repeat(np.arange(n), np.diff(A.indptr))
-    cols = A.indices.astype(np.int64).copy()
-    via_ghost = ((cols >= h - k) & (cols < h) & (rows >= h)) | ((cols >= h) & (cols < h + k) & (rows < h))
-    cols[via_ghost] = slot[cols[via_ghost]]
-    A_loop = sp.csr_matrix((A.data, cols.astype(np.int32), A.indptr), shape=(n, n + ghost_ids.size))
-    halo = {'peers': np.array([0], dtype=np.int32), 'send_ptr': np.array([0, ghost_ids.size], dtype=np.int64),
-            'send_idx': ghost_ids.astype(np.int32), 'recv_ptr': np.array([0, ghost_ids.size], dtype=np.int64)}
-    return A_loop, halo, int(via_ghost.sum())
+from new_cg_variants_amd.partition import loopback_problem  # noqa: E402  (one rank's view of a row-block run on one GPU)
 
 
 @pytest.mark.gpu

@@ -406,3 +406,27 @@ def test_window_formation_launches_on_randomised_spd_bands_and_grids(amd):
             for op in ops:
                 op.close()
     print(f'{len(cases)} operators x 7 variants x 2 preconditioners: worst deviation of x after 30 iterations {worst:.1e}')
+
+
+@pytest.mark.gpu
+def test_short_window_source_is_refused_not_faulted(amd):
+    """Round 2's memory fault (a window page of the last tile read past the end of a source vector allocated without
+    spare entries) as an error code: with PRCG_DEBUG_SHORT_SOURCES=1 (tests only) a Hestenes-Stiefel session
+    allocates r with exactly n entries; the product launch that would stage it must return PRCG_EINVAL."""
+    L = amd['L']
+    A = amd['problems'].WORKLOADS['s3_small']['make']()
+    n = A.shape[0]
+    b, x0, _ = amd['problems'].reference_rhs(A, n)
+    op = amd['device'].DeviceCSR(A, knobs={'PRCG_DEBUG_SHORT_SOURCES': '1'})
+    op.begin(L.HS, b, x0, 8)
+    assert op.schedule()['window'] and op.schedule()['fused']
+    with pytest.raises(L.PrcgError) as exc:
+        op.iterate(1)
+    assert exc.value.code == L.EINVAL and 'launch refused' in str(exc.value)
+    op.close()
+    op = amd['device'].DeviceCSR(A)                     # the same session with the regular allocation runs
+    op.begin(L.HS, b, x0, 8)
+    op.iterate(5)
+    op.sync()
+    assert np.isfinite(op.get_scalars(5)[L.S_NU])
+    op.close()

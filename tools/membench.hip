@@ -43,6 +43,47 @@ __global__ __launch_bounds__(256) void k_copy(const double2* __restrict__ a, dou
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += stride) b[i] = a[i];
 }
+// copy with UNROLL 16-byte loads in flight per thread before the first store (the guide's float4 copy: 6.29 TB/s);
+// NT: nontemporal loads and stores
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_copy_u(const double2* __restrict__ a, double2* __restrict__ b, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* A = reinterpret_cast<const d2*>(a);
+    d2* B = reinterpret_cast<d2*>(b);
+    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
+        d2 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(A + i + u * stride) : A[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { if (NT) __builtin_nontemporal_store(v[u], B + i + u * stride); else B[i + u * stride] = v[u]; }
+    }
+    for (; i < n2; i += stride) B[i] = A[i];
+}
+// The byte mix of the one-launch iteration with the dictionary (S3): per row (x,p) read and written in place,
+// (r,s) read from one array and written to another: 2 x 16 B in, 2 x 16 B out, nothing else.  n rows.
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_pairs_u(double2* __restrict__ xp, const double2* __restrict__ rs, double2* __restrict__ rsn, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* X = reinterpret_cast<d2*>(xp);
+    const d2* R = reinterpret_cast<const d2*>(rs);
+    d2* Rn = reinterpret_cast<d2*>(rsn);
+    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
+        d2 x[UNROLL], r[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { x[u] = X[i + u * stride]; r[u] = R[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            d2 xo = x[u], ro = r[u];
+            d2 xn = {xo.x + 0.5 * xo.y, ro.x + 0.25 * xo.y}, rn = {ro.x - 0.5 * ro.y, xo.y + 0.25 * ro.y};
+            if (NT) { __builtin_nontemporal_store(xn, X + i + u * stride); __builtin_nontemporal_store(rn, Rn + i + u * stride); }
+            else { X[i + u * stride] = xn; Rn[i + u * stride] = rn; }
+        }
+    }
+}
 // read/modify/write like the CG update: 3 pair arrays read, 2 written
 __global__ __launch_bounds__(256) void k_update_like(double2* __restrict__ a, double2* __restrict__ b, const double2* __restrict__ c, size_t n2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,6 +159,22 @@ int main() {
     }
     time([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, a, b, n2); }, "copy grid 2048 (r+w bytes)", 2 * G);
     time([&] { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, a, b, n2); }, "copy grid 8192 (r+w bytes)", 2 * G);
+    for (int g : {256 * 2, 256 * 4, 256 * 8}) {
+        char nm[64];
+        snprintf(nm, 64, "copy u4 grid %d (r+w bytes)", g); time([&] { hipLaunchKernelGGL((k_copy_u<4, false>), dim3(g), dim3(256), 0, 0, a, b, n2); }, nm, 2 * G);
+        snprintf(nm, 64, "copy u8 grid %d (r+w bytes)", g); time([&] { hipLaunchKernelGGL((k_copy_u<8, false>), dim3(g), dim3(256), 0, 0, a, b, n2); }, nm, 2 * G);
+        snprintf(nm, 64, "copy u4 nt grid %d (r+w bytes)", g); time([&] { hipLaunchKernelGGL((k_copy_u<4, true>), dim3(g), dim3(256), 0, 0, a, b, n2); }, nm, 2 * G);
+        snprintf(nm, 64, "copy u8 nt grid %d (r+w bytes)", g); time([&] { hipLaunchKernelGGL((k_copy_u<8, true>), dim3(g), dim3(256), 0, 0, a, b, n2); }, nm, 2 * G);
+    }
+    {   // the dictionary kernel's mix at S3's size: 1e7 rows, 64 B per row = 0.64 GB per launch
+        const size_t rows = 10000000;
+        for (int g : {256 * 2, 256 * 4, 256 * 8}) {
+            char nm[64];
+            snprintf(nm, 64, "pairs 2r+2w u2 grid %d (S3 rows)", g); time([&] { hipLaunchKernelGGL((k_pairs_u<2, false>), dim3(g), dim3(256), 0, 0, a, b, c, rows); }, nm, 64.0 * rows / 1e9);
+            snprintf(nm, 64, "pairs 2r+2w u4 grid %d (S3 rows)", g); time([&] { hipLaunchKernelGGL((k_pairs_u<4, false>), dim3(g), dim3(256), 0, 0, a, b, c, rows); }, nm, 64.0 * rows / 1e9);
+            snprintf(nm, 64, "pairs 2r+2w u4 nt grid %d (S3 rows)", g); time([&] { hipLaunchKernelGGL((k_pairs_u<4, true>), dim3(g), dim3(256), 0, 0, a, b, c, rows); }, nm, 64.0 * rows / 1e9);
+        }
+    }
     time([&] { hipLaunchKernelGGL(k_update_like, dim3(2048), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 2048", 5 * G);
     time([&] { hipLaunchKernelGGL(k_update_like, dim3(8192), dim3(256), 0, 0, a, b, c, n2); }, "update-like 3r+2w grid 8192", 5 * G);
     {   // S3-shaped: 1e7 rows

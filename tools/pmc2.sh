@@ -14,7 +14,7 @@ for group in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_U
              "TCC_REQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum" \
              "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $group --output-format csv -d $out/pass$i -- python3 $root/bench.py "$@" --no-cpu-baseline --no-plain-values --no-multi-rank-leg > $out/pass$i.json 2> $out/pass$i.err || echo "pass $i ($group) failed"
+  timeout -k 10 400 rocprofv3 --pmc $group --output-format csv -d $out/pass$i -- python3 $root/bench.py "$@" --no-cpu-baseline --no-plain-values --no-multi-rank-leg --no-workloads > $out/pass$i.json 2> $out/pass$i.err || echo "pass $i ($group) failed"
 done
 python3 $root/tools/pmc_summary.py $out > $root/gpurun_out/pmc_$label.json
 rm -rf $out
