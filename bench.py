@@ -169,10 +169,14 @@ def main():
            'cg_cg': L.CG_CG, 'gv_cg': L.GV}
 
     def one_rank_comm_device(A, halo=None, knobs=None):
+        """a 1-rank communicator session: the multi-rank schedule on this one GPU (its only peer is itself)"""
         uid = np.zeros((1, 128), dtype=np.uint8)
         path = L.default_rccl_path()
         L.check(None, L.lib().prcg_comm_unique_id(path.encode(), L.ptr(uid[0])))
-        return DeviceCSR(A, device=local_rank, comm_init=(0, 1, uid.tobytes(), path), halo=halo, knobs=knobs)
+        d = DeviceCSR(A, device=local_rank, comm_init=(0, 1, uid.tobytes(), path), halo=halo, knobs=knobs)
+        if (knobs or {}).get('PRCG_PEER', os.environ.get('PRCG_PEER', '1')) != '0':
+            partition.connect_peer_exchange(d, 0, lambda obj: [obj])
+        return d
 
     def timed_run(dev, variant, b, x0, inv_diag=None):
         """(elapsed, host enqueue time, kernel timings, residual finite, error).  A library error (a one-launch
@@ -287,14 +291,14 @@ def main():
     elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
     fallback = None
     if run_err is not None:
-        # the one-launch schedule of a communicator session could not be kept fed on this node (its waits are
-        # bounded and reported): every rank rebuilds its operator with the two-kernel schedule and the run is repeated
+        # the one-launch schedule of a multi-rank session could not be kept fed on this node (its waits are
+        # bounded and reported): every rank rebuilds its operator with the RCCL two-kernel schedule and the run is repeated
         fallback = run_err
         dev.close()
         if world == 1 and args.force_comm:
-            dev = one_rank_comm_device(A_rows.tocsr(), knobs={'PRCG_FUSED_COMM': '0'})
+            dev = one_rank_comm_device(A_rows.tocsr(), knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
         else:
-            op = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0'})
+            op = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
             dev = op.dev
         elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
         if run_err is not None:
@@ -318,8 +322,8 @@ def main():
     # rows, the whole exchange chain) beside the plain one-launch schedule on the same slice.
     multi = None
     if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant.startswith('pipe_'):
-        def comm_leg(A, halo, bb, xx0, dd):
-            d3 = one_rank_comm_device(A, halo)
+        def comm_leg(A, halo, bb, xx0, dd, knobs=None):
+            d3 = one_rank_comm_device(A, halo, knobs)
             e3, q3, tim3, fin3, err3 = timed_run(d3, variant, bb, xx0, dd)
             if err3:
                 d3.close()
@@ -348,11 +352,16 @@ def main():
                 ep, qp, timp, finp, _ = timed_run(dp, variant, b8, x8, d8)
                 dp.close()
                 leg = comm_leg(A8_loop, halo8, b8, x8, d8)
+                try:       # the RCCL schedule of the same slice, for comparison (update kernel + SpMM, all-gather on the communication stream)
+                    rccl_leg = comm_leg(A8_loop, halo8, b8, x8, d8, {'PRCG_PEER': '0'})
+                except Exception as exc:
+                    rccl_leg = {'error': str(exc)[:200]}
                 multi['s3_8th'] = {'what': 'one rank\'s share of S3 on 8 GPUs (n = 1.25e6) on this GPU: the plain one-launch schedule, and the '
-                                           'communicator schedule with a loopback halo (7 ghost rows per side, boundary tiles, the whole '
-                                           'exchange chain); a real 8-rank exchange adds xGMI latency to the second',
+                                           'multi-rank schedule with a loopback halo (7 ghost rows per side, boundary tiles, the whole '
+                                           'exchange: rows and partial sums stored into the exchange buffer by the launch itself, '
+                                           'next launch waits in-kernel); a real 8-rank exchange adds xGMI latency to the second',
                                    'plain_us_per_iteration': ep / K * 1e6, 'plain_host_enqueue_us_per_step': qp / K * 1e6,
-                                   'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg,
+                                   'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg, 'rccl_schedule': rccl_leg,
                                    'single_gpu_us_per_iteration': elapsed / K * 1e6,
                                    'speedup_ceiling_at_8_ranks': (elapsed / K * 1e6) / leg['us_per_iteration'] if leg['us_per_iteration'] > 0 else None}
         except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it

@@ -119,6 +119,24 @@ int prcg_set_option(prcg_t* h, const char* key, const char* value);
 int prcg_comm_unique_id(const char* rccl_path, void* id128);
 int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* ids, int n_ids);
 
+/* ---- direct peer exchange over xGMI ----------------------------------------------------
+ * The reduction and the halo of the pipelined loop WITHOUT a collective (replaces, inside the loop, the
+ * `comm.Allreduce` of scaling_experiments_mpi4py/cg_variants/pipe_pr_cg.py:67 and the neighbour exchange its dense
+ * column blocks make implicit): every rank owns one exchange buffer in fine-grained device memory, mapped into every
+ * other rank's process (hipIpc); the iteration launch stores the rows its neighbours need and its five partial inner
+ * products straight into their buffers, and waits inside the kernel for theirs.  One host call
+ * per iteration, no communication stream.  Call after prcg_set_csr / prcg_set_halo, on EVERY rank or on none:
+ *   prcg_peer_setup    allocates this rank's buffer for `max_ghost_any_rank` ghost rows (the largest ghost count of any
+ *                      rank: every buffer has the same layout), returns its 64-byte hipIpcMemHandle and, for ranks that
+ *                      share the process (tests: ranks in threads), its device address;
+ *   prcg_peer_connect  ipc_handles: nranks x 64 bytes, rank order (own entry ignored), or same_process_ptrs[q] non-null
+ *                      for a rank of this process; send_dst_off[q]: where in peer q's ghost area (prcg_set_halo's
+ *                      receive order of THAT rank) this rank's rows for it begin.
+ * Window operators only (others keep the RCCL schedule); PRCG_PEER=0 turns it off.  Waits are bounded: a rank that
+ * waits ~10 s for another sets an error that prcg_sync and the next prcg_iterate report. */
+int prcg_peer_setup(prcg_t* h, int64_t max_ghost_any_rank, void* ipc_handle64, void** local_ptr);
+int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_process_ptrs, const int64_t* send_dst_off);
+
 /* ---- operator -------------------------------------------------------------------
  * The rank's row block in CSR (what `A` is in figure_gen.py:350 / scaling_tests.py:51),
  * column indices already LOCAL: [0,n_rows) = owned entries, [n_rows, n_rows+n_ghost)
@@ -183,6 +201,7 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_COL16 128    /* ... 2-byte */
 #define PRCG_SCHED_FUSED_COMM 8192 /* one launch per iteration WITH a communicator: the interior launch waits in-kernel
                                       for the reduced inner products of the previous iteration */
+#define PRCG_SCHED_PEER 16384  /* ... through the direct peer exchange (prcg_peer_setup / prcg_peer_connect): no collective in the loop */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
 /* A preconditioner that is not a diagonal scaling: `fn(ctx, n, v, out)` must write M^-1 v to out (host buffers,

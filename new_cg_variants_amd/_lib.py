@@ -54,6 +54,8 @@ _SIGNATURES = {
     'prcg_comm_init': (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, _P, C.c_int]),
     'prcg_set_csr': (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     'prcg_set_halo': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    'prcg_peer_setup': (C.c_int, [_P, C.c_int64, _P, C.POINTER(_P)]),
+    'prcg_peer_connect': (C.c_int, [_P, _P, _P, _P]),
     'prcg_spmv': (C.c_int, [_P, _P, _P, C.c_int, _dp]),
     'prcg_spmv_ext': (C.c_int, [_P, _P, _P]),
     'prcg_spmm2': (C.c_int, [_P, _P, _P, C.c_int, _dp]),

@@ -201,9 +201,10 @@ struct FusedRowIn { double2 xp, rs; double d, w, wt; };
 //   unpreconditioned (pipe_pr_cg.py:61-74): in = (r,s);  w_prev = A r (recomputed) or the stored recurrence
 //   Jacobi           (pipe_pr_cg.py:169-186): in = (r~,s~); w~ = d w and u~ = d u as preconditioner(w), preconditioner(u)
 // Same expressions, same order, no FMA as k_pipe_update (the two-kernel schedule) -- vectors agree bit for bit.
+// Returns the row's new SpMM input pair (what went to IN_NEW): the peer exchange sends it on to the neighbours.
 template <bool PREC, bool RECOMP>
-__device__ __forceinline__ void fused_row_update(int row, const double2& sum, const FusedRowIn& q, const double2& in_old,
-                                                 const FusedRowPtrs& f, const Coefs& cf, double (&acc)[5])
+__device__ __forceinline__ double2 fused_row_update(int row, const double2& sum, const FusedRowIn& q, const double2& in_old,
+                                                    const FusedRowPtrs& f, const Coefs& cf, double (&acc)[5])
 {
     const double us = sum.y;                                   // u = A s  (A s~)
     const double wprev = RECOMP ? sum.x : q.w;                 // w = A r  (A r~), or the recurrence
@@ -217,6 +218,7 @@ __device__ __forceinline__ void fused_row_update(int row, const double2& sum, co
         f.IN_NEW[row] = make_double2(rn, sn);
         if constexpr (!RECOMP) f.W[row] = wn;
         acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
+        return make_double2(rn, sn);
     } else {
         const double ut = q.d * us;                            // u~ = M^-1 u
         const double wtprev = RECOMP ? q.d * sum.x : q.wt;     // w~ = M^-1 w, or the recurrence
@@ -232,6 +234,61 @@ __device__ __forceinline__ void fused_row_update(int row, const double2& sum, co
         f.IN_NEW[row] = make_double2(rtn, stn);
         if constexpr (!RECOMP) { f.W[row] = wn; f.WT[row] = wtn; }
         acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn; acc[3] += rtn * rn; acc[4] += rn * rn;
+        return make_double2(rtn, stn);
+    }
+}
+
+// ---- direct peer exchange: device side (PeerDev, prcg_kernels.h) ----
+__device__ __forceinline__ void peer_store(double* dst, double v) {           // leaves the chip: system scope, write-through
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long peer_counter(const PeerDev* px, int k) { return px->epoch | (unsigned long long)(unsigned)(k + 1); }
+// One wave: lane q < R waits (bounded) for rank q's slot of iteration k in THIS rank's buffer, then the five sums are
+// added in rank order (the same bits on every rank).  Returns lane-uniform sums in out[0..5); false on a timeout.
+__device__ __forceinline__ bool peer_collect(const PeerDev* px, int k, unsigned max_spins, double (&out)[5]) {
+    const int lane = threadIdx.x & 63;
+    const int R = px->nranks;
+    const double* slot = px->mine + peer_slot_off(R, k & 1, lane < R ? lane : 0);
+    const unsigned long long want = peer_counter(px, k);
+    const unsigned long long* cnt = reinterpret_cast<const unsigned long long*>(slot + 7);
+    bool ok = true;
+    if (lane < R) {
+        unsigned spins = 0;
+        while ((long long)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > max_spins) { ok = false; break; }
+        }
+    }
+    // the sums were stored (and had left their chip) before the counter was: order the loads behind the counter load
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = lane < R ? __hip_atomic_load(slot + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double t = __shfl(v[q], 0, 64);
+        for (int r = 1; r < R; ++r) t += __shfl(v[q], r, 64);
+        out[q] = t;
+    }
+    return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+// One wave: this rank's slot of iteration k (lane q < 5 holds sum q in v) into EVERY rank's buffer, counter last
+__device__ __forceinline__ void peer_send_slot(const PeerDev* px, int k, double v) {
+    const int lane = threadIdx.x & 63;
+    const int R = px->nranks;
+    double vq[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) vq[q] = __shfl(v, q, 64);
+    if (lane < R) {
+        double* slot = px->peer[lane] + peer_slot_off(R, k & 1, px->rank);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) peer_store(slot + q, vq[q]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the sums have arrived before the counter leaves
+    if (lane < R) {
+        double* slot = px->peer[lane] + peer_slot_off(R, k & 1, px->rank);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 7), peer_counter(px, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -14,6 +14,7 @@
 // enqueues; it never synchronises inside prcg_iterate.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -235,6 +236,24 @@ struct prcg_handle {
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
     bool multi() const { return comm != nullptr; }
+
+    // ---- direct peer exchange over xGMI (PeerDev, prcg_kernels.h): the multi-rank one-launch schedule without a collective ----
+    int want_fused_comm_rccl = 0;        // PRCG_FUSED_COMM=1: one launch per iteration with the RCCL all-gather chain on the communication
+                                         // stream (in-kernel wait for kernels of another stream: validated with one rank only -- opt-in)
+    bool want_peer = true;               // PRCG_PEER=0: never use the peer exchange even when connected
+    void* xbuf = nullptr;                // this rank's exchange buffer
+    size_t xbuf_bytes = 0;
+    bool xbuf_fine = false;              // allocated fine-grained (what other GPUs' stores need); else plain device memory (one GPU)
+    int ghost_cap = 0;                   // ghost rows per parity in EVERY rank's buffer (largest ghost count of any rank)
+    std::vector<void*> peer_opened;      // other ranks' buffers opened with hipIpcOpenMemHandle
+    PeerDev peer_host{};
+    DevBuf peer_dev, peer_ents, peer_tile_send, peer_ticket;
+    bool peer_ok = false;                // connected: every rank's buffer is mapped, send entries planned
+    bool peer = false;                   // this session uses it
+    uint64_t peer_epoch = 0;
+    unsigned* err_host = nullptr;        // pinned host word a timed-out wave also writes: prcg_iterate sees it without a sync
+    std::vector<int32_t> send_idx_host;  // prcg_set_halo's send lists (host copy: the peer plan is built from them)
+    std::vector<int32_t> wt_rb, wt_re;   // rows of the window tiles in table order
 
     bool debug_short_sources = false;    // PRCG_DEBUG_SHORT_SOURCES=1 (TESTS ONLY): Hestenes-Stiefel sessions allocate r without
                                          // the spare entries a window source needs -- the launch must be refused, not fault
@@ -724,14 +743,24 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     // ONE launch over all tiles: the boundary tiles come last in the table and are touched only after the wave has
     // seen the publication (which the ghost rows precede).  The launch signals the communication stream with its own
     // completion (no marker packet on the compute stream: the next iteration's launch follows directly).
-    const bool ext_signal = h->ext_signal;
+    const bool ext_signal = h->ext_signal && !h->peer;
     f.done = ext_signal ? h->e_kdone : nullptr;
+    if (h->peer) {
+        // direct peer exchange: this launch is the whole iteration -- its tiles send the neighbours' rows, its last workgroup
+        // this rank's partial sums, and its workgroup 0 turns the ranks' slots of iteration k-1 into the publication
+        f.prev.px = static_cast<const PeerDev*>(h->peer_dev.p);
+        f.prev.dots_prev_out = dots_at(h, k - 1);
+    }
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int g1 = eng_fused(h, h->sc, f, 0);
     LAUNCHCHK(h, g1);
     h->last_grid = g1;
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    if (h->peer) {
+        h->rs_cur = in_new;
+        return PRCG_OK;
+    }
     const int g2 = 0;
     if (ext_signal) {
         HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_kdone, 0));
@@ -1086,7 +1115,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_TILE_ORDER") h->kn.chunked = (val[0] == 'c') ? 1 : 0;
     else if (k == "PRCG_TILE_STEPS") h->steps_override = (v == 1 || v == 2 || v == 4) ? (int)v : 0;
     else if (k == "PRCG_WIN") h->want_win = v != 0;
-    else if (k == "PRCG_FUSED_COMM") h->want_fused_comm = v != 0;
+    else if (k == "PRCG_FUSED_COMM") { h->want_fused_comm = v != 0; h->want_fused_comm_rccl = v != 0; }
+    else if (k == "PRCG_PEER") h->want_peer = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
@@ -1099,7 +1129,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1223,10 +1253,12 @@ int prcg_create(prcg_t** out, int device_id) {
         hipEventCreateWithFlags(&h->e_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->e_red, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&h->e_kdone) != hipSuccess || hipEventCreate(&h->e_rdone) != hipSuccess) {
+        hipEventCreate(&h->e_kdone) != hipSuccess || hipEventCreate(&h->e_rdone) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocDefault) != hipSuccess) {
         prcg_destroy(h);
         return fail(nullptr, PRCG_EHIP, "prcg_create: stream/event creation failed");
     }
+    *h->err_host = 0u;
     *out = h;
     return PRCG_OK;
 }
@@ -1235,6 +1267,9 @@ void prcg_destroy(prcg_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     (void)hipDeviceSynchronize();
+    for (void* q : h->peer_opened) (void)hipIpcCloseMemHandle(q);
+    if (h->xbuf) (void)hipFree(h->xbuf);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     if (h->comm_halo && h->rccl) (void)h->rccl->CommDestroy(h->comm_halo);
     if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
     destroy_events(h->ev_spmv);
@@ -1491,8 +1526,11 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             HIPCHK(h, hipMemcpy(h->vdict.p, vdict.data(), vdict.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->vdesc.p, vdesc.data(), vdesc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    h->peer_ok = false;
+    h->wt_rb.clear(); h->wt_re.clear();
     if (h->win) {
         h->nwt_int = (int)wp.t0.size(); h->nwt_bnd = (int)wp.t1.size();
+        for (const auto& t : wall) { h->wt_rb.push_back(t.rb); h->wt_re.push_back(t.re); }
         // the tiles' stream images: byte-identical ones are stored once (prcg_plan.h: share_window_streams)
         std::vector<uint8_t> vstore;
         std::vector<uint16_t> rstore;
@@ -1572,8 +1610,123 @@ int prcg_set_halo(prcg_t* h, int n_peers, const int32_t* peer_rank, const int64_
     HIPCHK(h, h->send_buf.alloc((size_t)(nsend + 1) * 2 * sizeof(double)));
     if (nsend > 0)
         HIPCHK(h, hipMemcpy(h->send_idx.p, send_idx, (size_t)nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->send_idx_host.assign(send_idx, send_idx + nsend);
+    h->peer_ok = false;
     h->have_halo = true;
     h->gather_planned = false;
+    return PRCG_OK;
+}
+
+int prcg_peer_setup(prcg_t* h, int64_t max_ghost_any_rank, void* ipc_handle64, void** local_ptr) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->have_csr, "prcg_peer_setup: call prcg_set_csr (and prcg_set_halo) first");
+    CHECK(h, h->nranks >= 1 && h->nranks <= kMaxPeerRanks, "prcg_peer_setup: 1..%d ranks", kMaxPeerRanks);
+    CHECK(h, max_ghost_any_rank >= h->g && max_ghost_any_rank < (int64_t)1 << 28, "prcg_peer_setup: ghost capacity %lld < this rank's %lld ghosts",
+          (long long)max_ghost_any_rank, (long long)h->g);
+    HIPCHK(h, hipSetDevice(h->dev));
+    h->peer_ok = false;
+    const size_t bytes = peer_buffer_doubles(h->nranks, (int)max_ghost_any_rank) * sizeof(double) + 4096;
+    if (!h->xbuf || h->xbuf_bytes < bytes || h->ghost_cap != (int)max_ghost_any_rank) {
+        CHECK(h, h->peer_opened.empty() && !h->xbuf, "prcg_peer_setup: the exchange buffer of a connected handle cannot change size");
+        // fine-grained device memory: stores of OTHER GPUs become visible to this one's loads without a kernel boundary
+        h->xbuf_fine = hipExtMallocWithFlags(&h->xbuf, bytes, hipDeviceMallocFinegrained) == hipSuccess;
+        if (!h->xbuf_fine) {
+            (void)hipGetLastError();
+            HIPCHK(h, hipMalloc(&h->xbuf, bytes));
+        }
+        h->xbuf_bytes = bytes;
+        h->ghost_cap = (int)max_ghost_any_rank;
+        HIPCHK(h, hipMemset(h->xbuf, 0, bytes));
+        HIPCHK(h, hipDeviceSynchronize());
+    }
+    if (ipc_handle64) {
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands IPC handles around as 64 bytes");
+        hipIpcMemHandle_t hd;
+        memset(&hd, 0, sizeof hd);
+        if (hipIpcGetMemHandle(&hd, h->xbuf) != hipSuccess) { (void)hipGetLastError(); memset(&hd, 0, sizeof hd); }   // same-process peers still work
+        memcpy(ipc_handle64, &hd, sizeof hd);
+    }
+    if (local_ptr) *local_ptr = h->xbuf;
+    return PRCG_OK;
+}
+
+int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_process_ptrs, const int64_t* send_dst_off) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->xbuf != nullptr, "prcg_peer_connect: call prcg_peer_setup first");
+    CHECK(h, h->g == 0 || h->have_halo, "prcg_peer_connect: ghost columns but no halo plan");
+    const int np = h->have_halo ? h->n_peers : 0;
+    CHECK(h, np == 0 || send_dst_off != nullptr, "prcg_peer_connect: null destination offsets");
+    HIPCHK(h, hipSetDevice(h->dev));
+    h->peer_ok = false;
+    const int R = h->nranks;
+    PeerDev& P = h->peer_host;
+    if (h->peer_opened.empty()) {
+        for (int q = 0; q < kMaxPeerRanks; ++q) P.peer[q] = nullptr;
+        for (int q = 0; q < R; ++q) {
+            if (q == h->rank) { P.peer[q] = static_cast<double*>(h->xbuf); continue; }
+            if (same_process_ptrs && same_process_ptrs[q]) { P.peer[q] = static_cast<double*>(same_process_ptrs[q]); continue; }
+            CHECK(h, ipc_handles != nullptr, "prcg_peer_connect: no handle for rank %d", q);
+            hipIpcMemHandle_t hd;
+            memcpy(&hd, static_cast<const char*>(ipc_handles) + (size_t)q * sizeof hd, sizeof hd);
+            void* mapped = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&mapped, hd, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess)
+                return fail(h, PRCG_EHIP, "hipIpcOpenMemHandle for rank %d's exchange buffer: %s", q, hipGetErrorString(e));
+            h->peer_opened.push_back(mapped);
+            P.peer[q] = static_cast<double*>(mapped);
+        }
+    }
+    P.mine = static_cast<double*>(h->xbuf);
+    P.rank = h->rank; P.nranks = R; P.n_own = (int)h->n; P.ghost_cap = h->ghost_cap; P.epoch = 0;
+    // send entries {row, destination rank, index in its ghost area}, grouped by the tile that owns the row
+    struct Ent { int32_t row, peer, dst, tile; };
+    std::vector<Ent> ents;
+    if (h->win && np > 0) {
+        const size_t nt = h->wt_rb.size();
+        std::vector<int32_t> order(nt);
+        for (size_t i = 0; i < nt; ++i) order[i] = (int32_t)i;
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return h->wt_rb[a] < h->wt_rb[b]; });
+        for (int q = 0; q < np; ++q) {
+            const int64_t cnt = h->send_ptr[q + 1] - h->send_ptr[q];
+            CHECK(h, send_dst_off[q] >= 0 && send_dst_off[q] + cnt <= h->ghost_cap,
+                  "prcg_peer_connect: rows for rank %d would land outside its ghost area", h->peer_rank[q]);
+            for (int64_t j = 0; j < cnt; ++j) {
+                const int32_t row = h->send_idx_host[(size_t)(h->send_ptr[q] + j)];
+                // the tile whose rows hold `row`: last tile (by first row) that starts at or before it
+                size_t lo = 0, hi = nt;
+                while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (h->wt_rb[order[mid]] <= row) lo = mid; else hi = mid; }
+                const int32_t t = order[lo];
+                CHECK(h, row >= h->wt_rb[t] && row < h->wt_re[t], "prcg_peer_connect: row %d lies in no tile", row);
+                ents.push_back(Ent{row, h->peer_rank[q], (int32_t)(send_dst_off[q] + j), t});
+            }
+        }
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.tile != b.tile ? a.tile < b.tile : a.row < b.row; });
+    }
+    const size_t nt = h->wt_rb.size();
+    std::vector<int32_t> tsend(2 * (nt + 1), 0), flat(4 * (ents.size() + 1), 0);
+    {
+        size_t e = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            tsend[2 * t] = (int32_t)e;
+            while (e < ents.size() && ents[e].tile == (int32_t)t) ++e;
+            tsend[2 * t + 1] = (int32_t)e;
+        }
+        for (size_t i = 0; i < ents.size(); ++i) { flat[4 * i] = ents[i].row; flat[4 * i + 1] = ents[i].peer; flat[4 * i + 2] = ents[i].dst; }
+    }
+    HIPCHK(h, h->peer_tile_send.alloc(tsend.size() * sizeof(int32_t)));
+    HIPCHK(h, hipMemcpy(h->peer_tile_send.p, tsend.data(), tsend.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, h->peer_ents.alloc(flat.size() * sizeof(int32_t)));
+    HIPCHK(h, hipMemcpy(h->peer_ents.p, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, h->peer_ticket.alloc(64));
+    HIPCHK(h, h->peer_dev.alloc(sizeof(PeerDev)));
+    P.tile_send = static_cast<const int2*>(h->peer_tile_send.p);
+    P.send_ent = static_cast<const int4*>(h->peer_ents.p);
+    P.ticket = static_cast<unsigned*>(h->peer_ticket.p);
+    P.n_send = (int)ents.size();
+    HIPCHK(h, hipMemcpy(h->peer_dev.p, &P, sizeof P, hipMemcpyHostToDevice));
+    // (a non-window operator keeps the two-kernel schedule: the exchange is the iteration launch's own, and only the
+    //  window kernels have it)
+    h->peer_ok = h->win;
     return PRCG_OK;
 }
 
@@ -1691,12 +1844,17 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         // with a communicator: the same kernel in its deferred form (window operators only)
         h->fused_comm = false;
         h->red_pending = false;
-        if ((rc = plan_gather(h))) return rc;
+        // direct peer exchange (every rank connected, window operator): the one-launch schedule without a collective.
+        // Whether it is connected is the same on every rank (the host side connects all ranks or none).
+        h->peer = h->peer_ok && h->want_peer && h->want_fused && h->multi() && h->win && !h->fused_final && !h->cb_session;
+        if (!h->peer && (rc = plan_gather(h))) return rc;
         // with a communicator: the same kernel in its deferred form -- window operators whose halo rides on the
         // one all-gather per iteration (bands; the merged exchange).  Larger halos (send/recv + all-reduce chain)
         // keep the two-kernel schedule: RCCL's point-to-point path was seen to stall for ~1 s on its first use
         // from the communication stream while a launch waited for it (profiles/r02_sweeps.md).
-        h->fused_comm = h->want_fused && h->want_fused_comm && h->multi() && h->win && !h->fused_final && h->gather;
+        // (the one-launch schedule over the RCCL all-gather chain is opt-in, PRCG_FUSED_COMM=1: its launches wait inside the
+        //  kernel for kernels of ANOTHER stream to become resident, which has only ever been validated with one rank)
+        h->fused_comm = h->peer || (h->want_fused && h->want_fused_comm_rccl && h->multi() && h->win && !h->fused_final && h->gather);
         if (h->fused_comm) h->fused = true;        // state layout, derived vectors: as the one-launch schedule
         HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
@@ -1764,7 +1922,18 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             HIPCHK(h, hipStreamSynchronize(h->sm));
             if ((rc = exchange(h, h->rs_cur, 2, sc))) return rc;
         }
-        if (h->fused_comm) {
+        if (h->peer) {
+            // The initial state into the exchange buffers: this rank's boundary rows into the neighbours' ghost areas and its
+            // slot of "iteration 0" (rank 0 carries the reduced inner products).  Ordered behind the all-reduce above on this
+            // stream, i.e. behind everything the neighbours still had in flight from an earlier session on theirs.
+            h->peer_host.epoch = (unsigned long long)(++h->peer_epoch) << 32;
+            h->peer_host.n_own = (int)h->n;
+            HIPCHK(h, hipMemcpyAsync(h->peer_dev.p, &h->peer_host, sizeof(PeerDev), hipMemcpyHostToDevice, sc));
+            HIPCHK(h, hipStreamSynchronize(sc));                       // (peer_host must not change under the copy)
+            *h->err_host = 0u;
+            launch_peer_push(sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, 0), 0);
+            launch_peer_collect(sc, static_cast<const PeerDev*>(h->peer_dev.p), 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+        } else if (h->fused_comm) {
             // LOCAL part.  Can a kernel of the communication stream run while a kernel of the compute stream waits for
             // it?  (HIP may have mapped both streams to one hardware queue -- then the deferred form would only ever
             // time out.)  Probe once per session: a one-wave kernel on sc waits ~2 ms at most for a record that a
@@ -1779,7 +1948,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             HIPCHK(h, hipMemset(h->pub_err.p, 0, sizeof perr));
             if (perr) { h->fused_comm = false; h->fused = false; }       // streams are serialised here: two-kernel schedule
         }
-        if (h->fused_comm) launch_publish(sc, dots_at(h, 0), h->pub.d(), 0u);   // iteration 1 waits for "0": the initial inner products
+        if (h->fused_comm && !h->peer) launch_publish(sc, dots_at(h, 0), h->pub.d(), 0u);   // iteration 1 waits for "0": the initial inner products
     } else if (is_cg_family(variant)) {
         // x, r, r~, w, w~ (all with ghost room: whichever feeds the SpMV), p, s, s~, u, t
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
@@ -1899,6 +2068,9 @@ int prcg_iterate(prcg_t* h, int iters) {
     CHECK(h, h->k + iters <= h->max_iter, "prcg_iterate: %d more iterations exceed max_iter=%d (k=%d)", iters,
           h->max_iter, h->k);
     HIPCHK(h, hipSetDevice(h->dev));
+    if (h->fused_comm && *h->err_host != 0u)
+        return fail(h, PRCG_ERCCL, "a one-launch iteration waited more than its bound for the other ranks (a peer stalled or died); "
+                                   "the session's results are invalid -- PRCG_PEER=0 / PRCG_FUSED_COMM=0 select the two-kernel schedule");
     if (h->small && iters > 0) {
         // all `iters` iterations inside one launch of one workgroup
         SmallArgs sa{};
@@ -1933,6 +2105,9 @@ int prcg_iterate(prcg_t* h, int iters) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     }
+    if (h->peer && iters > 0)       // the inner products of the last iteration: every rank's slot, added in rank order
+        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->k, dots_at(h, h->k), h->pub.d(),
+                            static_cast<unsigned*>(h->pub_err.p));
     return PRCG_OK;
 }
 
@@ -1945,6 +2120,7 @@ int prcg_sync(prcg_t* h) {
     if (h->in_session && h->fused_comm && h->pub_err.p) {
         unsigned err = 0;
         HIPCHK(h, hipMemcpy(&err, h->pub_err.p, sizeof err, hipMemcpyDeviceToHost));
+        if (err) *h->err_host = 1u;
         if (err) return fail(h, PRCG_ERCCL, "a one-launch iteration waited more than its bound for the reduced inner products "
                                             "(communication stream starved or a peer stalled); results are invalid. "
                                             "PRCG_FUSED_COMM=0 selects the two-kernel schedule");
@@ -1965,7 +2141,8 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
-    return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+    return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) |
+           (h->peer ? PRCG_SCHED_PEER : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW
@@ -1977,6 +2154,16 @@ int prcg_set_iteration(prcg_t* h, int k) {
     CHECK(h, h->in_session, "prcg_set_iteration: no open session");
     CHECK(h, k >= 0 && k < h->max_iter, "prcg_set_iteration: k out of range");
     h->k = k;
+    if (h->peer && is_pipe(h->variant)) {
+        // teacher forcing: the exchange buffers must describe the state just loaded -- rows and slot of "iteration k" again
+        int rc = prcg_sync(h);
+        if (rc) return rc;
+        if ((rc = allreduce(h, h->t1.d(), 1, h->sc))) return rc;      // (collective: nobody is still reading what the pushes overwrite)
+        launch_peer_push(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, k), k);
+        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), k, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+        HIPCHK(h, hipStreamSynchronize(h->sc));
+        return PRCG_OK;
+    }
     if (h->gather && is_pipe(h->variant)) {
         // teacher forcing: what the deferred launch of iteration k+1 waits for and what its boundary tiles read
         // must describe the state just loaded (the exchange is collective over the session's ranks)
@@ -2052,6 +2239,7 @@ int prcg_set_scalars(prcg_t* h, int k, const double* in) {
     int rc = prcg_sync(h);
     if (rc) return rc;
     if ((rc = h2d(h, dots_at(h, k), in, kNS))) return rc;
+    if (h->peer) return PRCG_OK;      // (prcg_set_iteration re-sends rows and slot once the whole state is loaded)
     if (h->fused_comm) {      // the deferred launch of iteration k+1 reads the published copy
         launch_publish(h->sc, dots_at(h, k), h->pub.d(), (unsigned)k);
         HIPCHK(h, hipStreamSynchronize(h->sc));

@@ -21,6 +21,35 @@ constexpr int kPartialStride = 8;                   // doubles per block in a pa
 struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 #endif
 
+// ---- direct peer exchange over xGMI (multi-rank one-launch schedule) ------------------------
+// Every rank owns one EXCHANGE BUFFER (fine-grained device memory, mapped into every other rank's process with
+// hipIpc): per parity (iteration & 1) one 64-byte SLOT per rank -- that rank's five partial inner products of the
+// iteration and a 64-bit counter -- and a GHOST AREA that the neighbours' launches fill with the rows this rank needs.
+// A launch writes with system-scope stores straight into the consumers' buffers: the rows its tiles update (as soon
+// as the tile is done), then, from its last workgroup, its slot in EVERY rank's buffer.  The next launch of a rank
+// waits (inside the kernel, after the part of its work that needs neither) until all R slots of its own buffer carry
+// the iteration's counter, adds them in rank order -- the same bits on every rank -- and reads its ghost rows from
+// its own buffer.  No collective, no communication stream, one host call per iteration.
+//   layout (doubles):  slot(par, q) at (par * R + q) * 8 : [5 sums, pad, pad, counter]
+//                      ghost(par)   at 16 * R + par * 2 * (ghost_cap + 64) : ghost_cap pairs (+ 64 spare: a window page)
+//   counter = epoch | (k + 1): epoch = session number << 32 (stale slots of an earlier session are smaller)
+constexpr int kMaxPeerRanks = 16;
+struct PeerDev {
+    double* mine;                       // this rank's exchange buffer
+    double* peer[kMaxPeerRanks];        // every rank's exchange buffer as mapped here (peer[rank] == mine)
+    const int2* tile_send;              // per tile of the table in use: [first, end) of its entries in send_ent
+    const int4* send_ent;               // {local row, destination rank, index in the destination's ghost area, 0}, by tile
+    unsigned* ticket;                   // arrival counter of a launch's workgroups (zero between launches)
+    int rank, nranks, n_own, ghost_cap;
+    unsigned long long epoch;
+    int n_send;                         // entries in send_ent
+};
+__host__ __device__ inline int peer_slot_off(int nranks, int par, int q) { return (par * nranks + q) * 8; }
+__host__ __device__ inline long long peer_ghost_off(int nranks, int ghost_cap, int par) {
+    return 16LL * nranks + (long long)par * 2 * (ghost_cap + 64);
+}
+inline size_t peer_buffer_doubles(int nranks, int ghost_cap) { return (size_t)peer_ghost_off(nranks, ghost_cap, 2); }
+
 // partial inner products of the previous one-launch iteration (see launch_pipe_fused)
 // (+ the in-place operands of the Jacobi / 'p' flavours, see FusedState)
 struct FusedPrev {
@@ -30,6 +59,8 @@ struct FusedPrev {
     // bytes, each 5 doubles + a 32-bit iteration counter at byte 48, all stored write-through).  Each wave first computes the products of
     // its first tiles, then waits for pub's counter to reach `want`, then applies the deferred updates.
     const double* pub; unsigned want; unsigned* err;
+    const PeerDev* px;   // non-null: direct peer exchange (above) -- the launch's last workgroup sends this rank's partial sums,
+                         // its tiles send the rows the neighbours need, workgroup 0 turns the ranks' slots into `pub`
     int nt_int;       // tiles [nt_int, ntiles) touch ghost columns: they are neither computed nor even requested before
                       // the publication has arrived (the ghost rows travel with it)
     const double* dots_old;   // Hestenes-Stiefel product launch: the scalars of iteration k-1 (nu_k1 for b_k = nu_k / nu_k1)
@@ -315,6 +346,13 @@ void launch_gather_pack(hipStream_t st, const double* partials, int nparts, doub
 void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, int nranks, double* dots_out,
                           double* rs_ghost, const int* ghost_src, int nghost, double* pub = nullptr, unsigned pub_value = 0,
                           hipEvent_t done = nullptr);
+// peer exchange outside the iteration launches (session start, teacher forcing): send this rank's rows of `rs` to the
+// neighbours' ghost areas of parity k & 1 and its slot for iteration k (rank 0 contributes dots, the others zeros: the
+// sum in rank order is then exactly dots -- the state just set is the same on every rank)
+void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k);
+// one wave waits (bounded) until all ranks' slots of iteration k have arrived, adds them in rank order into dots_out[0..5)
+// and, if pub, publishes them with counter k; *err = 1 on a timeout
+void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, double* dots_out, double* pub, unsigned* err);
 // every copy c: pub[8c .. 8c+5) = dots[0..5), then the copy's counter (byte 48 of the record) = value: what the
 // deferred one-launch iteration waits for
 constexpr int kPubCopies = 64;

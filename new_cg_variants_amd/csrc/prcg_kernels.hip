@@ -882,6 +882,39 @@ __global__ __launch_bounds__(kFinalThreads) void k_gather_unpack(
     }
 }
 
+// ---- direct peer exchange outside the iteration launches (PeerDev, prcg_kernels.h) ----
+__global__ __launch_bounds__(256) void k_peer_push(const PeerDev* __restrict__ px, const double2* __restrict__ rs,
+                                                   const double* __restrict__ dots, int k) {
+    const int R = px->nranks;
+    const long long gout = peer_ghost_off(R, px->ghost_cap, k & 1);
+    for (int e = threadIdx.x; e < px->n_send; e += 256) {
+        const int4 ent = px->send_ent[e];
+        const double2 v = rs[ent.x];
+        double* dst = px->peer[ent.y] + gout + 2 * (long long)ent.z;
+        peer_store(dst, v.x);
+        peer_store(dst + 1, v.y);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // rank 0 contributes the (global) inner products of state k, the others zeros: added in rank order that is dots
+        const double v = (threadIdx.x < 5 && px->rank == 0) ? dots[threadIdx.x] : 0.0;
+        peer_send_slot(px, k, v);
+    }
+}
+__global__ __launch_bounds__(64) void k_peer_collect(const PeerDev* __restrict__ px, int k, double* __restrict__ dots_out, double* pub,
+                                                     unsigned* err) {
+    double tot[5];
+    const bool ok = peer_collect(px, k, 1u << 24, tot);
+    const int lane = threadIdx.x;
+    if (!ok && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v = lane == q ? tot[q] : v;
+    if (lane < 5 && dots_out) dots_out[lane] = v;
+    if (pub) publish(pub, v, 5, (unsigned)k);
+}
+
 __global__ __launch_bounds__(64) void k_publish(const double* __restrict__ dots, double* pub, unsigned value) {
     const double v = threadIdx.x < 5 ? dots[threadIdx.x] : 0.0;
     publish(pub, v, 5, value);
@@ -1231,6 +1264,12 @@ void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigne
     hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, st, pub, want, err);
 }
 
+void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k) {
+    hipLaunchKernelGGL(k_peer_push, dim3(1), dim3(256), 0, st, px, reinterpret_cast<const double2*>(rs), dots, k);
+}
+void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, double* dots_out, double* pub, unsigned* err) {
+    hipLaunchKernelGGL(k_peer_collect, dim3(1), dim3(64), 0, st, px, k, dots_out, pub, err);
+}
 void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, dots, pub, value);
 }

@@ -54,8 +54,11 @@ namespace {
 
 // pages + column encoding of tiles [first, last) of `tiles`; returns the most pages a tile needed,
 // or -1 if one needed more than max_pages
-int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n_cols, const int32_t* indptr,
+// n_own: owned columns [0, n_own) -- a page never serves columns on both sides of n_own (the ghost columns may live in
+// another buffer than the owned ones: the peer-exchange schedule reads them from the rank's exchange buffer)
+int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n_own, int64_t n_cols, const int32_t* indptr,
                  const int32_t* indices, int max_pages, uint16_t* cw) {
+    auto page_end = [n_own](int32_t start) { return (int64_t)start < n_own ? std::min<int64_t>((int64_t)start + 64, n_own) : (int64_t)start + 64; };
     std::vector<int32_t> cols;
     int most = 0;
     for (size_t ti = first; ti < last; ++ti) {
@@ -75,8 +78,8 @@ int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n
         bool fail = false;
         for (;;) {
             // smallest uncovered column among the needed ones and the own rows
-            while (ci < cols.size() && np > 0 && cols[ci] < page[np - 1] + 64) ++ci;
-            if (np > 0 && own < page[np - 1] + 64) own = std::max(own, page[np - 1] + 64);
+            while (ci < cols.size() && np > 0 && cols[ci] < page_end(page[np - 1])) ++ci;
+            if (np > 0 && own < page_end(page[np - 1])) own = (int32_t)std::max<int64_t>(own, page_end(page[np - 1]));
             int32_t c;
             const bool have_col = ci < cols.size(), have_own = own < t.re;
             if (!have_col && !have_own) break;
@@ -86,8 +89,9 @@ int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n
             // keep the page inside the vector where possible (its 64 entries are loaded unconditionally); a page
             // pushed behind the previous one may still end up to 63 entries past n_cols -- every vector that feeds
             // a product is allocated with spare entries behind its end (kGatherPad, prcg_engine.cpp)
-            if ((int64_t)c + 64 > n_cols) c = (int32_t)std::max<int64_t>(n_cols - 64, 0);
-            if (np > 0 && c < page[np - 1] + 64) c = page[np - 1] + 64;   // pages never overlap
+            // (a page of ghost columns is not pulled back below n_own; it may end past n_cols like a pushed one)
+            if ((int64_t)c + 64 > n_cols) c = (int32_t)std::max<int64_t>(n_cols - 64, (int64_t)c >= n_own ? n_own : 0);
+            if (np > 0 && c < page_end(page[np - 1])) c = (int32_t)page_end(page[np - 1]);   // the columns a page SERVES never overlap
             page[np++] = c;
         }
         if (fail) return -1;
@@ -101,13 +105,14 @@ int window_pages(std::vector<WTile>& tiles, size_t first, size_t last, int64_t n
         for (int32_t q = t.lo; q < t.hi; ++q) {
             const int32_t col = indices[q];
             int p = (int)(std::upper_bound(page, page + np, col) - page) - 1;
+            // (col lies inside page p: pages are opened at uncovered columns and cover 64 -- or up to n_own)
             cw[q] = (uint16_t)(p * 64 + (col - page[p]));
         }
     }
     return most;
 }
 
-bool window_class(std::vector<WTile>& tiles, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
+bool window_class(std::vector<WTile>& tiles, int64_t n_own, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
                   int max_pages, uint16_t* cw, int* most_pages) {
     if (tiles.empty()) { *most_pages = 0; return true; }
     unsigned nt = std::thread::hardware_concurrency();
@@ -119,8 +124,8 @@ bool window_class(std::vector<WTile>& tiles, int64_t n_cols, const int32_t* indp
     const size_t per = (tiles.size() + nt - 1) / nt;
     for (unsigned i = 0; i < nt; ++i) {
         const size_t a = std::min(tiles.size(), i * per), b = std::min(tiles.size(), a + per);
-        if (nt == 1) res[0] = window_pages(tiles, a, b, n_cols, indptr, indices, max_pages, cw);
-        else th.emplace_back([&, a, b, i] { res[i] = window_pages(tiles, a, b, n_cols, indptr, indices, max_pages, cw); });
+        if (nt == 1) res[0] = window_pages(tiles, a, b, n_own, n_cols, indptr, indices, max_pages, cw);
+        else th.emplace_back([&, a, b, i] { res[i] = window_pages(tiles, a, b, n_own, n_cols, indptr, indices, max_pages, cw); });
     }
     for (auto& t : th) t.join();
     int most = 0;
@@ -162,8 +167,8 @@ void plan_window_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const i
         }
     }
     if (n_cols < 64) out.ok0 = out.ok1 = false;     // a page must fit inside the vector
-    if (out.ok0) out.ok0 = window_class(out.t0, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages0);
-    if (out.ok1) out.ok1 = window_class(out.t1, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages1);
+    if (out.ok0) out.ok0 = window_class(out.t0, n, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages0);
+    if (out.ok1) out.ok1 = window_class(out.t1, n, n_cols, indptr, indices, max_pages, out.cw.data(), &out.pages1);
 }
 
 namespace {

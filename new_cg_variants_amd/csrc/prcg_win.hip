@@ -145,7 +145,8 @@ template <int NV, int EPI, int M, int PG, int CW, bool VD>
 __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d, int lane,
                                             const typename VecT<NV>::type* __restrict__ X, const double* __restrict__ X2,
                                             const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
-                                            WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false) {
+                                            WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false,
+                                            const typename VecT<NV>::type* G = nullptr, int n_own = 0) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -191,7 +192,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane];
                 if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) R.w[p].z = pr.d[d.pc[p] + lane];
             }
-            else R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];
+            else {
+                // (peer exchange: a page of ghost columns lies in this rank's exchange buffer -- pages never straddle n_own)
+                const typename VecT<NV>::type* src = (G != nullptr && d.pc[p] >= n_own) ? G : X;
+                R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(src)[d.pc[p] + lane];
+            }
         }
     }
 #pragma unroll
@@ -243,6 +248,49 @@ __device__ __forceinline__ void win_block_reduce_store(double (&acc)[NQ], double
     }
 }
 
+// End of a launch with the direct peer exchange: every workgroup leaves its partial sums where the others can see them
+// (agent-scope stores: written through, no L2 write-back of the launch's dirty vectors) and draws a ticket; the LAST
+// workgroup adds all partials in the fixed 256-thread tree and sends this rank's slot of iteration k to every rank.
+// Every wave has waited for its own stores -- the rows it sent to the neighbours included -- before the ticket is drawn,
+// so a neighbour that sees the slot's counter finds the rows in its ghost area.
+template <int WPB>
+__device__ __forceinline__ void peer_tail(double (&acc)[5], double* partials, const PeerDev* px, int k) {
+    __shared__ double red[WPB][5];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) v += red[w][threadIdx.x];
+        __hip_atomic_store(partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(px->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = tk == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double tot[5];
+    sum_prev_partials<5, WPB>(partials, (int)gridDim.x, 0, tot);
+    if (wv == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v = lane == q ? tot[q] : v;
+        peer_send_slot(px, k, v);
+        if (lane == 0) __hip_atomic_store(px->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts at zero
+    }
+}
+
 // per-wave constants of the tile loop
 template <int NV>
 struct WCtx {
@@ -253,12 +301,41 @@ struct WCtx {
     FusedRowPtrs fr;
     FusedPrev::PrOne pr;
     int lane;
+    // direct peer exchange (deferred form only, else null): the ghost columns [n_own, ...) of the input vector are read
+    // from this rank's exchange buffer (G = its ghost area of the iteration read, minus n_own), the rows the neighbours
+    // need go to THEIR ghost areas of the iteration written (offset gout, in doubles, into every exchange buffer)
+    const typename VecT<NV>::type* G; int n_own; const PeerDev* px; long long gout;
 };
 
 // One tile: park its image (R, requested DEPTH tiles ago) in LDS, request tile `dnext` into the
 // freed registers, then lane i walks row i (and i + 64, ...).
 // STASH: only the products -- the row sums go to `stash` (this wave's LDS, [M][64] pairs), the epilogue
 // follows later (deferred form of the one-launch iteration).
+// Direct peer exchange: the rows of tile t that neighbours need (px->tile_send / send_ent, planned on the host) go
+// straight into the destinations' ghost areas.  newp[j] = the new input pair of row rb + j*64 + lane, still in
+// registers; entry e is handled by lane e % 64, which fetches the pair from the lane that owns the row.
+template <int M>
+__device__ __forceinline__ void peer_send_rows(const PeerDev* px, int t, int rb, const double2 (&newp)[M], long long gout, int lane) {
+    const int2 ts = px->tile_send[t];
+    const int first = __builtin_amdgcn_readfirstlane(ts.x), end = __builtin_amdgcn_readfirstlane(ts.y);
+    for (int e0 = first; e0 < end; e0 += 64) {                              // wave-uniform
+        const int e = e0 + lane;
+        const bool on = e < end;
+        const int4 ent = px->send_ent[on ? e : first];
+        const int rel = ent.x - rb, src = rel & 63;
+        double2 v = make_double2(__shfl(newp[0].x, src, 64), __shfl(newp[0].y, src, 64));
+        if constexpr (M > 1) {
+            const double2 v1 = make_double2(__shfl(newp[1].x, src, 64), __shfl(newp[1].y, src, 64));
+            if (rel >= 64) v = v1;
+        }
+        if (on) {
+            double* dst = px->peer[ent.y] + gout + 2 * (long long)ent.z;
+            peer_store(dst, v.x);
+            peer_store(dst + 1, v.y);
+        }
+    }
+}
+
 __device__ __forceinline__ double uniform_double(double v) {       // the same value in every lane -> scalar registers
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
@@ -270,7 +347,7 @@ template <int NV, int EPI, int M, int PG, int CW, bool VD, int RL, bool STASH = 
 __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
                                          double (&acc)[5], const Coefs& cf, RowCache<M, RL, CW>& rc, bool same_cur,
-                                         double2* stash = nullptr, bool acquire_first = false)
+                                         double2* stash = nullptr, bool acquire_first = false, int tcur = 0)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -345,9 +422,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     // ---- request the tile DEPTH ahead (the image registers are free again) ----
     if (have_next) {
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
-        if (acquire_first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (acquire_first) { if (c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
         next_same = same_image<PG>(rc, dnext);
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own);
     }
 
     const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
@@ -402,6 +479,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     const bool cached = RL > 0 && (same_cur || fill);                  // wave-uniform
 
     // ---- lane i walks row i (and i + 64, ...) ----
+    double2 newp[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) newp[j] = make_double2(0.0, 0.0);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int row = dcur.rb + j * 64 + lane;
@@ -485,7 +565,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
             // update k of the row while (A in)_i = sum is in registers; the row's own entry of the OLD input
             // pair array comes from the staged window, the new pair goes to the other array
             const double2 in_old = c.sw[active ? dcur.own + j * 64 + lane : 0];
-            if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, fin[j], in_old, c.fr, cf, acc);
+            if (active) newp[j] = fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, fin[j], in_old, c.fr, cf, acc);
         } else if constexpr (epi_pr_one(EPI)) {
             // the row's own update (pr_cg.py:146-148,151) with the same expressions as the staged window, then
             // s = A p, s~ = d s and the partials of mu, dl, gm, nu, r.r (pr_cg.py:152-157)
@@ -552,6 +632,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
             if (active) finish_row<NV, EPI>(row, sum, c.yout, c.write_mask, c.X, c.ep_r, c.ep_d, c.ep_st, acc, cf, c.fr);
         }
     }
+    if constexpr (FUSED && !STASH) {
+        if (c.px) peer_send_rows<M>(c.px, tcur, dcur.rb, newp, c.gout, lane);
+    }
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
     return next_same;
 }
@@ -603,11 +686,23 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_), ep_r,
+    WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_), ep_r,
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
                                   reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt},
-                     fz.pr, lane};
+                     fz.pr, lane, nullptr, 0, nullptr, 0};
+    WCtx<NV>& cm = c;
+    if constexpr (DEF > 0) {
+        if (fz.px) {
+            // direct peer exchange: this launch is iteration k = want + 1; it reads the ghost rows of iteration k - 1 from
+            // its own exchange buffer and sends the rows of iteration k to the neighbours' buffers
+            const PeerDev* px = fz.px;
+            const int R = px->nranks;
+            cm.px = px; cm.n_own = px->n_own;
+            cm.G = reinterpret_cast<const V*>(px->mine + peer_ghost_off(R, px->ghost_cap, (int)(fz.want & 1u))) - px->n_own;
+            cm.gout = peer_ghost_off(R, px->ghost_cap, (int)((fz.want + 1u) & 1u));
+        }
+    }
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
@@ -674,7 +769,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         same[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i]);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own);
             else pend[i] = true;
         }
     }
@@ -683,7 +778,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     if constexpr (DEF > 0) {
         // ---- phase A: products of the first DEF tiles, sums parked in LDS ----
         int n_def = 0;
-        int rbA[DEF], reA[DEF];            // rows of the deferred tiles (wave-uniform)
+        int rbA[DEF], reA[DEF], tA[DEF];   // rows and table index of the deferred tiles (wave-uniform)
 #pragma unroll
         for (int turn = 0; turn < DEF / DEPTH; ++turn) {
 #pragma unroll
@@ -694,7 +789,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                     const bool have_next = tnext < safe;
                     d[i] = dn;
                     pend[i] = tnext < ntiles && !have_next;
-                    rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re;
+                    rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re; tA[turn * DEPTH + i] = t;
                     same[i] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i],
                                                                          s_stash[wv] + (turn * DEPTH + i) * M * 64);
                     if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
@@ -704,17 +799,37 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             }
         }
         // ---- wait for the reduced inner products of the previous iteration ----
+        if (fz.px && blockIdx.x == 0 && wv == 0) {
+            // direct peer exchange: ONE wave of the launch turns the ranks' slots (this rank's exchange buffer) into the
+            // publication record everybody else polls: all R counters seen -> sums added in rank order -> published
+            double tot[5];
+            const bool ok = peer_collect(fz.px, (int)fz.want, PRCG_WAIT_SPINS, tot);
+            if (!ok && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            double* mine = const_cast<double*>(fz.pub) + (size_t)lane * 8;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) __hip_atomic_store(mine + q, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 6), fz.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fz.dots_prev_out) {                                                      // the history's copy
+#pragma unroll
+                for (int q = 0; q < 5; ++q) if (lane == q) fz.dots_prev_out[q] = tot[q];
+            }
+        }
         {
             // this wave's copy of the record (the copies spread the pollers over the L2 channels)
             const double* rec = fz.pub + (size_t)((blockIdx.x * WPB + wv) & (kPubCopies - 1)) * 8;
             const unsigned* cnt = reinterpret_cast<const unsigned*>(rec + 6);
             unsigned spins = 0;
-            bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // sticky: never wait twice
+            bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;   // sticky: never wait twice
             while (!timed_out && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fz.want) < 0) {
                 __builtin_amdgcn_s_sleep(32);                                 // ~1 us between polls
                 if (++spins > PRCG_WAIT_SPINS) timed_out = true;             // ~10 s: a stalled peer, not a slow one
             }
-            if (timed_out && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (timed_out && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the payload was stored, and had left its CU, before the counter was: keep the payload loads behind the
+            // counter load (compiler: wavefront-scope acquire emits no cache operation; hardware: vmem returns in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             double dp[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) dp[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -737,9 +852,9 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i)
             if (pend[i]) {
-                if (!acquired) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+                if (!acquired) { if (fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
                 same[i] = same_image<PG>(rc, d[i]);
-                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], same[i]);
+                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], same[i], c.G, c.n_own);
                 pend[i] = false;
             }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -767,13 +882,16 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
                     if (c0 + i < n_def) {
+                        double2 newp[M];
 #pragma unroll
                         for (int j = 0; j < M; ++j) {
                             const int row = rbA[c0 + i] + j * 64 + lane;
+                            newp[j] = make_double2(0.0, 0.0);
                             if (row < reA[c0 + i])
-                                fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, s_stash[wv][((c0 + i) * M + j) * 64 + lane],
-                                                                                    q[i][j], io[i][j], c.fr, cf, acc);
+                                newp[j] = fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, s_stash[wv][((c0 + i) * M + j) * 64 + lane],
+                                                                                              q[i][j], io[i][j], c.fr, cf, acc);
                         }
+                        if (fz.px) peer_send_rows<M>(fz.px, tA[c0 + i], rbA[c0 + i], newp, c.gout, lane);
                     }
                 }
             }
@@ -789,7 +907,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
                 const bool have_next = tnext < ntiles;
                 d[i] = dn;
                 const bool acq = DEF > 0 && have_next && tnext >= safe && !acquired;
-                same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], nullptr, acq);
+                same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], nullptr, acq, t);
                 if (acq) acquired = true;
                 // descriptor of the tile after that one: loaded now, looked at one step later
                 if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
@@ -798,6 +916,13 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         }
     }
 
+    if constexpr (FUSED && DEF > 0) {
+        if (fz.px) {
+            if constexpr (!epi_prec(EPI)) acc[4] = acc[3];
+            peer_tail<WPB>(acc, partials, fz.px, (int)fz.want + 1);
+            return;
+        }
+    }
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
@@ -861,8 +986,9 @@ int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
 // 160 KiB of LDS per CU.  The bound below keeps room for one such workgroup on every CU
 // (2-wave workgroups do not: two of them can land on the same SIMD pair and fill its register file --
 // seen as a stalled reduction with the 250-register 128-row geometry).
-int defer_grid_per_cu(const void* kernel) {
-    constexpr int kGuestVgprs = 144, kGuestLds = 24 * 1024;
+int defer_grid_per_cu(const void* kernel, bool guest) {
+    // (direct peer exchange: nothing else has to run beside the launch -- only its own residency counts)
+    const int kGuestVgprs = guest ? 144 : 0, kGuestLds = guest ? 24 * 1024 : 0;
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return 1;
     const int vg = ((fa.numRegs + 7) / 8) * 8;
@@ -907,12 +1033,12 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     constexpr int WPB = DEFER ? kWPBDefer : waves_per_block(win_nw(NV, EPI), PG, CW, vd);
     auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
-    static int cached_ntiles_cap[2][16] = {};
+    static int cached_ntiles_cap[2][2][16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int& cap = cached_ntiles_cap[vd ? 1 : 0][dev & 15];
+    int& cap = cached_ntiles_cap[vd ? 1 : 0][fz.px ? 1 : 0][dev & 15];
     int tuned = (vd ? 16 : 8) / WPB;        // resident waves per CU that stream best (see win_grid)
-    if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k));
+    if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k), fz.px == nullptr);
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
     int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
     const int need = (ntiles + WPB - 1) / WPB;

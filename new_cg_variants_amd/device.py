@@ -96,6 +96,7 @@ class DeviceCSR:
         self.n, self.n_ghost, self.nnz = int(n_rows), int(n_ghost), int(A.nnz)
         self._check(self._lib.prcg_set_csr(self._h, self.n, self.n_ghost, self.nnz, L.ptr(indptr), int(is64),
                                            L.ptr(indices), L.ptr(data)))
+        self.halo = halo
         if halo is not None:
             peers = np.ascontiguousarray(halo['peers'], dtype=np.int32)
             send_ptr = np.ascontiguousarray(halo['send_ptr'], dtype=np.int64)
@@ -103,6 +104,24 @@ class DeviceCSR:
             recv_ptr = np.ascontiguousarray(halo['recv_ptr'], dtype=np.int64)
             self._check(self._lib.prcg_set_halo(self._h, len(peers), L.ptr(peers), L.ptr(send_ptr),
                                                 L.ptr(send_idx), L.ptr(recv_ptr)))
+
+    # -- direct peer exchange (prcg.h: prcg_peer_setup / prcg_peer_connect) ------------------------------
+    def peer_setup(self, max_ghost_any_rank):
+        """Allocate this rank's exchange buffer; returns (64-byte IPC handle, device address)."""
+        handle = np.zeros(64, dtype=np.uint8)
+        ptr = C.c_void_p()
+        self._check(self._lib.prcg_peer_setup(self._h, int(max_ghost_any_rank), L.ptr(handle), C.byref(ptr)))
+        return handle.tobytes(), int(ptr.value or 0)
+
+    def peer_connect(self, handles, same_process_ptrs, send_dst_off):
+        """handles: list of 64-byte IPC handles in rank order (or None); same_process_ptrs: list of device addresses
+        (0: use the handle) or None; send_dst_off[q]: where this rank's rows begin in peer q's ghost area."""
+        hb = None if handles is None else np.frombuffer(b''.join(handles), dtype=np.uint8).copy()
+        pp = None if same_process_ptrs is None else (C.c_void_p * len(same_process_ptrs))(*[C.c_void_p(int(v) or None) for v in same_process_ptrs])
+        off = np.ascontiguousarray(send_dst_off, dtype=np.int64)
+        if off.size == 0:
+            off = np.zeros(1, dtype=np.int64)
+        self._check(self._lib.prcg_peer_connect(self._h, L.ptr(hb), pp, L.ptr(off)))
 
     # -- products (tests / bench) ---------------------------------------------------------
     def matvec(self, x, reps=1):
@@ -180,7 +199,7 @@ class DeviceCSR:
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
                 'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
-                'window': bool(s & 4096), 'fused_comm': bool(s & 8192)}
+                'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384)}
 
     def layout(self):
         """Diagnostic (prcg.h: prcg_debug_layout): what the summation order of the one-launch iteration's inner

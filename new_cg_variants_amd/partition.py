@@ -104,6 +104,53 @@ def split_serial(A, nranks, offsets=None):
     return offsets, out
 
 
+def receive_offsets(halo):
+    """{peer rank: first slot of its rows in this rank's ghost area} of a halo plan -- what every OTHER rank needs to
+    know to store its rows straight into this rank's exchange buffer (direct peer exchange)."""
+    if halo is None:
+        return {}
+    return {int(q): int(halo['recv_ptr'][i]) for i, q in enumerate(halo['peers'])}
+
+
+def connect_peer_exchange(dev, rank, allgather):
+    """Collective over the ranks of a run (``allgather(obj) -> [obj of rank 0, ...]``): give every rank's device handle
+    the direct peer exchange (prcg.h: prcg_peer_setup / prcg_peer_connect) -- exchange buffers allocated with one common
+    ghost capacity, IPC handles (or, for ranks that share the process, device addresses) swapped, destination offsets
+    taken from the receivers' halo plans.  Returns True if every rank connected; otherwise every rank stays on the
+    RCCL schedules (the decision is the same everywhere)."""
+    import os
+    halo = getattr(dev, 'halo', None)
+    infos = allgather({'g': int(dev.n_ghost), 'recv': receive_offsets(halo)})
+    cap = max(i['g'] for i in infos)
+    ok, err = True, None
+    try:
+        handle, ptr = dev.peer_setup(cap)
+    except Exception as exc:           # noqa: BLE001 -- decided collectively below
+        ok, err, handle, ptr = False, exc, b'\0' * 64, 0
+    mine = os.getpid()
+    everyone = allgather({'ok': ok, 'handle': handle, 'pid': mine, 'ptr': ptr})
+    if all(e['ok'] for e in everyone):
+        try:
+            peers = [] if halo is None else [int(q) for q in halo['peers']]
+            dst = [infos[q]['recv'][rank] for q in peers]
+            dev.peer_connect([e['handle'] for e in everyone], [e['ptr'] if e['pid'] == mine else 0 for e in everyone], dst)
+        except Exception as exc:       # noqa: BLE001
+            ok, err = False, exc
+    else:
+        ok = False
+    flags = allgather(bool(ok))
+    if not all(flags):
+        try:
+            dev.peer_setup(cap)        # (resets a connected handle: all ranks or none)
+        except Exception:              # noqa: BLE001
+            pass
+        if err is not None:
+            import sys
+            print(f'[prcg] rank {rank}: direct peer exchange not available ({err}); using the RCCL schedule', file=sys.stderr)
+        return False
+    return True
+
+
 def loopback_problem(A, k):
     """One rank's view of a row-block run, on ONE GPU: rewrite A as if it were cut at row n/2 into two
     row blocks whose halo is exchanged with ... itself.  Columns in [n/2-k, n/2) seen from rows >= n/2

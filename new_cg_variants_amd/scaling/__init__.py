@@ -119,6 +119,12 @@ class RowBlockOperator:
             A_local = A_rows.tocsr()
             self.ghost_ids = np.zeros(0, dtype=np.int64)
         self.dev = DeviceCSR(A_local, device=device, comm_init=comm_init, halo=halo, knobs=knobs)
+        # Direct peer exchange over xGMI (include/prcg.h): the per-iteration reduction and halo as stores into the
+        # consumers' buffers instead of collectives.  All ranks or none; PRCG_PEER=0 (environment or knob) keeps RCCL.
+        self.peer = False
+        want = (knobs or {}).get('PRCG_PEER', os.environ.get('PRCG_PEER', '1')) != '0'
+        if size > 1 and want:
+            self.peer = partition.connect_peer_exchange(self.dev, rank, comm.allgather_obj)
 
 
 def _as_operator(comm, A):

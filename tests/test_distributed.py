@@ -133,8 +133,8 @@ def test_one_launch_schedule_with_a_communicator(workload, prec):
     uid, path = rccl_ids(1)
     uid2, _ = rccl_ids(1)
     plain = DeviceCSR(A)
-    comm = DeviceCSR(A, comm_init=(0, 1, uid, path))
-    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid2, path), halo=halo)
+    comm = DeviceCSR(A, comm_init=(0, 1, uid, path), knobs={'PRCG_FUSED_COMM': '1'})
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid2, path), halo=halo, knobs={'PRCG_FUSED_COMM': '1'})
     for variant in (L.PIPE_PR, L.PIPE_P_M):
         outs = []
         for op in (plain, comm, loop):
@@ -241,8 +241,10 @@ def test_two_ranks_through_rccl_when_the_box_allows_it(tmp_path):
 # ranks on one device).  Real inter-rank data: what rank r reads in its ghost rows was computed by the
 # kernels of rank r +- 1.
 # ---------------------------------------------------------------------------------------
-def run_ranks_in_threads(A, nranks, variant, iters, knobs=None, inv_diag=None, hist_mask=15, offsets=None):
-    """Solve with `nranks` row blocks, one thread per rank, all on cuda:0.  Returns (x, histories of rank 0, schedules)."""
+def run_ranks_in_threads(A, nranks, variant, iters, knobs=None, inv_diag=None, hist_mask=15, offsets=None, peer=False, chunks=None):
+    """Solve with `nranks` row blocks, one thread per rank, all on cuda:0.  Returns (x, histories of rank 0, schedules).
+    peer: connect the ranks' exchange buffers (direct peer exchange; same process: device addresses instead of IPC handles).
+    chunks: lengths of the prcg_iterate calls (default: one call)."""
     import threading
     from new_cg_variants_amd import _lib as L
     from new_cg_variants_amd import partition, problems
@@ -263,22 +265,40 @@ def run_ranks_in_threads(A, nranks, variant, iters, knobs=None, inv_diag=None, h
             lo, hi = int(offsets[r]), int(offsets[r + 1])
             op = DeviceCSR(A_local, comm_init=(r, nranks, uid.tobytes(), path), halo=halo,
                            knobs=knobs[r] if isinstance(knobs, list) else knobs)
+            if peer:
+                assert partition.connect_peer_exchange(op, r, gather_objects), 'peer exchange did not connect'
             y = op.matvec(x_true[lo:hi] * (1.0 + np.arange(lo, hi)))[0]
             op.begin(variant, b[lo:hi], x0[lo:hi], iters + 1, x_true=x_true[lo:hi],
                      inv_diag=None if inv_diag is None else inv_diag[lo:hi], hist_mask=hist_mask)
             sched = op.schedule()
-            op.iterate(iters)
+            for c in (chunks or [iters]):
+                op.iterate(c)
             op.sync()
             out[r] = (op.get_vector('x'), op.history(), sched, y)
             op.close()
         except Exception as exc:           # noqa: BLE001 -- reported by the caller
             errs.append((r, repr(exc)))
 
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    # all-gather of Python objects among the rank threads (what torch.distributed.all_gather_object is between processes)
+    box = {}
+    barrier = threading.Barrier(nranks)
+    seq = [0] * nranks
+
+    def gather_objects(obj):
+        r = int(threading.current_thread().name.split('-')[-1])
+        key = seq[r]
+        seq[r] += 1
+        box[(key, r)] = obj
+        barrier.wait(timeout=120)
+        res = [box[(key, q)] for q in range(nranks)]
+        barrier.wait(timeout=120)
+        return res
+
+    threads = [threading.Thread(target=rank_main, args=(r,), name=f'rank-{r}', daemon=True) for r in range(nranks)]
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=240)
+        t.join(timeout=240)          # (daemon threads: a rank that never returns fails the test instead of hanging pytest)
     assert not errs, errs
     assert all(o is not None for o in out), 'a rank did not finish'
     x = np.concatenate([o[0] for o in out])
@@ -337,9 +357,9 @@ def test_ranks_in_threads_one_launch_schedule(workload, nranks, variant, prec):
     b, x0, x_true = problems.reference_rhs(A, n)
     inv_diag = (1 / A.diagonal()) if prec else None
     iters = 200
-    x, hist, scheds = run_ranks_in_threads(A, nranks, getattr(L, variant), iters, knobs={'PRCG_DEFER_GRID_PER_CU': '1'},
+    x, hist, scheds = run_ranks_in_threads(A, nranks, getattr(L, variant), iters, knobs={'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_FUSED_COMM': '1'},
                                            inv_diag=inv_diag)
-    assert all(s['fused_comm'] and s['gather'] for s in scheds), scheds
+    assert all(s['fused_comm'] and s['gather'] and not s['peer'] for s in scheds), scheds
     one = DeviceCSR(A)
     one.begin(getattr(L, variant), b, x0, iters + 1, x_true=x_true, inv_diag=inv_diag, hist_mask=15)
     one.iterate(iters)
@@ -371,7 +391,7 @@ def test_s3_full_size_row_blocks_in_threads():
     one.sync()
     ref = one.history()['updated_residual_2_norm']
     one.close()
-    for nranks, knobs, flag in ((8, {'PRCG_FUSED_COMM': '0'}, False), (2, {'PRCG_DEFER_GRID_PER_CU': '1'}, True)):
+    for nranks, knobs, flag in ((8, {'PRCG_FUSED_COMM': '0'}, False), (2, {'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_FUSED_COMM': '1'}, True)):
         x, hist, scheds = run_ranks_in_threads(A, nranks, L.PIPE_PR, iters, knobs=knobs, hist_mask=1)
         assert all(s['fused_comm'] == flag and s['gather'] and s['window'] for s in scheds), scheds
         np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
@@ -425,7 +445,7 @@ def test_ranks_in_threads_may_run_different_schedules():
     n = A.shape[0]
     b, x0, x_true = problems.reference_rhs(A, n)
     iters = 150
-    knobs = [{'PRCG_DEFER_GRID_PER_CU': '1'}, {'PRCG_FUSED_COMM': '0'}, {'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_WIN': '0'}]
+    knobs = [{'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_FUSED_COMM': '1'}, {'PRCG_FUSED_COMM': '0'}, {'PRCG_DEFER_GRID_PER_CU': '1', 'PRCG_FUSED_COMM': '1', 'PRCG_WIN': '0'}]
     x, hist, scheds = run_ranks_in_threads(A, 3, L.PIPE_PR, iters, knobs=knobs)
     assert [s['fused_comm'] for s in scheds] == [True, False, False] and all(s['gather'] for s in scheds), scheds
     one = DeviceCSR(A)
@@ -437,3 +457,130 @@ def test_ranks_in_threads_may_run_different_schedules():
     for q in ref_hist:
         np.testing.assert_allclose(hist[q][:8], ref_hist[q][:8], rtol=1e-11, atol=1e-13 * ref_hist[q][0], err_msg=q)
     np.testing.assert_allclose(hist['error_A_norm'][-1], ref_hist['error_A_norm'][-1], rtol=0.5)
+
+
+# ---------------------------------------------------------------------------------------
+# Direct peer exchange (include/prcg.h: prcg_peer_setup / prcg_peer_connect): the one-launch schedule whose reduction
+# and halo are stores into the consumers' exchange buffers -- no collective inside the loop.
+# ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,prec', [('s3_small', False), ('s3_small', True), ('s1_small', False)])
+def test_peer_exchange_with_one_rank_and_a_loopback_halo(workload, prec):
+    """One rank whose only peer is itself: the launch's tiles store the "neighbour's" rows into the rank's own exchange
+    buffer, its last workgroup the rank's slot, workgroup 0 of the next launch publishes it; boundary tiles read their
+    ghost pages from the exchange buffer.  Against the plain one-launch schedule: same arithmetic per element, the
+    inner products summed in another order (last workgroup's tree) -- prefix to rounding, convergence level beyond;
+    no wave may have timed out; iterate calls of any length."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems
+    from new_cg_variants_amd.device import DeviceCSR
+    from oracle import ne_oracle as orc
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    inv_diag = (1 / A.diagonal()) if prec else None
+    A_loop, halo, moved = partition.loopback_problem(A, 9 if workload == 's3_small' else 70)
+    uid, path = rccl_ids(1)
+    uid2, _ = rccl_ids(1)
+    plain = DeviceCSR(A)
+    solo = DeviceCSR(A, comm_init=(0, 1, uid, path))
+    loop = DeviceCSR(A_loop, comm_init=(0, 1, uid2, path), halo=halo)
+    for op in (solo, loop):
+        assert partition.connect_peer_exchange(op, 0, lambda obj: [obj])
+    for variant in (L.PIPE_PR, L.PIPE_P_M):
+        outs = []
+        for op in (plain, solo, loop):
+            op.begin(variant, b, x0, 300, x_true=x_true, inv_diag=inv_diag, hist_mask=15)
+            s = op.schedule()
+            assert s['fused'] and s['fused_comm'] == (op is not plain) and s['peer'] == (op is not plain) and not s['gather'], s
+            for c in (1, 2, 50, 246):
+                op.iterate(c)
+            op.sync()                                        # raises if a launch waited beyond its bound
+            outs.append((op.history(), op.get_vector('x')))
+        for other in outs[1:]:
+            for q in outs[0][0]:
+                np.testing.assert_allclose(other[0][q][:8], outs[0][0][q][:8], rtol=1e-11, atol=1e-13 * outs[0][0][q][0])
+            ia, aa = orc.convergence_summary(other[0]['error_A_norm'])
+            ib, ab = orc.convergence_summary(outs[0][0]['error_A_norm'])
+            assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
+    # teacher forcing reaches the exchange buffers: load the plain engine's state k into the loopback engine, step both
+    plain.begin(L.PIPE_PR, b, x0, 40, inv_diag=inv_diag)
+    loop.begin(L.PIPE_PR, b, x0, 40, inv_diag=inv_diag)
+    plain.iterate(7)
+    stored = ['x', 'r', 'p', 's'] + (['rt', 'st'] if prec else [])
+    for k in (7, 8, 9):
+        for v in stored:
+            loop.set_vector(v, plain.get_vector(v))
+        loop.set_scalars(k, plain.get_scalars(k))
+        loop.set_iteration(k)
+        plain.iterate(1)
+        loop.iterate(1)
+        for v in stored:
+            assert np.array_equal(loop.get_vector(v), plain.get_vector(v)), (k, v)
+        a, c = loop.get_scalars(k + 1)[:5], plain.get_scalars(k + 1)[:5]
+        assert np.max(np.abs(a - c) / np.abs(c)) <= 1e-12
+    for op in (plain, solo, loop):
+        op.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,nranks,variant,prec', [
+    ('s3_small', 2, 'PIPE_PR', False), ('s3_small', 3, 'PIPE_PR', True), ('s3_small', 4, 'PIPE_P', False),
+    ('s1_small', 2, 'PIPE_PR', False), ('s1_small', 3, 'PIPE_PR_M', True)])
+def test_ranks_in_threads_peer_exchange(workload, nranks, variant, prec):
+    """2-4 REAL ranks (threads on one GPU) through the direct peer exchange, small halos (band: 7 rows per side) and
+    large ones (stencil: a grid line): every rank's launch k+1 waits inside the kernel for the other ranks' launch k,
+    reads ghost rows the neighbours' tiles stored into its exchange buffer; no collective in the loop.  The ranks share
+    one GPU, so each launches one workgroup per CU (all of them must be resident at once)."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    from oracle import ne_oracle as orc
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    inv_diag = (1 / A.diagonal()) if prec else None
+    iters = 200
+    x, hist, scheds = run_ranks_in_threads(A, nranks, getattr(L, variant), iters, knobs={'PRCG_DEFER_GRID_PER_CU': '1'},
+                                           inv_diag=inv_diag, peer=True, chunks=[1, 3, 96, 100])
+    assert all(s['fused_comm'] and s['peer'] and not s['gather'] for s in scheds), scheds
+    one = DeviceCSR(A)
+    one.begin(getattr(L, variant), b, x0, iters + 1, x_true=x_true, inv_diag=inv_diag, hist_mask=15)
+    one.iterate(iters)
+    one.sync()
+    ref_hist, ref_x = one.history(), one.get_vector('x')
+    one.close()
+    for q in ref_hist:
+        np.testing.assert_allclose(hist[q][:8], ref_hist[q][:8], rtol=1e-11, atol=1e-13 * ref_hist[q][0], err_msg=q)
+    ia, aa = orc.convergence_summary(hist['error_A_norm'])
+    ib, ab = orc.convergence_summary(ref_hist['error_A_norm'])
+    assert abs(ia - ib) <= max(2, 0.05 * ib) and abs(aa - ab) <= 2.0, ((ia, aa), (ib, ab))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload,nranks', [('s2', 4), ('s3', 2)])
+def test_full_size_row_blocks_in_threads_peer_exchange(workload, nranks):
+    """BASELINE.json's multi-GPU configurations at full size through the direct peer exchange, ranks in threads on ONE
+    GPU: S2 (config 4: 7-point Laplacian 216^3 in 4 blocks of whole planes, halo = one 216^2 plane per side -- the
+    one-launch schedule now serves halos of any size) and S3 (n = 1e7 in 2 blocks)."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.WORKLOADS[workload]['make']()
+    n = A.shape[0]
+    b, x0, x_true = problems.reference_rhs(A, n)
+    iters = 30
+    offsets = None
+    if workload == 's2':
+        offsets = np.arange(nranks + 1, dtype=np.int64) * (216 // nranks) * 216 * 216
+    one = DeviceCSR(A)
+    one.begin(L.PIPE_PR, b, x0, iters + 1, hist_mask=1)
+    one.iterate(iters)
+    one.sync()
+    ref = one.history()['updated_residual_2_norm']
+    one.close()
+    x, hist, scheds = run_ranks_in_threads(A, nranks, L.PIPE_PR, iters, knobs={'PRCG_DEFER_GRID_PER_CU': '1'}, hist_mask=1,
+                                           offsets=offsets, peer=True)
+    assert all(s['fused_comm'] and s['peer'] and s['window'] for s in scheds), scheds
+    np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
+    np.testing.assert_allclose(hist['updated_residual_2_norm'], ref, rtol=1e-4)
