@@ -99,6 +99,8 @@ def lib():
             raise ImportError(
                 f'{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). '
                 'new_cg_variants_amd has no CPU fallback.')
+        global _torch_runtime
+        _torch_runtime = 'torch' in sys.modules      # which HIP runtime libprcg.so binds to is decided HERE, at load time
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
@@ -108,10 +110,16 @@ def lib():
     return _lib
 
 
+_torch_runtime = None
+
+
 def default_rccl_path():
-    """RCCL must be the copy that matches the HIP runtime already in the process: torch
-    wheels bundle their own libamdhip64/librccl, so prefer those once torch is imported."""
-    if 'torch' in sys.modules:
+    """RCCL must be the copy that matches the HIP runtime libprcg.so itself is bound to: torch wheels bundle their
+    own libamdhip64/librccl, so torch's copy iff torch was imported BEFORE libprcg.so was loaded (a torch imported later
+    brings a second runtime into the process; streams of one handed to the RCCL of the other fail with "unhandled
+    cuda error")."""
+    lib()
+    if _torch_runtime and 'torch' in sys.modules:
         cand = os.path.join(os.path.dirname(sys.modules['torch'].__file__), 'lib', 'librccl.so')
         if os.path.exists(cand):
             return cand

@@ -502,6 +502,13 @@ int record(prcg_t* h, int k) {
     if (h->hs_fused) hs_flush(h);
     if (h->pr_fused) fused_flush(h);
     if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
+    if (h->peer && h->pend_parts > 0) {
+        // (peer exchange: the last launch's partials are still to be sent by the next launch's communication wave -- the
+        //  recorders reuse the buffer, so the slot goes out now)
+        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->pend_k, h->pend_buf, h->pend_parts, dots_at(h, h->pend_k),
+                            h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+        h->pend_parts = 0;
+    }
     const int64_t n = h->n;
     int rc;
     if (m & PRCG_HIST_RESIDUAL_2_NORM) {
@@ -750,6 +757,10 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
         // this rank's partial sums, and its workgroup 0 turns the ranks' slots of iteration k-1 into the publication
         f.prev.px = static_cast<const PeerDev*>(h->peer_dev.p);
         f.prev.dots_prev_out = dots_at(h, k - 1);
+        f.prev.err_host = h->err_host;
+        // the partial sums launch k-1 left are summed and SENT by this launch's communication wave (none pending: the
+        // slot of iteration k-1 is already out -- session start, teacher forcing, or the end of the last prcg_iterate call)
+        if (h->pend_parts > 0 && h->pend_k == k - 1) { f.prev.prev_partials = h->pend_buf; f.prev.nprev = h->pend_parts; }
     }
     bool on = false;
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
@@ -758,6 +769,7 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     h->last_grid = g1;
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     if (h->peer) {
+        h->pend_parts = g1; h->pend_k = k; h->pend_buf = part_out;
         h->rs_cur = in_new;
         return PRCG_OK;
     }
@@ -1724,6 +1736,10 @@ int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_proc
     P.ticket = static_cast<unsigned*>(h->peer_ticket.p);
     P.n_send = (int)ents.size();
     HIPCHK(h, hipMemcpy(h->peer_dev.p, &P, sizeof P, hipMemcpyHostToDevice));
+    if (h->win) {
+        launch_flag_send_tiles(h->sc, h->wtiles.p, h->peer_tile_send.p, (int)nt);
+        HIPCHK(h, hipStreamSynchronize(h->sc));
+    }
     // (a non-window operator keeps the two-kernel schedule: the exchange is the iteration launch's own, and only the
     //  window kernels have it)
     h->peer_ok = h->win;
@@ -1932,7 +1948,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             HIPCHK(h, hipStreamSynchronize(sc));                       // (peer_host must not change under the copy)
             *h->err_host = 0u;
             launch_peer_push(sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, 0), 0);
-            launch_peer_collect(sc, static_cast<const PeerDev*>(h->peer_dev.p), 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+            launch_peer_collect(sc, static_cast<const PeerDev*>(h->peer_dev.p), 0, nullptr, 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
         } else if (h->fused_comm) {
             // LOCAL part.  Can a kernel of the communication stream run while a kernel of the compute stream waits for
             // it?  (HIP may have mapped both streams to one hardware queue -- then the deferred form would only ever
@@ -2105,9 +2121,13 @@ int prcg_iterate(prcg_t* h, int iters) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     }
-    if (h->peer && iters > 0)       // the inner products of the last iteration: every rank's slot, added in rank order
-        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->k, dots_at(h, h->k), h->pub.d(),
-                            static_cast<unsigned*>(h->pub_err.p));
+    if (h->peer && h->pend_parts > 0 && h->pend_k == h->k) {
+        // the inner products of the last iteration: this rank's slot goes out now (no next launch to send it), then every
+        // rank's slot is added in rank order
+        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->k, h->pend_buf, h->pend_parts, dots_at(h, h->k),
+                            h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+        h->pend_parts = 0;
+    }
     return PRCG_OK;
 }
 
@@ -2160,8 +2180,9 @@ int prcg_set_iteration(prcg_t* h, int k) {
         if (rc) return rc;
         if ((rc = allreduce(h, h->t1.d(), 1, h->sc))) return rc;      // (collective: nobody is still reading what the pushes overwrite)
         launch_peer_push(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, k), k);
-        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), k, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
+        launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), k, nullptr, 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
         HIPCHK(h, hipStreamSynchronize(h->sc));
+        h->pend_parts = 0;
         return PRCG_OK;
     }
     if (h->gather && is_pipe(h->variant)) {

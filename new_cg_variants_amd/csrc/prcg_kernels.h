@@ -25,11 +25,14 @@ struct alignas(16) Tile { int row_begin, row_end, nnz_begin, nnz_end; };
 // Every rank owns one EXCHANGE BUFFER (fine-grained device memory, mapped into every other rank's process with
 // hipIpc): per parity (iteration & 1) one 64-byte SLOT per rank -- that rank's five partial inner products of the
 // iteration and a 64-bit counter -- and a GHOST AREA that the neighbours' launches fill with the rows this rank needs.
-// A launch writes with system-scope stores straight into the consumers' buffers: the rows its tiles update (as soon
-// as the tile is done), then, from its last workgroup, its slot in EVERY rank's buffer.  The next launch of a rank
-// waits (inside the kernel, after the part of its work that needs neither) until all R slots of its own buffer carry
-// the iteration's counter, adds them in rank order -- the same bits on every rank -- and reads its ghost rows from
-// its own buffer.  No collective, no communication stream, one host call per iteration.
+// Launch k of a rank stores with system scope straight into the consumers' buffers: the rows of iteration k its tiles
+// update, as soon as a tile is done.  Its COMMUNICATION WAVE (wave 0 of workgroup 0; takes no tiles) first adds the
+// partial sums launch k-1 left (kernel boundary: complete, and launch k-1's row stores have arrived), sends them as
+// the rank's slot of iteration k-1 into EVERY rank's buffer, waits until all R slots of its own buffer carry that
+// counter, adds them in rank order -- the same bits on every rank -- and publishes the sums to the other waves, which
+// meanwhile compute the part of the iteration that needs neither (products of their first tiles).  The tiles that
+// read ghost rows come last and read them from the rank's own buffer.  No collective, no communication stream, one
+// host call per iteration.
 //   layout (doubles):  slot(par, q) at (par * R + q) * 8 : [5 sums, pad, pad, counter]
 //                      ghost(par)   at 16 * R + par * 2 * (ghost_cap + 64) : ghost_cap pairs (+ 64 spare: a window page)
 //   counter = epoch | (k + 1): epoch = session number << 32 (stale slots of an earlier session are smaller)
@@ -59,6 +62,7 @@ struct FusedPrev {
     // bytes, each 5 doubles + a 32-bit iteration counter at byte 48, all stored write-through).  Each wave first computes the products of
     // its first tiles, then waits for pub's counter to reach `want`, then applies the deferred updates.
     const double* pub; unsigned want; unsigned* err;
+    unsigned* err_host;  // pinned host word a timed-out wave also sets (prcg_iterate reads it without a synchronisation), or null
     const PeerDev* px;   // non-null: direct peer exchange (above) -- the launch's last workgroup sends this rank's partial sums,
                          // its tiles send the rows the neighbours need, workgroup 0 turns the ranks' slots into `pub`
     int nt_int;       // tiles [nt_int, ntiles) touch ghost columns: they are neither computed nor even requested before
@@ -350,9 +354,14 @@ void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, 
 // neighbours' ghost areas of parity k & 1 and its slot for iteration k (rank 0 contributes dots, the others zeros: the
 // sum in rank order is then exactly dots -- the state just set is the same on every rank)
 void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k);
-// one wave waits (bounded) until all ranks' slots of iteration k have arrived, adds them in rank order into dots_out[0..5)
-// and, if pub, publishes them with counter k; *err = 1 on a timeout
-void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, double* dots_out, double* pub, unsigned* err);
+// one wave: if nparts > 0 first adds this rank's block partials of iteration k (lane l: rows l, l + 64, ...; butterfly --
+// as the communication wave of the next launch would) and sends the slot; then waits (bounded) until all ranks' slots
+// of iteration k have arrived, adds them in rank order into dots_out[0..5) and, if pub, publishes them with counter
+// k; *err = 1 on a timeout
+void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, const double* partials, int nparts, double* dots_out, double* pub,
+                         unsigned* err);
+// marks the window tiles that own rows of the send plan (bit 30 of WTile::geo)
+void launch_flag_send_tiles(hipStream_t st, void* wtiles, const void* tile_send, int ntiles);
 // every copy c: pub[8c .. 8c+5) = dots[0..5), then the copy's counter (byte 48 of the record) = value: what the
 // deferred one-launch iteration waits for
 constexpr int kPubCopies = 64;

@@ -902,11 +902,23 @@ __global__ __launch_bounds__(256) void k_peer_push(const PeerDev* __restrict__ p
         peer_send_slot(px, k, v);
     }
 }
-__global__ __launch_bounds__(64) void k_peer_collect(const PeerDev* __restrict__ px, int k, double* __restrict__ dots_out, double* pub,
-                                                     unsigned* err) {
-    double tot[5];
-    const bool ok = peer_collect(px, k, 1u << 24, tot);
+__global__ __launch_bounds__(64) void k_peer_collect(const PeerDev* __restrict__ px, int k, const double* __restrict__ partials, int nparts,
+                                                     double* __restrict__ dots_out, double* pub, unsigned* err) {
     const int lane = threadIdx.x;
+    double tot[5];
+    if (nparts > 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) tot[q] = 0.0;
+        for (int j = lane; j < nparts; j += 64) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) tot[q] += partials[(size_t)j * kPartialStride + q];
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const double sq = wave_sum(tot[q]); v = lane == q ? sq : v; }
+        peer_send_slot(px, k, v);
+    }
+    const bool ok = peer_collect(px, k, 1u << 24, tot);
     if (!ok && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     double v = 0.0;
 #pragma unroll
@@ -1264,11 +1276,23 @@ void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigne
     hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, st, pub, want, err);
 }
 
+// bit 30 of a window tile's `geo` word: some of its rows go to neighbours (the iteration launch then looks at tile_send)
+__global__ void k_flag_send_tiles(int* __restrict__ wtiles, const int2* __restrict__ tile_send, int ntiles) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        const int2 ts = tile_send[t];
+        int& geo = wtiles[(size_t)t * 24 + 4];
+        geo = ts.y > ts.x ? (geo | (1 << 30)) : (geo & ~(1 << 30));
+    }
+}
+void launch_flag_send_tiles(hipStream_t st, void* wtiles, const void* tile_send, int ntiles) {
+    if (ntiles > 0) hipLaunchKernelGGL(k_flag_send_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, st, static_cast<int*>(wtiles), static_cast<const int2*>(tile_send), ntiles);
+}
 void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k) {
     hipLaunchKernelGGL(k_peer_push, dim3(1), dim3(256), 0, st, px, reinterpret_cast<const double2*>(rs), dots, k);
 }
-void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, double* dots_out, double* pub, unsigned* err) {
-    hipLaunchKernelGGL(k_peer_collect, dim3(1), dim3(64), 0, st, px, k, dots_out, pub, err);
+void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, const double* partials, int nparts, double* dots_out, double* pub,
+                         unsigned* err) {
+    hipLaunchKernelGGL(k_peer_collect, dim3(1), dim3(64), 0, st, px, k, partials, nparts, dots_out, pub, err);
 }
 void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, dots, pub, value);

@@ -56,6 +56,7 @@ struct WDesc {
     int rb, re, lo, hi, np, own, maxlen, vdf, vdc;
     int srcc, srcv, srcr;      // where the tile's (possibly shared) stream images start: window indices, value indices, row pointers
     int img;                   // image id: equal (and non-zero) for tiles that read identical streams, table and shape
+    int send;                  // peer exchange: some of the tile's rows go to neighbours (bit 30 of `geo`, set by prcg_peer_connect)
     int pc[PG];
 };
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ WDesc<PG> read_desc(const int4* __restrict__ wt, int 
     d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
     d.lo = __builtin_amdgcn_readfirstlane(a.z); d.hi = __builtin_amdgcn_readfirstlane(a.w);
     const int geo = __builtin_amdgcn_readfirstlane(b.x);
-    d.np = geo & 255; d.own = geo >> 8;
+    d.np = geo & 255; d.own = (geo >> 8) & 0xffff; d.send = (geo >> 30) & 1;
     d.maxlen = __builtin_amdgcn_readfirstlane(b.y);
     d.vdf = __builtin_amdgcn_readfirstlane(b.z); d.vdc = __builtin_amdgcn_readfirstlane(b.w);
     d.srcc = __builtin_amdgcn_readfirstlane(e.x); d.srcv = __builtin_amdgcn_readfirstlane(e.y);
@@ -245,49 +246,6 @@ __device__ __forceinline__ void win_block_reduce_store(double (&acc)[NQ], double
 #pragma unroll
         for (int w = 1; w < WPB; ++w) v += red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
-    }
-}
-
-// End of a launch with the direct peer exchange: every workgroup leaves its partial sums where the others can see them
-// (agent-scope stores: written through, no L2 write-back of the launch's dirty vectors) and draws a ticket; the LAST
-// workgroup adds all partials in the fixed 256-thread tree and sends this rank's slot of iteration k to every rank.
-// Every wave has waited for its own stores -- the rows it sent to the neighbours included -- before the ticket is drawn,
-// so a neighbour that sees the slot's counter finds the rows in its ghost area.
-template <int WPB>
-__device__ __forceinline__ void peer_tail(double (&acc)[5], double* partials, const PeerDev* px, int k) {
-    __shared__ double red[WPB][5];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const double v = wave_sum(acc[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < 5) {
-        double v = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < WPB; ++w) v += red[w][threadIdx.x];
-        __hip_atomic_store(partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned tk = __hip_atomic_fetch_add(px->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = tk == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double tot[5];
-    sum_prev_partials<5, WPB>(partials, (int)gridDim.x, 0, tot);
-    if (wv == 0) {
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) v = lane == q ? tot[q] : v;
-        peer_send_slot(px, k, v);
-        if (lane == 0) __hip_atomic_store(px->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts at zero
     }
 }
 
@@ -633,7 +591,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         }
     }
     if constexpr (FUSED && !STASH) {
-        if (c.px) peer_send_rows<M>(c.px, tcur, dcur.rb, newp, c.gout, lane);
+        if (c.px && dcur.send) peer_send_rows<M>(c.px, tcur, dcur.rb, newp, c.gout, lane);
     }
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
     return next_same;
@@ -746,8 +704,19 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     // (the first tiles are requested AFTER the prologue: vmcnt is in order, so partial rows requested behind the
     //  images would wait for the images' HBM latency -- measured 1-4 % slower the other way round)
     const int nblk = gridDim.x;
-    const int W = nblk * WPB;
+    int W = nblk * WPB;
     int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
+    bool relay = false;
+    if constexpr (DEF > 0) {
+        if (fz.px) {
+            // direct peer exchange: wave 0 of workgroup 0 is the launch's COMMUNICATION WAVE and takes no tiles -- it sends this
+            // rank's partial sums of the previous launch to every rank, waits for everybody's, and publishes the sums
+            // to the other waves, all while those compute the part of the iteration that needs neither
+            relay = t == 0;
+            W -= 1;
+            t = relay ? ntiles : t - 1;
+        }
+    }
 
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
     WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
@@ -776,35 +745,49 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
 
     if constexpr (DEF > 0) {
-        // ---- phase A: products of the first DEF tiles, sums parked in LDS ----
+        static_assert(DEPTH == 1, "the deferred form keeps one image per wave");
+        // ---- phase A: products of the first DEF tiles, sums parked in LDS (a loop, not unrolled: one copy of the tile
+        //      step here and one in the main loop -- five unrolled copies outgrew the instruction cache) ----
         int n_def = 0;
-        int rbA[DEF], reA[DEF], tA[DEF];   // rows and table index of the deferred tiles (wave-uniform)
-#pragma unroll
-        for (int turn = 0; turn < DEF / DEPTH; ++turn) {
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {
-                if (t < safe && n_def == turn * DEPTH + i) {            // (stops for good at the first tile that must wait)
-                    const WDesc<PG> dcur = d[i];
-                    const int tnext = t + DEPTH * W;
-                    const bool have_next = tnext < safe;
-                    d[i] = dn;
-                    pend[i] = tnext < ntiles && !have_next;
-                    rbA[turn * DEPTH + i] = dcur.rb; reA[turn * DEPTH + i] = dcur.re; tA[turn * DEPTH + i] = t;
-                    same[i] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i],
-                                                                         s_stash[wv] + (turn * DEPTH + i) * M * 64);
-                    if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
-                    t += W;
-                    ++n_def;
-                }
-            }
+        const int t_first = t;
+#pragma unroll 1
+        for (int it = 0; it < DEF; ++it) {
+            if (t >= safe) break;                                   // (stops for good at the first tile that must wait)
+            const WDesc<PG> dcur = d[0];
+            const int tnext = t + W;
+            const bool have_next = tnext < safe;
+            d[0] = dn;
+            pend[0] = tnext < ntiles && !have_next;
+            same[0] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[0], dcur, have_next, d[0], acc, cf, rc, same[0],
+                                                                 s_stash[wv] + it * M * 64);
+            if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
+            t += W;
+            ++n_def;
         }
-        // ---- wait for the reduced inner products of the previous iteration ----
-        if (fz.px && blockIdx.x == 0 && wv == 0) {
-            // direct peer exchange: ONE wave of the launch turns the ranks' slots (this rank's exchange buffer) into the
-            // publication record everybody else polls: all R counters seen -> sums added in rank order -> published
+        // ---- the communication wave of the peer exchange ----
+        if (relay) {
+            const PeerDev* px = fz.px;
             double tot[5];
-            const bool ok = peer_collect(fz.px, (int)fz.want, PRCG_WAIT_SPINS, tot);
-            if (!ok && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (fz.nprev > 0) {
+                // this rank's partial sums of the previous launch (one row per workgroup, complete: kernel boundary): lane l adds
+                // rows l, l + 64, ...; xor butterfly -- then the rank's slot goes into EVERY rank's exchange buffer
+#pragma unroll
+                for (int q = 0; q < 5; ++q) tot[q] = 0.0;
+                for (int j = lane; j < fz.nprev; j += 64) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) tot[q] += fz.prev_partials[(size_t)j * kPartialStride + q];
+                }
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) { const double sq = wave_sum(tot[q]); v = lane == q ? sq : v; }
+                peer_send_slot(px, (int)fz.want, v);
+            }
+            // all R slots of iteration `want` in this rank's buffer -> sums in rank order -> the publication record
+            const bool ok = peer_collect(px, (int)fz.want, PRCG_WAIT_SPINS, tot);
+            if (!ok && lane == 0) {
+                __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (fz.err_host) __hip_atomic_store(fz.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             double* mine = const_cast<double*>(fz.pub) + (size_t)lane * 8;
 #pragma unroll
             for (int q = 0; q < 5; ++q) __hip_atomic_store(mine + q, tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,18 +797,23 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 #pragma unroll
                 for (int q = 0; q < 5; ++q) if (lane == q) fz.dots_prev_out[q] = tot[q];
             }
-        }
-        {
+            cf = predict(tot, (write_mask >> 2) & 1);
+            if (lane == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+        } else {
+            // ---- wait for the reduced inner products of the previous iteration ----
             // this wave's copy of the record (the copies spread the pollers over the L2 channels)
             const double* rec = fz.pub + (size_t)((blockIdx.x * WPB + wv) & (kPubCopies - 1)) * 8;
             const unsigned* cnt = reinterpret_cast<const unsigned*>(rec + 6);
             unsigned spins = 0;
-            bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;   // sticky: never wait twice
+            bool timed_out = __hip_atomic_load(fz.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // sticky: never wait twice
             while (!timed_out && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fz.want) < 0) {
                 __builtin_amdgcn_s_sleep(32);                                 // ~1 us between polls
                 if (++spins > PRCG_WAIT_SPINS) timed_out = true;             // ~10 s: a stalled peer, not a slow one
             }
-            if (timed_out && lane == 0) __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (timed_out && lane == 0) {
+                __hip_atomic_store(fz.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fz.err_host) __hip_atomic_store(fz.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             // the payload was stored, and had left its CU, before the counter was: keep the payload loads behind the
             // counter load (compiler: wavefront-scope acquire emits no cache operation; hardware: vmem returns in order)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -834,65 +822,58 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
 #pragma unroll
             for (int q = 0; q < 4; ++q) dp[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cf = predict(dp, (write_mask >> 2) & 1);
-            if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+            if (!fz.px && blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
         }
-        // the ring continues with image (n_def mod DEPTH): bring that image to position 0
-        if constexpr (DEPTH == 2) {
-            if (n_def & 1) {
-                const WRegs<win_nw(NV, EPI), M, PG, CW, VD> r0 = R[0]; R[0] = R[1]; R[1] = r0;
-                const WDesc<PG> d0 = d[0]; d[0] = d[1]; d[1] = d0;
-                const bool p0 = pend[0]; pend[0] = pend[1]; pend[1] = p0;
-                const bool s0 = same[0]; same[0] = same[1]; same[1] = s0;
-            }
-        }
-        static_assert(DEPTH <= 2, "ring rotation after the deferred phase is written for one or two images");
         // the postponed requests.  Consumer side of the release / acquire hand-off, paid only by the waves that read
         // ghost rows (an agent-scope acquire invalidates the CU's L1: ~1.7 us each, serialised per CU): what the wave
         // loads from here on is what the publisher wrote before publishing
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            if (pend[i]) {
-                if (!acquired) { if (fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
-                same[i] = same_image<PG>(rc, d[i]);
-                issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], same[i], c.G, c.n_own);
-                pend[i] = false;
-            }
+        if (pend[0]) {
+            if (!acquired) { if (fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+            same[0] = same_image<PG>(rc, d[0]);
+            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own);
+            pend[0] = false;
+        }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
         //      at once (one memory round trip per chunk, not per tile), then the chunk is updated ----
-        constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : DEF;
+        constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : (DEF > 4 ? 4 : DEF);
+#pragma unroll 1
+        for (int c0 = 0; c0 < n_def; c0 += CH) {
+            FusedRowIn q[CH][M];
+            double2 io[CH][M];
+            int rbB[CH], reB[CH], sendB[CH];                           // rows of the chunk's tiles (wave-uniform, re-read: scalar loads)
 #pragma unroll
-        for (int c0 = 0; c0 < DEF; c0 += CH) {
-            if (c0 < n_def) {                                              // wave-uniform
-                FusedRowIn q[CH][M];
-                double2 io[CH][M];
+            for (int i = 0; i < CH; ++i) {
+                rbB[i] = reB[i] = sendB[i] = 0;
+                if (c0 + i < n_def) {
+                    const int ti = t_first + (c0 + i) * W;
+                    const int4 a4 = wt[ti * 6 + 0];
+                    const int geo = wt[ti * 6 + 1].x;
+                    rbB[i] = __builtin_amdgcn_readfirstlane(a4.x); reB[i] = __builtin_amdgcn_readfirstlane(a4.y);
+                    sendB[i] = (__builtin_amdgcn_readfirstlane(geo) >> 30) & 1;
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if (c0 + i < n_def) {
-#pragma unroll
-                        for (int j = 0; j < M; ++j) {
-                            const int row = rbA[c0 + i] + j * 64 + lane;
-                            const int rr = row < reA[c0 + i] ? row : rbA[c0 + i];
-                            q[i][j].xp = c.fr.XP[rr];
-                            io[i][j] = c.X[rr];
-                            if constexpr (epi_prec(EPI)) { q[i][j].rs = c.fr.RS[rr]; q[i][j].d = c.fr.D[rr]; }
-                            if constexpr (!epi_recompute(EPI)) { q[i][j].w = c.fr.W[rr]; if constexpr (epi_prec(EPI)) q[i][j].wt = c.fr.WT[rr]; }
-                        }
+                    for (int j = 0; j < M; ++j) {
+                        const int row = rbB[i] + j * 64 + lane;
+                        const int rr = row < reB[i] ? row : rbB[i];
+                        q[i][j].xp = c.fr.XP[rr];
+                        io[i][j] = c.X[rr];
+                        if constexpr (epi_prec(EPI)) { q[i][j].rs = c.fr.RS[rr]; q[i][j].d = c.fr.D[rr]; }
+                        if constexpr (!epi_recompute(EPI)) { q[i][j].w = c.fr.W[rr]; if constexpr (epi_prec(EPI)) q[i][j].wt = c.fr.WT[rr]; }
                     }
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if (c0 + i < n_def) {
-                        double2 newp[M];
+            for (int i = 0; i < CH; ++i) {
+                if (c0 + i < n_def) {
+                    double2 newp[M];
 #pragma unroll
-                        for (int j = 0; j < M; ++j) {
-                            const int row = rbA[c0 + i] + j * 64 + lane;
-                            newp[j] = make_double2(0.0, 0.0);
-                            if (row < reA[c0 + i])
-                                newp[j] = fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, s_stash[wv][((c0 + i) * M + j) * 64 + lane],
-                                                                                              q[i][j], io[i][j], c.fr, cf, acc);
-                        }
-                        if (fz.px) peer_send_rows<M>(fz.px, tA[c0 + i], rbA[c0 + i], newp, c.gout, lane);
+                    for (int j = 0; j < M; ++j) {
+                        const int row = rbB[i] + j * 64 + lane;
+                        newp[j] = make_double2(0.0, 0.0);
+                        if (row < reB[i])
+                            newp[j] = fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, s_stash[wv][((c0 + i) * M + j) * 64 + lane],
+                                                                                          q[i][j], io[i][j], c.fr, cf, acc);
                     }
+                    if (fz.px && sendB[i]) peer_send_rows<M>(fz.px, t_first + (c0 + i) * W, rbB[i], newp, c.gout, lane);
                 }
             }
         }
@@ -916,13 +897,6 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         }
     }
 
-    if constexpr (FUSED && DEF > 0) {
-        if (fz.px) {
-            if constexpr (!epi_prec(EPI)) acc[4] = acc[3];
-            peer_tail<WPB>(acc, partials, fz.px, (int)fz.want + 1);
-            return;
-        }
-    }
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
@@ -948,7 +922,10 @@ constexpr int waves_per_block(int nv, int pg, int cw, bool vd) {
     return 4 * lds_bytes_per_wave(nv, pg, cw, vd) <= 80 * 1024 ? 4 : 2;
 #endif
 }
-constexpr int kWPBDefer = 4;   // ... of the deferred form: one wave on EACH SIMD of the CU, see defer_grid_per_cu
+// ... of the deferred form: one wave on EACH SIMD of the CU (see defer_grid_per_cu) for the 64-row geometries; the 128-row
+// ones (12 KB of window per wave + the stashed sums) take two-wave workgroups: a four-wave one needs 86 KB of LDS and would
+// be alone on its CU
+constexpr int wpb_defer(int m) { return m == 1 ? 4 : 2; }
 
 // Workgroups per CU.  Upper bounds: what is truly co-resident (160 KiB of LDS per CU; the occupancy API
 // knows the register limit) -- a persistent strided grid with queued workgroups grows a serial tail (S3
@@ -986,7 +963,7 @@ int win_grid(K kernel, int ntiles, int per_cu_override, int tuned, int wpb) {
 // 160 KiB of LDS per CU.  The bound below keeps room for one such workgroup on every CU
 // (2-wave workgroups do not: two of them can land on the same SIMD pair and fill its register file --
 // seen as a stalled reduction with the 250-register 128-row geometry).
-int defer_grid_per_cu(const void* kernel, bool guest) {
+int defer_grid_per_cu(const void* kernel, bool guest, int wpb) {
     // (direct peer exchange: nothing else has to run beside the launch -- only its own residency counts)
     const int kGuestVgprs = guest ? 144 : 0, kGuestLds = guest ? 24 * 1024 : 0;
     hipFuncAttributes fa;
@@ -994,8 +971,8 @@ int defer_grid_per_cu(const void* kernel, bool guest) {
     const int vg = ((fa.numRegs + 7) / 8) * 8;
     const int lds = (int)fa.sharedSizeBytes;
     int best = 1;
-    for (int b = 2; b <= 4; ++b) {
-        const bool regs_ok = b * vg + kGuestVgprs <= 512;
+    for (int b = 2; b <= 16 / wpb; ++b) {
+        const bool regs_ok = ((b * wpb + 3) / 4) * vg + kGuestVgprs <= 512;       // waves per SIMD x registers
         const bool lds_ok = b * lds + kGuestLds <= 160 * 1024;
         if (regs_ok && lds_ok) best = b;
     }
@@ -1029,8 +1006,8 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu, hipEvent_t done)
 {
-    constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 4) : 0;
-    constexpr int WPB = DEFER ? kWPBDefer : waves_per_block(win_nw(NV, EPI), PG, CW, vd);
+    constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 2) : 0;     // (128-row tiles: two stashed tiles = 16 KB of LDS per workgroup)
+    constexpr int WPB = DEFER ? wpb_defer(M) : waves_per_block(win_nw(NV, EPI), PG, CW, vd);
     auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][2][16] = {};
@@ -1038,7 +1015,7 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][fz.px ? 1 : 0][dev & 15];
     int tuned = (vd ? 16 : 8) / WPB;        // resident waves per CU that stream best (see win_grid)
-    if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k), fz.px == nullptr);
+    if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k), fz.px == nullptr, WPB);
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
     int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
     const int need = (ntiles + WPB - 1) / WPB;
@@ -1076,7 +1053,7 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
 }  // namespace
 
 int win_fused_waves_per_block(int geom, bool value_dict, bool deferred) {
-    if (deferred) return kWPBDefer;
+    if (deferred) return wpb_defer(geom < 2 ? 1 : 2);
     switch (geom) {
     case 0: return waves_per_block(2, 2, 8, value_dict);
     case 1: return waves_per_block(2, 4, 8, value_dict);

@@ -558,11 +558,12 @@ def test_ranks_in_threads_peer_exchange(workload, nranks, variant, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workload,nranks', [('s2', 4), ('s3', 2)])
+@pytest.mark.parametrize('workload,nranks', [('s2', 2), ('s1', 3), ('s3', 2)])
 def test_full_size_row_blocks_in_threads_peer_exchange(workload, nranks):
     """BASELINE.json's multi-GPU configurations at full size through the direct peer exchange, ranks in threads on ONE
-    GPU: S2 (config 4: 7-point Laplacian 216^3 in 4 blocks of whole planes, halo = one 216^2 plane per side -- the
-    one-launch schedule now serves halos of any size) and S3 (n = 1e7 in 2 blocks)."""
+    GPU: S2 (config 4: 7-point Laplacian 216^3 in 2 blocks of whole planes, halo = one 216^2 plane = 746 KB of pairs
+    -- the one-launch schedule serves halos of any size) and S3 (n = 1e7 in 2 blocks).  Two ranks: the persistent
+    launches of ALL ranks must be resident on the one GPU at once (250 VGPRs each for S2's geometry)."""
     from new_cg_variants_amd import _lib as L
     from new_cg_variants_amd import problems
     from new_cg_variants_amd.device import DeviceCSR
@@ -573,6 +574,8 @@ def test_full_size_row_blocks_in_threads_peer_exchange(workload, nranks):
     offsets = None
     if workload == 's2':
         offsets = np.arange(nranks + 1, dtype=np.int64) * (216 // nranks) * 216 * 216
+    if workload == 's1':       # whole grid lines per rank: halo = one line of 1000 rows per side
+        offsets = np.array([0, 333, 667, 1000], dtype=np.int64) * 1000
     one = DeviceCSR(A)
     one.begin(L.PIPE_PR, b, x0, iters + 1, hist_mask=1)
     one.iterate(iters)
