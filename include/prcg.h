@@ -136,6 +136,16 @@ int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const
  * waits ~10 s for another sets an error that prcg_sync and the next prcg_iterate report. */
 int prcg_peer_setup(prcg_t* h, int64_t max_ghost_any_rank, void* ipc_handle64, void** local_ptr);
 int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_process_ptrs, const int64_t* send_dst_off);
+/* Rank and world size WITHOUT a communicator (instead of prcg_comm_init): enough for the peer exchange's own plumbing
+ * -- prcg_peer_setup / prcg_peer_connect / prcg_peer_selftest -- not for solver sessions on a block with ghost columns
+ * (their set-up products and the recorders use the communicator).  Lets two PROCESSES share one GPU in the tests, which
+ * RCCL refuses. */
+int prcg_world_init(prcg_t* h, int rank, int nranks);
+/* One round of the exchange primitives, outside any session (tests): send rows2n (this rank's n (r,s) pairs; the rows of
+ * the send plan go to the neighbours' ghost areas of parity k & 1) and slot5 as this rank's slot of round k, wait for
+ * every rank's slot, return their sum in rank order (sums5) and this rank's ghost area of that parity (ghost2g, 2 doubles
+ * per ghost row, nullable).  Every rank calls it with the same k (increasing from call to call). */
+int prcg_peer_selftest(prcg_t* h, int k, const double* rows2n, const double* slot5, double* sums5, double* ghost2g);
 
 /* ---- operator -------------------------------------------------------------------
  * The rank's row block in CSR (what `A` is in figure_gen.py:350 / scaling_tests.py:51),

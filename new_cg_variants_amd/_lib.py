@@ -56,6 +56,8 @@ _SIGNATURES = {
     'prcg_set_halo': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     'prcg_peer_setup': (C.c_int, [_P, C.c_int64, _P, C.POINTER(_P)]),
     'prcg_peer_connect': (C.c_int, [_P, _P, _P, _P]),
+    'prcg_world_init': (C.c_int, [_P, C.c_int, C.c_int]),
+    'prcg_peer_selftest': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     'prcg_spmv': (C.c_int, [_P, _P, _P, C.c_int, _dp]),
     'prcg_spmv_ext': (C.c_int, [_P, _P, _P]),
     'prcg_spmm2': (C.c_int, [_P, _P, _P, C.c_int, _dp]),

@@ -193,6 +193,7 @@ __device__ __forceinline__ Coefs predict(const double* __restrict__ dp, int meur
 // Extra per-row operands of the one-launch iteration (see FusedState): kernel arguments
 struct FusedRowPtrs {
     double2* XP; double2* IN_NEW; double2* RS; const double* D; double* W; double* WT;
+    bool stream;      // streaming stores for the row results (see store_pair)
 };
 // the row's operands as loaded (ahead of time where the kernel can)
 struct FusedRowIn { double2 xp, rs; double d, w, wt; };
@@ -201,6 +202,25 @@ struct FusedRowIn { double2 xp, rs; double d, w, wt; };
 //   unpreconditioned (pipe_pr_cg.py:61-74): in = (r,s);  w_prev = A r (recomputed) or the stored recurrence
 //   Jacobi           (pipe_pr_cg.py:169-186): in = (r~,s~); w~ = d w and u~ = d u as preconditioner(w), preconditioner(u)
 // Same expressions, same order, no FMA as k_pipe_update (the two-kernel schedule) -- vectors agree bit for bit.
+// The iteration's row results are written once and not read again before the next launch.  When the vectors are far
+// larger than the caches (S3, S2: 640 MB of pairs per launch against 256 MB of Infinity Cache) streaming (nontemporal)
+// stores keep them from displacing the stream images and window pages: S3 7.7 -> 8.8 k it/s, the same 2-read 2-write
+// mix in tools/membench.hip 6.0 -> 6.7 TB/s.  When they fit (S1, one eighth of S3) the next launch finds them in the
+// cache and plain stores win (S1 -8 % with streaming stores): `stream` is chosen per operator by the engine.
+__device__ __forceinline__ void store_pair(double2* p, const double2& v, bool stream) {
+    if (stream) {                                                           // wave-uniform
+        typedef double d2v_t __attribute__((ext_vector_type(2)));
+        d2v_t w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<d2v_t*>(p));
+    } else {
+        *p = v;
+    }
+}
+
+__device__ __forceinline__ void store_one(double* p, double v, bool stream) {
+    if (stream) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // Returns the row's new SpMM input pair (what went to IN_NEW): the peer exchange sends it on to the neighbours.
 template <bool PREC, bool RECOMP>
 __device__ __forceinline__ double2 fused_row_update(int row, const double2& sum, const FusedRowIn& q, const double2& in_old,
@@ -214,8 +234,8 @@ __device__ __forceinline__ double2 fused_row_update(int row, const double2& sum,
         const double wn = wprev - cf.al * us;                  // w -= a u
         const double pn = rn + cf.bt * q.xp.y;                 // p = r + b p
         const double sn = wn + cf.bt * in_old.y;               // s = w + b s
-        f.XP[row] = make_double2(xn, pn);
-        f.IN_NEW[row] = make_double2(rn, sn);
+        store_pair(f.XP + row, make_double2(xn, pn), f.stream);
+        store_pair(f.IN_NEW + row, make_double2(rn, sn), f.stream);
         if constexpr (!RECOMP) f.W[row] = wn;
         acc[0] += pn * sn; acc[1] += rn * sn; acc[2] += sn * sn; acc[3] += rn * rn;
         return make_double2(rn, sn);
@@ -229,9 +249,9 @@ __device__ __forceinline__ double2 fused_row_update(int row, const double2& sum,
         const double pn = rtn + cf.bt * q.xp.y;                // p = r~ + b p
         const double sn = wn + cf.bt * q.rs.y;                 // s = w + b s
         const double stn = wtn + cf.bt * in_old.y;             // s~ = w~ + b s~
-        f.XP[row] = make_double2(xn, pn);
-        f.RS[row] = make_double2(rn, sn);
-        f.IN_NEW[row] = make_double2(rtn, stn);
+        store_pair(f.XP + row, make_double2(xn, pn), f.stream);
+        store_pair(f.RS + row, make_double2(rn, sn), f.stream);
+        store_pair(f.IN_NEW + row, make_double2(rtn, stn), f.stream);
         if constexpr (!RECOMP) { f.W[row] = wn; f.WT[row] = wtn; }
         acc[0] += pn * sn; acc[1] += rn * stn; acc[2] += stn * sn; acc[3] += rtn * rn; acc[4] += rn * rn;
         return make_double2(rtn, stn);

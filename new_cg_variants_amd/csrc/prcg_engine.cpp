@@ -238,6 +238,9 @@ struct prcg_handle {
     bool multi() const { return comm != nullptr; }
 
     // ---- direct peer exchange over xGMI (PeerDev, prcg_kernels.h): the multi-rank one-launch schedule without a collective ----
+    int stream_stores = 0;               // the one-launch iteration writes its row results with streaming stores: chosen per operator in
+                                         // prcg_set_csr (vectors far larger than the 256 MB Infinity Cache), PRCG_STREAM_STORES=0|1 overrides
+    int stream_override = -1;
     int want_fused_comm_rccl = 0;        // PRCG_FUSED_COMM=1: one launch per iteration with the RCCL all-gather chain on the communication
                                          // stream (in-kernel wait for kernels of another stream: validated with one rank only -- opt-in)
     bool want_peer = true;               // PRCG_PEER=0: never use the peer exchange even when connected
@@ -707,6 +710,7 @@ int iterate_pipe_fused(prcg_t* h, int k) {
     f.wt = (!rec && h->prec) ? h->wt.d() : nullptr;
     f.dots_prev = dots_at(h, k - 1); f.coef_out = coef_at(h, k); f.partials = part_out;
     f.meurant = meurant(h->variant); f.recompute_w = rec;
+    f.stream_stores = h->stream_stores;
     f.prev = prev;
     const int grid = eng_fused(h, h->sc, f);
     LAUNCHCHK(h, grid);
@@ -743,6 +747,7 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     f.wt = (!rec && h->prec) ? h->wt.d() : nullptr;
     f.dots_prev = dots_at(h, k - 1); f.coef_out = coef_at(h, k); f.partials = part_out;
     f.meurant = meurant(h->variant); f.recompute_w = rec;
+    f.stream_stores = h->stream_stores;
     f.prev = FusedPrev{};
     f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
     f.deferred = 1;
@@ -936,7 +941,7 @@ int iterate_pr_fused(prcg_t* h, int k) {
     SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.p_old, 1});
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_win_pr_one(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f,
-                                       meurant(h->variant), part_out, coef_at(h, k), h->win_per_cu);
+                                       (meurant(h->variant) ? 1 : 0) | (h->stream_stores ? 2 : 0), part_out, coef_at(h, k), h->win_per_cu);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out; h->last_grid = grid;
@@ -1129,6 +1134,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN") h->want_win = v != 0;
     else if (k == "PRCG_FUSED_COMM") { h->want_fused_comm = v != 0; h->want_fused_comm_rccl = v != 0; }
     else if (k == "PRCG_PEER") h->want_peer = v != 0;
+    else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
     else if (k == "PRCG_WIN_GRID_PER_CU") h->win_per_cu = (v >= 1 && v <= 32) ? (int)v : 0;
@@ -1141,7 +1147,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1579,6 +1585,9 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     }
     h->n = n_rows; h->g = n_ghost; h->nnz = nnz;
     h->nt_int = (int)t0.size(); h->nt_bnd = (int)t1.size();
+    // what one launch moves -- the operator as streamed plus 64 bytes of vectors per row: beyond the Infinity Cache
+    // (256 MB) the next launch finds none of its row results cached anyway (S3 +23 %, s4b +4 %, S2 +2 %; S1 and one
+    // eighth of S3 fit and lose 4-8 % with streaming stores)
     HIPCHK(h, h->tmp_ext.alloc((size_t)2 * (n_rows + n_ghost + kGatherPad) * sizeof(double)));
     HIPCHK(h, h->t1.alloc((size_t)2 * n_rows * sizeof(double)));
     HIPCHK(h, h->partA.alloc((size_t)8192 * kPartialStride * sizeof(double)));
@@ -1587,6 +1596,8 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     h->have_csr = true;
     h->have_halo = false;
     h->gather_planned = false;
+    h->stream_stores = h->stream_override >= 0 ? h->stream_override
+                                               : ((int64_t)64 * n_rows + prcg_operator_bytes(h) > (int64_t)256 << 20);
     return PRCG_OK;
 }
 
@@ -1743,6 +1754,45 @@ int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_proc
     // (a non-window operator keeps the two-kernel schedule: the exchange is the iteration launch's own, and only the
     //  window kernels have it)
     h->peer_ok = h->win;
+    return PRCG_OK;
+}
+
+int prcg_world_init(prcg_t* h, int rank, int nranks) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, nranks >= 1 && rank >= 0 && rank < nranks, "prcg_world_init: bad rank %d of %d", rank, nranks);
+    CHECK(h, h->comm == nullptr, "prcg_world_init: the handle already has a communicator");
+    h->rank = rank;
+    h->nranks = nranks;
+    return PRCG_OK;
+}
+
+int prcg_peer_selftest(prcg_t* h, int k, const double* rows2n, const double* slot5, double* sums5, double* ghost2g) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, h->peer_ok, "prcg_peer_selftest: call prcg_peer_setup / prcg_peer_connect first");
+    CHECK(h, k >= 0 && rows2n && slot5 && sums5, "prcg_peer_selftest: bad argument");
+    HIPCHK(h, hipSetDevice(h->dev));
+    const PeerDev* px = static_cast<const PeerDev*>(h->peer_dev.p);
+    DevBuf rows, slot, out, err;
+    HIPCHK(h, rows.alloc((size_t)2 * (h->n + 1) * sizeof(double)));
+    HIPCHK(h, slot.alloc(64));
+    HIPCHK(h, out.alloc(64));
+    HIPCHK(h, err.alloc(64));
+    HIPCHK(h, hipMemcpy(rows.p, rows2n, (size_t)2 * h->n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(slot.p, slot5, 5 * sizeof(double), hipMemcpyHostToDevice));
+    if (h->peer_host.epoch == 0) {
+        h->peer_host.epoch = (unsigned long long)(++h->peer_epoch) << 32;
+        HIPCHK(h, hipMemcpy(h->peer_dev.p, &h->peer_host, sizeof(PeerDev), hipMemcpyHostToDevice));
+    }
+    launch_peer_push(h->sc, px, rows.d(), slot.d(), k, 1);
+    launch_peer_collect(h->sc, px, k, nullptr, 0, out.d(), nullptr, static_cast<unsigned*>(err.p));
+    HIPCHK(h, hipStreamSynchronize(h->sc));
+    unsigned e = 0;
+    HIPCHK(h, hipMemcpy(&e, err.p, sizeof e, hipMemcpyDeviceToHost));
+    if (e) return fail(h, PRCG_ERCCL, "prcg_peer_selftest: the other ranks' slots of round %d did not arrive", k);
+    HIPCHK(h, hipMemcpy(sums5, out.p, 5 * sizeof(double), hipMemcpyDeviceToHost));
+    if (ghost2g && h->g > 0)
+        HIPCHK(h, hipMemcpy(ghost2g, static_cast<const double*>(h->xbuf) + peer_ghost_off(h->nranks, h->ghost_cap, k & 1),
+                            (size_t)2 * h->g * sizeof(double), hipMemcpyDeviceToHost));
     return PRCG_OK;
 }
 
@@ -1947,7 +1997,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
             HIPCHK(h, hipMemcpyAsync(h->peer_dev.p, &h->peer_host, sizeof(PeerDev), hipMemcpyHostToDevice, sc));
             HIPCHK(h, hipStreamSynchronize(sc));                       // (peer_host must not change under the copy)
             *h->err_host = 0u;
-            launch_peer_push(sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, 0), 0);
+            launch_peer_push(sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, 0), 0, h->rank == 0);
             launch_peer_collect(sc, static_cast<const PeerDev*>(h->peer_dev.p), 0, nullptr, 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
         } else if (h->fused_comm) {
             // LOCAL part.  Can a kernel of the communication stream run while a kernel of the compute stream waits for
@@ -2179,7 +2229,7 @@ int prcg_set_iteration(prcg_t* h, int k) {
         int rc = prcg_sync(h);
         if (rc) return rc;
         if ((rc = allreduce(h, h->t1.d(), 1, h->sc))) return rc;      // (collective: nobody is still reading what the pushes overwrite)
-        launch_peer_push(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, k), k);
+        launch_peer_push(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), h->rs_cur, dots_at(h, k), k, h->rank == 0);
         launch_peer_collect(h->sc, static_cast<const PeerDev*>(h->peer_dev.p), k, nullptr, 0, nullptr, h->pub.d(), static_cast<unsigned*>(h->pub_err.p));
         HIPCHK(h, hipStreamSynchronize(h->sc));
         h->pend_parts = 0;

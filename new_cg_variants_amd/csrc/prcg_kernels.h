@@ -90,6 +90,7 @@ struct FusedState {
     const double* dots_prev; double* coef_out; double* partials;
     int meurant, recompute_w;
     FusedPrev prev;
+    int stream_stores; // 1: the row results go out with streaming (nontemporal) stores: vectors far larger than the caches
     int deferred;     // 1: the launch waits in-kernel for prev.pub (communicator sessions, interior tiles)
     hipEvent_t done;  // non-null: the launch's own completion signal is this event (hipExtLaunchKernel): the
                       // communication stream waits for it, and NO marker packet sits between two launches
@@ -351,9 +352,10 @@ void launch_gather_unpack(hipStream_t st, const double* gbuf, int slot_doubles, 
                           double* rs_ghost, const int* ghost_src, int nghost, double* pub = nullptr, unsigned pub_value = 0,
                           hipEvent_t done = nullptr);
 // peer exchange outside the iteration launches (session start, teacher forcing): send this rank's rows of `rs` to the
-// neighbours' ghost areas of parity k & 1 and its slot for iteration k (rank 0 contributes dots, the others zeros: the
-// sum in rank order is then exactly dots -- the state just set is the same on every rank)
-void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k);
+// neighbours' ghost areas of parity k & 1 and its slot for iteration k (contribute: the slot carries dots, else zeros --
+// the engine lets rank 0 alone contribute the GLOBAL inner products of the state just set: the sum in rank order is
+// then exactly that)
+void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k, int contribute);
 // one wave: if nparts > 0 first adds this rank's block partials of iteration k (lane l: rows l, l + 64, ...; butterfly --
 // as the communication wave of the next launch would) and sends the slot; then waits (bounded) until all ranks' slots
 // of iteration k have arrived, adds them in rank order into dots_out[0..5) and, if pub, publishes them with counter

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tiles(
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
     const FusedRowPtrs fr{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st), reinterpret_cast<double2*>(fz.rs),
-                          ep_d, fz.w, fz.wt};
+                          ep_d, fz.w, fz.wt, (write_mask & 8) != 0};
     if constexpr (epi_fused(EPI)) {
         // ep_r = the reduced inner products of the previous iteration; bit 2 of write_mask =
         // Meurant's prediction; aux = where alpha, beta, nu_pred of this iteration are kept
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kFinalThreads) void k_gather_unpack(
 
 // ---- direct peer exchange outside the iteration launches (PeerDev, prcg_kernels.h) ----
 __global__ __launch_bounds__(256) void k_peer_push(const PeerDev* __restrict__ px, const double2* __restrict__ rs,
-                                                   const double* __restrict__ dots, int k) {
+                                                   const double* __restrict__ dots, int k, int contribute) {
     const int R = px->nranks;
     const long long gout = peer_ghost_off(R, px->ghost_cap, k & 1);
     for (int e = threadIdx.x; e < px->n_send; e += 256) {
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void k_peer_push(const PeerDev* __restrict__ p
     __syncthreads();
     if (threadIdx.x < 64) {
         // rank 0 contributes the (global) inner products of state k, the others zeros: added in rank order that is dots
-        const double v = (threadIdx.x < 5 && px->rank == 0) ? dots[threadIdx.x] : 0.0;
+        const double v = (threadIdx.x < 5 && contribute) ? dots[threadIdx.x] : 0.0;
         peer_send_slot(px, k, v);
     }
 }
@@ -1115,7 +1115,7 @@ int launch_pipe_fused(hipStream_t st, const CsrDev& A, const Tile* tiles, int nt
     if (ntiles <= 0) return 0;
     FusedPrev fz = f.prev;
     fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
-    const int mask = 3 | (f.meurant ? 4 : 0);
+    const int mask = 3 | (f.meurant ? 4 : 0) | (f.stream_stores ? 8 : 0);
     if (f.dinv) {
         if (f.recompute_w)
             return launch_tiles_steps<2, kEpiPipeFusedJ>(steps, st, A, tiles, ntiles, f.in_old, f.xp, mask, f.dots_prev, f.dinv,
@@ -1287,8 +1287,8 @@ __global__ void k_flag_send_tiles(int* __restrict__ wtiles, const int2* __restri
 void launch_flag_send_tiles(hipStream_t st, void* wtiles, const void* tile_send, int ntiles) {
     if (ntiles > 0) hipLaunchKernelGGL(k_flag_send_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, st, static_cast<int*>(wtiles), static_cast<const int2*>(tile_send), ntiles);
 }
-void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k) {
-    hipLaunchKernelGGL(k_peer_push, dim3(1), dim3(256), 0, st, px, reinterpret_cast<const double2*>(rs), dots, k);
+void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const double* dots, int k, int contribute) {
+    hipLaunchKernelGGL(k_peer_push, dim3(1), dim3(256), 0, st, px, reinterpret_cast<const double2*>(rs), dots, k, contribute);
 }
 void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, const double* partials, int nparts, double* dots_out, double* pub,
                          unsigned* err) {

@@ -42,6 +42,9 @@ namespace {
 #ifndef PRCG_WIN_UNROLL
 #define PRCG_WIN_UNROLL 8
 #endif
+#ifndef PRCG_NT_LOADS
+#define PRCG_NT_LOADS 0
+#endif
 #ifndef PRCG_WIN_UNIFORM_ROWS
 #define PRCG_WIN_UNIFORM_ROWS 1  // 0: no scalar-value / scalar-offset row walk (A/B builds)
 #endif
@@ -218,7 +221,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             if constexpr (EPI == kEpiGVWJ) { R.dd[j] = pr.d[rr]; R.ww[j] = pr.rt[rr]; R.wwt[j] = pr.st[rr]; }
         }
         if constexpr (FUSED) {
+#if PRCG_NT_LOADS
+            R.xp[j] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(fr.XP) + rr);       // read once per launch
+#else
             R.xp[j] = reinterpret_cast<const d2_t*>(fr.XP)[rr];
+#endif
             if constexpr (epi_prec(EPI)) {
                 R.rsx[j] = reinterpret_cast<const d2_t*>(fr.RS)[rr];
                 R.dd[j] = fr.D[rr];
@@ -531,18 +538,19 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                 const double xn = fin[j].xp.x + cf.al * zr[j].z;            // x += a p_old
                 const double zn = zr[j].x - cf.al * zr[j].y;                // r~ -= a s~   (r -= a s without Jacobi)
                 const double pn = zn + cf.bt * zr[j].z;                     // p = r~ + b p_old
-                c.pr.x[row] = xn;
-                c.pr.z_new[row] = zn;
-                c.pr.p_new[row] = pn;
+                const bool st = c.fr.stream;
+                store_one(c.pr.x + row, xn, st);
+                store_one(c.pr.z_new + row, zn, st);
+                store_one(c.pr.p_new + row, pn, st);
                 if constexpr (EPI == kEpiPROneJ) {
                     const double rn = fin[j].rs.x - cf.al * fin[j].rs.y;    // r -= a s
                     const double stn = fin[j].d * sum;                      // s~ = M^-1 s
-                    c.pr.r[row] = rn;
-                    c.pr.s[row] = sum;
-                    c.pr.zs_new[row] = stn;
+                    store_one(c.pr.r + row, rn, st);
+                    store_one(c.pr.s + row, sum, st);
+                    store_one(c.pr.zs_new + row, stn, st);
                     acc[0] += pn * sum; acc[1] += rn * stn; acc[2] += stn * sum; acc[3] += zn * rn; acc[4] += rn * rn;
                 } else {
-                    c.pr.zs_new[row] = sum;
+                    store_one(c.pr.zs_new + row, sum, st);
                     acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
                 }
             }
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
     WCtx<NV> c{s_val[wv], s_vi[wv], s_col[wv], s_dict[wv], s_win[wv], reinterpret_cast<const V*>(xin_), ep_r,
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
-                                  reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt},
+                                  reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt, (write_mask & 8) != 0},
                      fz.pr, lane, nullptr, 0, nullptr, 0};
     WCtx<NV>& cm = c;
     if constexpr (DEF > 0) {
@@ -1090,7 +1098,7 @@ int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int n
                       int meurant, double* partials, double* coef_out, int per_cu)
 {
     if (ntiles <= 0) return 0;
-    const int mask = 3 | (meurant ? 4 : 0);
+    const int mask = 3 | ((meurant & 1) ? 4 : 0) | ((meurant & 2) ? 8 : 0);      // (bit 1 of `meurant`: streaming stores)
     if (f.pr.d)
         return launch_win<1, kEpiPROneJ>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, f.pr.d, nullptr, partials,
                                          coef_out, f, per_cu);
@@ -1134,7 +1142,7 @@ int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, i
     if (ntiles <= 0) return 0;
     FusedPrev fz = f.prev;
     fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
-    const int mask = 3 | (f.meurant ? 4 : 0);
+    const int mask = 3 | (f.meurant ? 4 : 0) | (f.stream_stores ? 8 : 0);
     if (f.deferred) {
         if (f.dinv) {
             if (f.recompute_w)

@@ -37,7 +37,7 @@ class DeviceCSR:
     ``partition.plan_halo`` (columns >= n_rows are ghosts).
     """
 
-    def __init__(self, A, device=0, comm_init=None, halo=None, knobs=None):
+    def __init__(self, A, device=0, comm_init=None, halo=None, knobs=None, world=None):
         """knobs: dict of PRCG_* experiment switches for THIS handle (prcg_set_option), e.g.
         {'PRCG_FUSED': '0'} keeps the two-kernel schedule on one GPU.  The process environment
         is not touched."""
@@ -59,6 +59,9 @@ class DeviceCSR:
                 self._check(self._lib.prcg_comm_init(self._h, path.encode() if path else None, rank, nranks,
                                                      L.ptr(ids), ids.size // 128))
             self.rank, self.nranks = rank, nranks
+        elif world is not None:        # rank / world size without a communicator (prcg.h: prcg_world_init; peer-exchange plumbing only)
+            self._check(self._lib.prcg_world_init(self._h, int(world[0]), int(world[1])))
+            self.rank, self.nranks = int(world[0]), int(world[1])
         self._set_matrix(A, halo)
 
     # -- plumbing ---------------------------------------------------------------------
@@ -122,6 +125,14 @@ class DeviceCSR:
         if off.size == 0:
             off = np.zeros(1, dtype=np.int64)
         self._check(self._lib.prcg_peer_connect(self._h, L.ptr(hb), pp, L.ptr(off)))
+
+    def peer_selftest(self, k, rows, slot):
+        """One round of the exchange primitives (prcg.h: prcg_peer_selftest): returns (sum of all ranks' slots, ghost area)."""
+        rows, slot = L.f64(rows), L.f64(slot)
+        assert rows.shape == (self.n, 2) and slot.shape == (5,)
+        sums, ghost = np.zeros(5), np.zeros((max(self.n_ghost, 1), 2))
+        self._check(self._lib.prcg_peer_selftest(self._h, int(k), L.ptr(rows), L.ptr(slot), L.ptr(sums), L.ptr(ghost)))
+        return sums, ghost[:self.n_ghost]
 
     # -- products (tests / bench) ---------------------------------------------------------
     def matvec(self, x, reps=1):

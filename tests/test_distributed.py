@@ -587,3 +587,49 @@ def test_full_size_row_blocks_in_threads_peer_exchange(workload, nranks):
     assert all(s['fused_comm'] and s['peer'] and s['window'] for s in scheds), scheds
     np.testing.assert_allclose(hist['updated_residual_2_norm'][:10], ref[:10], rtol=1e-11)
     np.testing.assert_allclose(hist['updated_residual_2_norm'], ref, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nranks', [2, 3])
+def test_peer_exchange_between_processes(nranks):
+    """The peer exchange's plumbing between PROCESSES sharing the one GPU (what RCCL refuses): every rank allocates its
+    exchange buffer, the 64-byte hipIpc handles travel over the control plane, every rank maps the others' buffers and
+    plans its sends from the receivers' halo plans; then six rounds of the exchange primitives -- rows stored straight
+    into the neighbours' ghost areas, every rank's slot into every buffer, counters last -- and every rank checks the
+    sum of the slots (rank order, bit for bit) and the ghost rows it received against the closed form."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import peer_ipc_worker
+    ctx = mp.get_context('spawn')
+    pipes = [ctx.Pipe() for _ in range(nranks)]
+    procs = [ctx.Process(target=peer_ipc_worker.main, args=(r, nranks, pipes[r][1]), daemon=True) for r in range(nranks)]
+    for p in procs:
+        p.start()
+    conns = [pp[0] for pp in pipes]
+    done = {}
+    try:
+        while len(done) < nranks:
+            msgs = {}
+            for r, c in enumerate(conns):
+                if r in done:
+                    continue
+                assert c.poll(180), f'rank {r} is silent'
+                kind, obj = c.recv()
+                if kind == 'done':
+                    done[r] = obj
+                else:
+                    msgs[r] = obj
+            if msgs:
+                assert len(msgs) + len(done) == nranks and not done, (list(msgs), done)   # lockstep: all gather or none
+                everyone = [msgs[r] for r in range(nranks)]
+                for c in conns:
+                    c.send(everyone)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert len({d['pid'] for d in done.values()}) == nranks
+    for r in range(nranks):
+        assert done[r]['connected'], done[r]
+        assert not done[r]['bad'], done[r]['bad']
