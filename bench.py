@@ -288,8 +288,14 @@ def main():
     variant = VAR[args.variant]
     inv_diag = (1.0 / A_rows.tocsr()[:, lo:hi].diagonal()) if args.variant == 'pipe_pr_pcg' else None
 
-    elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
     fallback = None
+    run_err = None
+    if world > 1 and args.variant.startswith('pipe_'):
+        # the multi-rank one-launch schedule against the RCCL two-kernel schedule on the first iterations, before anything
+        # is timed (scaling.one_launch_self_check): on disagreement every rank runs the timed region on the RCCL schedule
+        run_err = scaling.one_launch_self_check(op, variant, b, x0, inv_diag)
+    if run_err is None:
+        elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
     if run_err is not None:
         # the one-launch schedule of a multi-rank session could not be kept fed on this node (its waits are
         # bounded and reported): every rank rebuilds its operator with the RCCL two-kernel schedule and the run is repeated

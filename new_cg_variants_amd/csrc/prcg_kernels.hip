@@ -902,20 +902,22 @@ __global__ __launch_bounds__(256) void k_peer_push(const PeerDev* __restrict__ p
         peer_send_slot(px, k, v);
     }
 }
-__global__ __launch_bounds__(64) void k_peer_collect(const PeerDev* __restrict__ px, int k, const double* __restrict__ partials, int nparts,
-                                                     double* __restrict__ dots_out, double* pub, unsigned* err) {
+__global__ __launch_bounds__(256) void k_peer_collect(const PeerDev* __restrict__ px, int k, const double* __restrict__ partials, int nparts,
+                                                      double* __restrict__ dots_out, double* pub, unsigned* err) {
+    __shared__ double s_mine[5];
+    if (nparts > 0) {      // the same 256-thread tree as workgroup 0 of a following launch would use
+        double mine[5];
+        sum_prev_partials<5, 4>(partials, nparts, 0, mine);
+        if (threadIdx.x < 5) s_mine[threadIdx.x] = mine[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     double tot[5];
     if (nparts > 0) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) tot[q] = 0.0;
-        for (int j = lane; j < nparts; j += 64) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) tot[q] += partials[(size_t)j * kPartialStride + q];
-        }
         double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { const double sq = wave_sum(tot[q]); v = lane == q ? sq : v; }
+        for (int q = 0; q < 5; ++q) v = lane == q ? s_mine[q] : v;
         peer_send_slot(px, k, v);
     }
     const bool ok = peer_collect(px, k, 1u << 24, tot);
@@ -1292,7 +1294,7 @@ void launch_peer_push(hipStream_t st, const PeerDev* px, const double* rs, const
 }
 void launch_peer_collect(hipStream_t st, const PeerDev* px, int k, const double* partials, int nparts, double* dots_out, double* pub,
                          unsigned* err) {
-    hipLaunchKernelGGL(k_peer_collect, dim3(1), dim3(64), 0, st, px, k, partials, nparts, dots_out, pub, err);
+    hipLaunchKernelGGL(k_peer_collect, dim3(1), dim3(256), 0, st, px, k, partials, nparts, dots_out, pub, err);
 }
 void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, dots, pub, value);

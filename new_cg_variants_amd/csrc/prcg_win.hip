@@ -197,9 +197,20 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                 if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) R.w[p].z = pr.d[d.pc[p] + lane];
             }
             else {
-                // (peer exchange: a page of ghost columns lies in this rank's exchange buffer -- pages never straddle n_own)
-                const typename VecT<NV>::type* src = (G != nullptr && d.pc[p] >= n_own) ? G : X;
-                R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(src)[d.pc[p] + lane];
+                if (G != nullptr && d.pc[p] >= n_own) {
+                    // peer exchange: a page of ghost columns lies in this rank's exchange buffer (pages never straddle n_own),
+                    // written by OTHER GPUs' stores: system-scope loads, which no cache of this GPU serves -- no acquire
+                    // fence (and no invalidation of anybody's cached lines) needed
+                    const double* gp = reinterpret_cast<const double*>(G + d.pc[p] + lane);
+                    if constexpr (NV == 2) {
+                        R.w[p].x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        R.w[p].y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        R.w[p] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                } else {
+                    R.w[p] = reinterpret_cast<const typename RegV<NV>::type*>(X)[d.pc[p] + lane];
+                }
             }
         }
     }
@@ -387,7 +398,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     // ---- request the tile DEPTH ahead (the image registers are free again) ----
     if (have_next) {
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
-        if (acquire_first) { if (c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+        if (acquire_first && !c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         next_same = same_image<PG>(rc, dnext);
         issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own);
     }
@@ -725,6 +736,18 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             t = relay ? ntiles : t - 1;
         }
     }
+    __shared__ double s_mine[5];
+    if constexpr (DEF > 0) {
+        if (fz.px && blockIdx.x == 0 && fz.nprev > 0) {
+            // peer exchange, workgroup 0: this rank's partial sums of the previous launch (one row per workgroup; complete:
+            // kernel boundary) in the fixed 256-thread tree -- all its waves, before they request their first tiles (vmcnt is
+            // in order); then the communication wave goes on alone
+            double mine[5];
+            sum_prev_partials<5, WPB>(fz.prev_partials, fz.nprev, 0, mine);
+            if (threadIdx.x < 5) s_mine[threadIdx.x] = mine[threadIdx.x];
+            __syncthreads();
+        }
+    }
 
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
     WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
@@ -777,17 +800,11 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
             const PeerDev* px = fz.px;
             double tot[5];
             if (fz.nprev > 0) {
-                // this rank's partial sums of the previous launch (one row per workgroup, complete: kernel boundary): lane l adds
-                // rows l, l + 64, ...; xor butterfly -- then the rank's slot goes into EVERY rank's exchange buffer
-#pragma unroll
-                for (int q = 0; q < 5; ++q) tot[q] = 0.0;
-                for (int j = lane; j < fz.nprev; j += 64) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) tot[q] += fz.prev_partials[(size_t)j * kPartialStride + q];
-                }
+                // this rank's partial sums of the previous launch (s_mine: summed by the whole workgroup, below) go as the rank's
+                // slot into EVERY rank's exchange buffer
                 double v = 0.0;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) { const double sq = wave_sum(tot[q]); v = lane == q ? sq : v; }
+                for (int q = 0; q < 5; ++q) v = lane == q ? s_mine[q] : v;
                 peer_send_slot(px, (int)fz.want, v);
             }
             // all R slots of iteration `want` in this rank's buffer -> sums in rank order -> the publication record
@@ -836,7 +853,7 @@ __global__ __launch_bounds__(64 * WPB) void k_win_tiles(
         // ghost rows (an agent-scope acquire invalidates the CU's L1: ~1.7 us each, serialised per CU): what the wave
         // loads from here on is what the publisher wrote before publishing
         if (pend[0]) {
-            if (!acquired) { if (fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
+            if (!acquired) { if (!fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
             same[0] = same_image<PG>(rc, d[0]);
             issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own);
             pend[0] = false;
@@ -987,8 +1004,12 @@ int defer_grid_per_cu(const void* kernel, bool guest, int wpb) {
     return best;
 }
 
+// 64-row tiles whose update waits for the other ranks' inner products.  One eighth of S3 on one GPU (nothing to wait for:
+// the pure cost of deferring), peer exchange with a loopback halo: 2 tiles 30.1 us per iteration, 3 tiles 31.1, 4 tiles
+// 32.5 (plain one-launch schedule 25.2); a round of tiles takes ~4 us there, the exchange chain of a real 8-rank run
+// (sum, stores over xGMI, the slowest rank's skew, publication) is estimated at 6-8 us: three rounds of cover
 #ifndef PRCG_DEFER_TILES
-#define PRCG_DEFER_TILES 4
+#define PRCG_DEFER_TILES 3
 #endif
 constexpr int kDeferTiles = PRCG_DEFER_TILES;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
 

@@ -82,6 +82,7 @@ class RowBlockOperator:
 
     def __init__(self, comm, A_rows, device=None, rccl_path=None, knobs=None):
         self.comm = comm
+        self.A_rows, self.rccl_path = A_rows, rccl_path
         rank, size = comm.Get_rank(), comm.Get_size()
         n_local, n = A_rows.shape
         sizes = comm.allgather_obj(int(n_local))
@@ -92,6 +93,7 @@ class RowBlockOperator:
         self.n_local, self.n = n_local, n
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', '0'))
+        self.device = device
         comm_init = None
         halo = None
         if size > 1:
@@ -127,6 +129,43 @@ class RowBlockOperator:
             self.peer = partition.connect_peer_exchange(self.dev, rank, comm.allgather_obj)
 
 
+def one_launch_self_check(op, variant, b, x0, inv_diag=None, iters=24):
+    """Collective.  Before anything is timed or trusted on a new node: the first iterations of the multi-rank one-launch
+    schedule (direct peer exchange: in-kernel waits for stores of OTHER GPUs) against the RCCL two-kernel schedule on the
+    same row blocks (stream-ordered collectives only).  The two differ in the summation order of the inner products
+    alone (~1e-12); a protocol or visibility problem between GPUs would show as a gross difference, or as a bounded
+    wait running out.  Returns None if they agree (or the session does not use the one-launch schedule), else the
+    reason -- the same on every rank."""
+    comm, dev = op.comm, op.dev
+    err, nu_a, one_launch = None, None, False
+    try:
+        dev.begin(variant, b, x0, iters + 8, inv_diag=inv_diag)
+        one_launch = dev.schedule()['fused_comm']
+        if one_launch:
+            dev.iterate(iters)
+            dev.sync()
+            nu_a = np.array([dev.get_scalars(k)[L.S_NU] for k in range(0, iters + 1, 3)])
+    except L.PrcgError as exc:
+        one_launch, err = True, str(exc)
+    if not any(comm.allgather_obj(bool(one_launch))):
+        return None
+    verdict = None
+    try:
+        ref = RowBlockOperator(comm, op.A_rows, device=op.device, rccl_path=op.rccl_path, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
+        ref.dev.begin(variant, b, x0, iters + 8, inv_diag=inv_diag)
+        ref.dev.iterate(iters)
+        ref.dev.sync()
+        nu_b = np.array([ref.dev.get_scalars(k)[L.S_NU] for k in range(0, iters + 1, 3)])
+        ref.dev.close()
+        if err is not None:
+            verdict = err
+        elif nu_a is None or not np.all(np.abs(nu_a - nu_b) <= 1e-6 * np.abs(nu_b)):
+            verdict = f'one-launch and RCCL schedules disagree: nu = {None if nu_a is None else nu_a.tolist()} vs {nu_b.tolist()}'
+    except L.PrcgError as exc:
+        verdict = f'reference (RCCL two-kernel) schedule failed: {exc}'
+    return next((v for v in comm.allgather_obj(verdict) if v), None)
+
+
 def _as_operator(comm, A):
     if isinstance(A, RowBlockOperator):
         return A
@@ -144,6 +183,28 @@ def _as_operator(comm, A):
 
 
 def _timed(comm, op, variant, b, max_iter):
+    """One timed solve.  If the one-launch multi-rank schedule cannot be kept fed on this node (its in-kernel waits are
+    bounded; a rank that waits too long reports it), the ranks agree on that and repeat the solve on the RCCL
+    two-kernel schedule -- the caller gets a result either way."""
+    try:
+        out, err = _timed_once(comm, op, variant, b, max_iter), None
+    except L.PrcgError as exc:
+        out, err = None, str(exc)
+    errs = [e for e in comm.allgather_obj(err) if e]
+    if not errs:
+        return out
+    if not op.dev.schedule().get('fused_comm'):
+        raise L.PrcgError(L.ERCCL, errs[0])
+    import sys
+    if comm.Get_rank() == 0:
+        print(f'[prcg] one-launch multi-rank schedule gave up ({errs[0][:120]}); repeating on the RCCL two-kernel schedule', file=sys.stderr)
+    op.dev.close()
+    op2 = RowBlockOperator(comm, op.A_rows, device=op.device, rccl_path=op.rccl_path, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
+    op.dev, op.peer = op2.dev, False
+    return _timed_once(comm, op, variant, b, max_iter)
+
+
+def _timed_once(comm, op, variant, b, max_iter):
     dev = op.dev
     b = L.f64(b)
     rank = comm.Get_rank()
@@ -199,4 +260,4 @@ def gv_cg(comm, A, b, max_iter):
     return _timed(comm, _as_operator(comm, A), L.GV, b, max_iter)
 
 
-__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'pipe_pr_cg', 'pipe_p_cg', 'hs_cg', 'pr_cg', 'cg_cg', 'gv_cg']
+__all__ = ['TorchComm', 'SelfComm', 'RowBlockOperator', 'one_launch_self_check', 'pipe_pr_cg', 'pipe_p_cg', 'hs_cg', 'pr_cg', 'cg_cg', 'gv_cg']

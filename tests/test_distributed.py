@@ -633,3 +633,86 @@ def test_peer_exchange_between_processes(nranks):
     for r in range(nranks):
         assert done[r]['connected'], done[r]
         assert not done[r]['bad'], done[r]['bad']
+
+
+class ThreadComm:
+    """The communicator-like object of new_cg_variants_amd.scaling for ranks that are threads of this process."""
+
+    def __init__(self, rank, size, shared):
+        self.rank, self.size, self.shared = rank, size, shared
+        self.seq = 0
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def allgather_obj(self, obj):
+        box, barrier = self.shared
+        key = self.seq
+        self.seq += 1
+        box[(key, self.rank)] = obj
+        barrier.wait(timeout=180)
+        res = [box[(key, q)] for q in range(self.size)]
+        barrier.wait(timeout=180)
+        return res
+
+    def Barrier(self):
+        self.allgather_obj(None)
+
+    def bcast_obj(self, obj, root=0):
+        return self.allgather_obj(obj)[root]
+
+
+@pytest.mark.gpu
+def test_row_block_operator_self_check_and_drop_in_call_in_threads():
+    """The host side of an N > 1 run exactly as bench.py and the scaling drop-ins drive it -- RowBlockOperator (row block with
+    global column ids -> local numbering, halo plan, communicator, peer exchange connected over the control plane),
+    scaling.one_launch_self_check (first iterations of the one-launch schedule against the RCCL two-kernel schedule) and
+    `sol, t = pipe_pr_cg(comm, A, b, max_iter)` -- with three ranks in threads on the one GPU."""
+    import threading
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems, scaling
+    from new_cg_variants_amd.device import DeviceCSR
+    path = os.path.join(ROOT, 'tests', 'transport', 'libthreads_ccl.so')
+    A = problems.WORKLOADS['s3_small']['make']()
+    n = A.shape[0]
+    nranks = 3
+    offsets = partition.even_offsets(n, nranks)
+    x_true = np.ones(n) / np.sqrt(n)
+    b = A @ x_true
+    shared = ({}, threading.Barrier(nranks))
+    out, errs = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            lo, hi = int(offsets[r]), int(offsets[r + 1])
+            comm = ThreadComm(r, nranks, shared)
+            op = scaling.RowBlockOperator(comm, A[lo:hi], device=0, rccl_path=path, knobs={'PRCG_DEFER_GRID_PER_CU': '1'})
+            assert op.peer
+            verdict = scaling.one_launch_self_check(op, L.PIPE_PR, b[lo:hi], np.zeros(hi - lo))
+            sol, t = scaling.pipe_pr_cg(comm, op, b[lo:hi], 150)
+            out[r] = (verdict, sol, t, op.dev.schedule())
+            op.dev.close()
+        except Exception as exc:       # noqa: BLE001
+            import traceback
+            errs.append((r, repr(exc), traceback.format_exc()[-1200:]))
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errs, errs
+    assert all(o is not None for o in out), 'a rank did not finish'
+    assert all(o[0] is None for o in out), [o[0] for o in out]
+    assert all(o[3]['peer'] and o[3]['fused_comm'] for o in out), [o[3] for o in out]
+    assert out[0][2]['tot'] > 0 and out[1][2] is None
+    x = np.concatenate([o[1] for o in out])
+    one = DeviceCSR(A)
+    one.begin(L.PIPE_PR, b, np.zeros(n), 152)
+    one.iterate(150)
+    ref = one.get_vector('x')
+    one.close()
+    assert np.linalg.norm(x - ref) <= 1e-6 * np.linalg.norm(ref)
