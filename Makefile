@@ -9,7 +9,7 @@ OUT := new_cg_variants_amd/libprcg.so
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
 # TEST INFRASTRUCTURE: a stand-in for librccl.so that connects ranks living in threads of one process on one GPU
 TRANSPORT := tests/transport/libthreads_ccl.so
-OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
+OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_sell.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
 
 all: $(OUT) $(TRANSPORT)
 
@@ -17,6 +17,9 @@ $(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h $(CSRC)/
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_win.o: $(CSRC)/prcg_win.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_sell.o: $(CSRC)/prcg_sell.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h

@@ -211,6 +211,7 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_COL16 128    /* ... 2-byte */
 #define PRCG_SCHED_FUSED_COMM 8192 /* one launch per iteration WITH a communicator: the interior launch waits in-kernel
                                       for the reduced inner products of the previous iteration */
+#define PRCG_SCHED_SELL 32768  /* lane-per-row kernels over 64-row slices (medium-length rows: assembled FEM matrices) */
 #define PRCG_SCHED_PEER 16384  /* ... through the direct peer exchange (prcg_peer_setup / prcg_peer_connect): no collective in the loop */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */

@@ -126,6 +126,13 @@ struct prcg_handle {
     bool win_vd = false;
     int nwt_int = 0, nwt_bnd = 0;
     DevBuf wtiles, wcw, wvidx, wvdict, wrel;
+    // ---- sliced rows (lane-per-row kernels for medium-length rows, prcg_sell.hip): all rows of the operator or none ----
+    bool want_sell = true;               // PRCG_SELL=0 turns them off
+    int sell_per_cu = 0;                 // PRCG_SELL_GRID_PER_CU
+    bool sell = false;
+    int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
+    int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
+    DevBuf sval, scol, sslices;
     bool want_share = true;              // PRCG_WIN_SHARE=0: every window tile keeps its own stream images
     int64_t win_stream_bytes = 0;        // bytes of the encoded operator a product must read at least once (window form)
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
@@ -234,6 +241,9 @@ struct prcg_handle {
                       static_cast<const unsigned short*>(wrel.p)};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
+    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p)}; }
+    const double* val_sell() const { return static_cast<const double*>(sval.p); }
+    const void* sslice_ptr(int first = 0) const { return static_cast<const char*>(sslices.p) + (size_t)first * 32; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
     bool multi() const { return comm != nullptr; }
 
@@ -353,6 +363,11 @@ int eng_spmv(prcg_t* h, hipStream_t st, int which, const double* x, double* y, S
         return launch_win_spmv(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, x, y, epi, ep_r, ep_d, ep_st, partials,
                                h->win_per_cu);
     }
+    if (h->sell) {
+        const int first = which == 2 ? h->nst_int : 0;
+        const int nt = which == 0 ? h->nst_int + h->nst_bnd : (which == 1 ? h->nst_int : h->nst_bnd);
+        return launch_sell_spmv(st, h->sdev(), h->sslice_ptr(first), nt, x, y, epi, ep_r, ep_d, ep_st, partials, h->sell_per_cu);
+    }
     const int first = which == 2 ? h->nt_int : 0;
     const int nt = which == 0 ? h->nt_int + h->nt_bnd : (which == 1 ? h->nt_int : h->nt_bnd);
     const CsrDev A = which == 0 ? h->csr() : (which == 1 ? h->csr(0, h->nt_bnd == 0) : h->csr(h->nt_int, false));
@@ -364,6 +379,11 @@ int eng_spmm2(prcg_t* h, hipStream_t st, int which, const double* rs, double* wu
         const int first = which == 2 ? h->nwt_int : 0;
         const int nt = which == 0 ? h->nwt_int + h->nwt_bnd : (which == 1 ? h->nwt_int : h->nwt_bnd);
         return launch_win_spmm2(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, rs, wu, mask, h->win_per_cu);
+    }
+    if (h->sell) {
+        const int first = which == 2 ? h->nst_int : 0;
+        const int nt = which == 0 ? h->nst_int + h->nst_bnd : (which == 1 ? h->nst_int : h->nst_bnd);
+        return launch_sell_spmm2(st, h->sdev(), h->sslice_ptr(first), nt, rs, wu, mask, h->sell_per_cu);
     }
     const int first = which == 2 ? h->nt_int : 0;
     const int nt = which == 0 ? h->nt_int + h->nt_bnd : (which == 1 ? h->nt_int : h->nt_bnd);
@@ -378,6 +398,7 @@ int eng_fused(prcg_t* h, hipStream_t st, const FusedState& f, int which = 0) {
         return launch_win_pipe_fused(st, h->wdev(), h->wtile_ptr(first), nt, h->win_geom, f,
                                      f.deferred ? h->defer_per_cu : h->win_per_cu);
     }
+    if (h->sell) return launch_sell_pipe_fused(st, h->sdev(), h->sslice_ptr(0), h->nst_int + h->nst_bnd, f, h->sell_per_cu);
     return launch_pipe_fused(st, h->csr(), h->tile_ptr(), h->nt_int + h->nt_bnd, h->steps, f, h->kn);
 }
 
@@ -1134,6 +1155,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN") h->want_win = v != 0;
     else if (k == "PRCG_FUSED_COMM") { h->want_fused_comm = v != 0; h->want_fused_comm_rccl = v != 0; }
     else if (k == "PRCG_PEER") h->want_peer = v != 0;
+    else if (k == "PRCG_SELL") h->want_sell = v != 0;
+    else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
@@ -1147,7 +1170,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1417,7 +1440,13 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             }
         }
     }
-    const bool classic_enc = !h->win;      // column / value re-encodings of the CSR-adaptive kernels
+    // --- sliced rows (lane-per-row kernels): operators that are no window operators but whose rows are long enough for
+    // a lane each -- assembled FEM matrices -- when the padding to the slices' longest rows stays below 25 % ---
+    h->sell = false; h->nst_int = h->nst_bnd = 0;
+    SellPlan sp;
+    if (!h->win && h->want_sell && n_rows >= 64 && nnz >= 8 * n_rows)
+        h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, 1.25, sp);
+    const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels
 
     // --- 16-bit tile-relative column encoding (host, once) ---
     std::vector<int32_t> tbase(all.size() + 1, 0);
@@ -1543,6 +1572,19 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         if (!vdict.empty())
             HIPCHK(h, hipMemcpy(h->vdict.p, vdict.data(), vdict.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->vdesc.p, vdesc.data(), vdesc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (h->sell) {
+        h->nst_int = (int)sp.s0.size(); h->nst_bnd = (int)sp.s1.size();
+        std::vector<SellSlice> sall(sp.s0);
+        sall.insert(sall.end(), sp.s1.begin(), sp.s1.end());
+        HIPCHK(h, h->sval.alloc(sp.val.size() * sizeof(double), false));
+        HIPCHK(h, hipMemcpy(h->sval.p, sp.val.data(), sp.val.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, h->scol.alloc(sp.col.size() * sizeof(uint16_t), false));
+        HIPCHK(h, hipMemcpy(h->scol.p, sp.col.data(), sp.col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIPCHK(h, h->sslices.alloc((sall.size() + 1) * sizeof(SellSlice)));
+        if (!sall.empty()) HIPCHK(h, hipMemcpy(h->sslices.p, sall.data(), sall.size() * sizeof(SellSlice), hipMemcpyHostToDevice));
+        h->sell_bytes = sp.padded_nnz * 10 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1);
+        sp = SellPlan{};
     }
     h->peer_ok = false;
     h->wt_rb.clear(); h->wt_re.clear();
@@ -2203,6 +2245,7 @@ int prcg_iteration(const prcg_t* h) { return h ? h->k : -1; }
 int64_t prcg_operator_bytes(const prcg_t* h) {
     if (!h || !h->have_csr) return -1;
     if (h->win) return h->win_stream_bytes;
+    if (h->sell) return h->sell_bytes;
     // CSR-adaptive tiles: row pointers, tile table, column stream as encoded, values or dictionary indices
     const int64_t colb = h->c8_int ? 1 : (h->c16_int ? 2 : 4);
     const int64_t nt = (int64_t)h->nt_int + h->nt_bnd;
@@ -2212,7 +2255,7 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
     return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) |
-           (h->peer ? PRCG_SCHED_PEER : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+           (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW

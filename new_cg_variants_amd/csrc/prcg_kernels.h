@@ -261,6 +261,23 @@ int launch_win_cg_w(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
 int launch_win_gv_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
                     double* t_out, double* partials, double* coef_out, int per_cu);
 
+// ---- sliced rows: lane-per-row kernels for medium-length rows (prcg_sell.hip) -----------------
+// Planned on the host by plan_sell (prcg_plan.cpp): slices of up to 64 consecutive rows of one class; nonzero u of row
+// rb + lane at position (u, lane) of the slice -- val in chunks of two doubles, col16 (column - the slice's smallest
+// column) in chunks of four -- so that one wave instruction reads "nonzeros u.. of all 64 rows" fully coalesced.
+// Lossless re-layout of the caller's CSR arrays; the row lengths are read from indptr.  Slice descriptor: 8 int32
+// {first row, end row, offset of the slice in val, offset in col16, longest row, smallest column, 0, 0}.
+struct SellDev {
+    const int* indptr;
+    const double* val;
+    const unsigned short* col16;
+};
+int launch_sell_spmv(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* x, double* y, SpmvEpilogue epi,
+                     const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu);
+int launch_sell_spmm2(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* rs, double* wu, int write_mask,
+                      int per_cu);
+int launch_sell_pipe_fused(hipStream_t st, const SellDev& A, const void* slices, int nslices, const FusedState& f, int per_cu);
+
 // ---- small systems: the whole pipelined solve in one launch of one workgroup -------------
 struct SmallArgs {
     int n, nnz;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <climits>
 #include <cstring>
 #include <thread>
 #include <unordered_map>
@@ -297,6 +298,71 @@ template StreamStats share_window_streams<uint8_t>(std::vector<WTile>&, const in
                                                    std::vector<uint8_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&);
 template StreamStats share_window_streams<uint16_t>(std::vector<WTile>&, const int32_t*, const uint16_t*, const uint8_t*, bool,
                                                     std::vector<uint16_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&);
+
+bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
+               double max_overhead, SellPlan& out) {
+    out.s0.clear(); out.s1.clear(); out.val.clear(); out.col.clear(); out.padded_nnz = 0;
+    const int64_t nnz = indptr[n];
+    // pass 1: slices, widths, offsets
+    std::vector<SellSlice> all;
+    std::vector<uint8_t> cls_of;
+    int64_t voff = 0, coff = 0, r = 0;
+    while (r < n) {
+        const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
+        int64_t e = r;
+        int width = 0;
+        int32_t cmin = INT32_MAX, cmax = -1;
+        while (e < n && e - r < 64 && (!row_class || (row_class[e] != 0) == cls)) {
+            width = std::max(width, indptr[e + 1] - indptr[e]);
+            for (int32_t q = indptr[e]; q < indptr[e + 1]; ++q) { cmin = std::min(cmin, indices[q]); cmax = std::max(cmax, indices[q]); }
+            ++e;
+        }
+        if (cmax < 0) cmin = 0;
+        if (cmax >= 0 && cmax - cmin >= 65536) return false;
+        const int w2 = (width + 1) & ~1, w4 = (width + 3) & ~3;
+        if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w4 * 64 >= (int64_t)INT32_MAX - 4096) return false;
+        all.push_back(SellSlice{(int)r, (int)e, (int)voff, (int)coff, width, cmin, 0, 0});
+        cls_of.push_back(cls);
+        voff += (int64_t)w2 * 64;
+        coff += (int64_t)w4 * 64;
+        r = e;
+    }
+    if ((double)voff > max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
+    out.padded_nnz = voff;
+    // pass 2: fill (padding: value 0, column 0)
+    out.val.assign((size_t)voff + 1024, 0.0);
+    out.col.assign((size_t)coff + 1024, 0);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+    if (all.size() < 1024) nt = 1;
+    auto fill = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+            const SellSlice& sl = all[i];
+            for (int row = sl.rb; row < sl.re; ++row) {
+                const int l = row - sl.rb;
+                const int32_t lo = indptr[row];
+                const int len = indptr[row + 1] - lo;
+                for (int u = 0; u < len; ++u) {
+                    out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + u];
+                    out.col[(size_t)sl.coff + ((size_t)(u >> 2) * 64 + l) * 4 + (u & 3)] = (uint16_t)(indices[lo + u] - sl.cbase);
+                }
+            }
+        }
+    };
+    if (nt == 1) fill(0, all.size());
+    else {
+        std::vector<std::thread> th;
+        const size_t per = (all.size() + nt - 1) / nt;
+        for (unsigned i = 0; i < nt; ++i) {
+            const size_t a = std::min(all.size(), i * per), b = std::min(all.size(), a + per);
+            th.emplace_back(fill, a, b);
+        }
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < all.size(); ++i) (cls_of[i] ? out.s1 : out.s0).push_back(all[i]);
+    return true;
+}
 
 int plan_gather_sources(int rank, int T, const double* tab, int n_peers, const int32_t* peer_rank,
                         const int64_t* recv_ptr, int64_t slot, int32_t* src) {

@@ -68,6 +68,23 @@ StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indpt
                                  bool share, std::vector<CW>& cw_store, std::vector<uint8_t>& vidx_store,
                                  std::vector<uint16_t>& rel_store);
 
+// ---- sliced rows (prcg_sell.hip) ---------------------------------------------------------------
+// Slices of up to 64 consecutive rows of one class (interior slices first).  Within a slice of width w (its longest
+// row), nonzero u of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4]
+// (column minus the slice's smallest column); shorter rows are padded with value 0 / column 0 (never multiplied: the
+// kernels mask by the row length).  The arrays end with a whole trip of padding.  Returns false (nothing built) if
+// the operator does not qualify: a slice's columns span 65536 or more, or padding would exceed `max_overhead` x nnz.
+struct SellSlice { int rb, re, voff, coff, width, cbase, pad0, pad1; };
+static_assert(sizeof(SellSlice) == 32, "the kernels read a slice descriptor as two int4");
+struct SellPlan {
+    std::vector<SellSlice> s0, s1;       // interior slices, slices touching ghost columns
+    std::vector<double> val;
+    std::vector<uint16_t> col;
+    int64_t padded_nnz = 0;
+};
+bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
+               double max_overhead, SellPlan& out);
+
 // Merged exchange (small halos ride on the one all-gather per iteration):
 // every rank contributes a slot of `slot` doubles = 8 (partial sums) + 2 x its packed send rows;
 // `tab` holds every rank's send table, `T` doubles per rank: [n_peers, (peer, first row of the

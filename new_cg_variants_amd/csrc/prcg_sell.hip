@@ -1,0 +1,212 @@
+// gfx950 (MI355X / CDNA4): "sliced rows" kernels for operators with medium-length rows that are no window
+// operators -- assembled FEM matrices (3 dof x 27 neighbours = 81 nonzeros per row; SuiteSparse Queen_4147 has ~76).
+//
+// The CSR-adaptive tile kernels (prcg_kernels.hip) stream such a matrix in CSR order, park the products in LDS and let
+// ONE LANE PER ROW add them -- with 81 nonzeros per row a 1021-nonzero tile holds 12 rows: 12 of 64 lanes work in the
+// reduction phase, two dependent round trips per tile.  Here the rows keep their own lane for the whole product:
+//
+//   * the operator is re-laid once, on the host, in SLICES of 64 consecutive rows (prcg_plan.cpp: plan_sell): nonzero
+//     u of row (rb + lane) sits at position (u, lane) of its slice -- values in chunks of two, 16-bit slice-relative
+//     columns in chunks of four -- so that the wave's load of "nonzeros u..u+1 of all 64 rows" is ONE fully coalesced
+//     16-byte-per-lane instruction (a device-internal, lossless re-layout of the caller's CSR arrays; rows shorter than
+//     the slice's longest are padded and the padding is never multiplied);
+//   * lane i walks row i left to right, 8 nonzeros per trip with the next trip's values and columns already in flight:
+//     no LDS, no cross-lane step, the same sum as scipy's csr_matvec bit for bit
+//     (numerical_experiments/cg_variants/pipe_pr_cg.py:69-70 calls `A @ v`);
+//   * the input vector is gathered per nonzero from memory (L1 / L2: the columns of consecutive FEM rows are clustered);
+//   * the row epilogues are those of the CSR-adaptive family (finish_row: store, inner-product partials, the fused
+//     pipelined update), so every schedule that runs on CSR-adaptive tiles runs on slices.
+#include <hip/hip_runtime.h>
+
+#include "prcg_device.hpp"
+#include "prcg_kernels.h"
+
+namespace prcg {
+namespace {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+struct SDesc { int rb, re, voff, coff, width, cbase; };
+
+__device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) {
+    const int4 a = st[2 * t], b = st[2 * t + 1];
+    SDesc d;
+    d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
+    d.voff = __builtin_amdgcn_readfirstlane(a.z); d.coff = __builtin_amdgcn_readfirstlane(a.w);
+    d.width = __builtin_amdgcn_readfirstlane(b.x); d.cbase = __builtin_amdgcn_readfirstlane(b.y);
+    return d;
+}
+
+// 8 nonzeros of every row of the slice: four value chunks (2 doubles per lane each), two column chunks (4 x u16)
+struct Trip { d2_t v[4]; uint2 c[2]; };
+
+__device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip& T) {
+    // chunk index of nonzero u: values u / 2, columns u / 4; a chunk past the slice's width re-reads the last one
+    // (padding is allocated to a whole trip at the end of the arrays; see plan_sell)
+    const int64_t vb = (int64_t)d.voff + ((int64_t)(u0 >> 1) * 64 + lane) * 2;
+    const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 2) * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T.v[k] = *reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)k * 128);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) T.c[k] = *reinterpret_cast<const uint2*>(A.col16 + cb + (int64_t)k * 256);
+}
+
+template <int NV, int EPI>
+__global__ __launch_bounds__(kBlock) void k_sell_tiles(
+    SellDev A, const int4* __restrict__ slices, int nslices,
+    const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
+    const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,
+    double* __restrict__ partials, double* __restrict__ aux, FusedPrev fz)
+{
+    using V = typename VecT<NV>::type;
+    const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    Coefs cf = {0.0, 0.0, 0.0};
+    const FusedRowPtrs fr{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st), reinterpret_cast<double2*>(fz.rs),
+                          ep_d, fz.w, fz.wt, (write_mask & 8) != 0};
+    if constexpr (epi_fused(EPI)) {
+        // inner products of the previous iteration: one row of partials per workgroup of the previous launch, summed by
+        // every workgroup of this one in the fixed 256-thread tree (as k_spmv_tiles / k_win_tiles do)
+        if (fz.nprev > 0) {
+            double dsum[5];
+            sum_prev_partials<5, kWaves>(fz.prev_partials, fz.nprev, 0, dsum);
+            if (blockIdx.x == 0 && threadIdx.x < 5) fz.dots_prev_out[threadIdx.x] = dsum[threadIdx.x];
+            cf = predict(dsum, (write_mask >> 2) & 1);
+        } else {
+            cf = predict(ep_r, (write_mask >> 2) & 1);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+    }
+
+    const int nblk = gridDim.x;
+    const int W = nblk * kWaves;
+    int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+
+    Trip cur, nxt;
+    SDesc d = {0, 0, 0, 0, 0, 0}, dn = {0, 0, 0, 0, 0, 0};
+    if (t < nslices) {
+        d = read_sdesc(slices, t);
+        load_trip(A, d, 0, lane, cur);
+        if (t + W < nslices) dn = read_sdesc(slices, t + W);
+    }
+    while (t < nslices) {
+        const int row = d.rb + lane;
+        const bool active = row < d.re;
+        const int rr = active ? row : d.rb;
+        const int len = active ? A.indptr[rr + 1] - A.indptr[rr] : 0;
+        V sum; vzero(sum);
+        for (int u0 = 0; u0 < d.width; u0 += 8) {                            // wave-uniform trip count
+            // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
+            const bool more = u0 + 8 < d.width;
+            if (more) load_trip(A, d, u0 + 8, lane, nxt);
+            else if (t + W < nslices) load_trip(A, dn, 0, lane, nxt);
+            int col[8];
+            col[0] = cur.c[0].x & 0xffffu; col[1] = cur.c[0].x >> 16; col[2] = cur.c[0].y & 0xffffu; col[3] = cur.c[0].y >> 16;
+            col[4] = cur.c[1].x & 0xffffu; col[5] = cur.c[1].x >> 16; col[6] = cur.c[1].y & 0xffffu; col[7] = cur.c[1].y >> 16;
+            V g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + col[k]];         // (padding columns are 0: a valid entry, never used)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double a = (k & 1) ? cur.v[k >> 1].y : cur.v[k >> 1].x;
+                if (u0 + k < len) vacc(sum, vmul(a, g[k]));                  // left to right, product rounded, then added
+            }
+            cur = nxt;
+        }
+        if (d.width == 0 && t + W < nslices) load_trip(A, dn, 0, lane, cur);
+        if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
+        t += W;
+        d = dn;
+        if (t + W < nslices) dn = read_sdesc(slices, t + W);
+    }
+
+    if constexpr (epi_fused(EPI)) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+    else if constexpr (EPI == kEpiCG) block_reduce_store<5>(acc, partials, 0);
+    else if constexpr (EPI != kEpiNone) {
+        double a3[3] = {acc[0], acc[1], acc[2]};
+        block_reduce_store<3>(a3, partials, 0);
+    }
+}
+
+// persistent grid: workgroups that are truly co-resident (the kernel uses no LDS beyond the reduction scratch: the
+// occupancy API's register bound is the bound), at most `per_cu` per CU
+template <typename K>
+int sell_grid(K kernel, int nslices, int per_cu) {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 256, occ = 4;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
+        }
+        if (occ > 4) occ = 4;
+        cached = occ * 1024 + cus;
+    }
+    int occ = cached / 1024;
+    const int cus = cached % 1024;
+    if (per_cu >= 1 && per_cu <= 8) occ = per_cu;
+    int g = (nslices + kWaves - 1) / kWaves;
+    if (g > occ * cus) g = occ * cus;
+    if (g < 1) g = 1;
+    return g;
+}
+
+template <int NV, int EPI>
+int launch_sell(hipStream_t st, const SellDev& A, const void* slices, int nslices, const void* x, void* y, int write_mask,
+                const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz, int per_cu)
+{
+    auto k = k_sell_tiles<NV, EPI>;
+    const int grid = sell_grid(k, nslices, per_cu);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r, ep_d,
+                       ep_st, partials, aux, fz);
+    return hipGetLastError() == hipSuccess ? grid : -1;
+}
+
+}  // namespace
+
+int launch_sell_spmv(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* x, double* y, SpmvEpilogue epi,
+                     const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu)
+{
+    if (nslices <= 0) return 0;
+    const FusedPrev none{};
+    switch (epi) {
+    case kEpiNone: return launch_sell<1, kEpiNone>(st, A, slices, nslices, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiDotXY: return launch_sell<1, kEpiDotXY>(st, A, slices, nslices, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiPR: return launch_sell<1, kEpiPR>(st, A, slices, nslices, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    case kEpiCG: return launch_sell<1, kEpiCG>(st, A, slices, nslices, x, y, 3, ep_r, ep_d, ep_st, partials, nullptr, none, per_cu);
+    default: break;
+    }
+    return -1;
+}
+
+int launch_sell_spmm2(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* rs, double* wu, int write_mask,
+                      int per_cu)
+{
+    if (nslices <= 0) return 0;
+    return launch_sell<2, kEpiNone>(st, A, slices, nslices, rs, wu, write_mask, nullptr, nullptr, nullptr, nullptr, nullptr, FusedPrev{}, per_cu);
+}
+
+int launch_sell_pipe_fused(hipStream_t st, const SellDev& A, const void* slices, int nslices, const FusedState& f, int per_cu)
+{
+    if (nslices <= 0) return 0;
+    FusedPrev fz = f.prev;
+    fz.rs = f.rs; fz.w = f.w; fz.wt = f.wt;
+    const int mask = 3 | (f.meurant ? 4 : 0) | (f.stream_stores ? 8 : 0);
+    if (f.dinv) {
+        if (f.recompute_w)
+            return launch_sell<2, kEpiPipeFusedJ>(st, A, slices, nslices, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new, f.partials,
+                                                  f.coef_out, fz, per_cu);
+        return launch_sell<2, kEpiPipeFusedPJ>(st, A, slices, nslices, f.in_old, f.xp, mask, f.dots_prev, f.dinv, f.in_new, f.partials,
+                                               f.coef_out, fz, per_cu);
+    }
+    if (f.recompute_w)
+        return launch_sell<2, kEpiPipeFused>(st, A, slices, nslices, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new, f.partials,
+                                             f.coef_out, fz, per_cu);
+    return launch_sell<2, kEpiPipeFusedP>(st, A, slices, nslices, f.in_old, f.xp, mask, f.dots_prev, nullptr, f.in_new, f.partials,
+                                          f.coef_out, fz, per_cu);
+}
+
+}  // namespace prcg

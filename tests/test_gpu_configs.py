@@ -55,6 +55,7 @@ def test_window_kernels_selected_for_bands_and_stencils_only(amd):
         op = amd['device'].DeviceCSR(A)
         s = op.schedule()
         assert s['window'] == window, (name, s)
+        assert s['sliced_rows'] == (name == 'fem'), (name, s)      # lane-per-row slices: medium-length rows that are no window operator
         if window:
             assert s['col_bytes'] == col_bytes, (name, s)
         x = rng.standard_normal(A.shape[0])
@@ -430,3 +431,100 @@ def test_short_window_source_is_refused_not_faulted(amd):
     op.sync()
     assert np.isfinite(op.get_scalars(5)[L.S_NU])
     op.close()
+
+
+@pytest.mark.gpu
+def test_sliced_row_kernels_on_randomised_medium_rows(amd):
+    """The lane-per-row kernels over 64-row slices (prcg_sell.hip; FEM-like operators, config 5): ragged rows of 0..120
+    nonzeros, unsorted and duplicate indices, empty rows, +-0 / inf / nan values, a row block with ghost columns -- the
+    products are scipy's csr_matvec bit for bit, and bit for bit what the CSR-adaptive kernels (PRCG_SELL=0) give."""
+    rng = np.random.default_rng(77)
+    for trial in range(4):
+        n = int(rng.integers(3000, 20000))
+        lens = rng.integers(0, 121, size=n)
+        lens[rng.integers(0, n, size=n // 50)] = 0
+        if trial == 3:
+            lens[:] = 81                                      # every row full: no padding, no masked slot
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(n), lens)
+        cols = np.clip(rows + rng.integers(-2000, 2001, size=rows.size), 0, n - 1).astype(np.int32)
+        vals = rng.standard_normal(rows.size)
+        if trial == 1:
+            vals[rng.integers(0, vals.size, size=50)] = 0.0
+            vals[rng.integers(0, vals.size, size=50)] = -0.0
+            vals[rng.integers(0, vals.size, size=5)] = np.inf
+            vals[rng.integers(0, vals.size, size=5)] = np.nan
+        A = sp.csr_matrix((vals, cols, indptr), shape=(n, n))
+        A.has_canonical_format = False
+        x = rng.standard_normal(n)
+        with np.errstate(all='ignore'):
+            ref = A @ x
+            ref2 = A @ (2.0 * x[::-1])
+        op = amd['device'].DeviceCSR(A)
+        s = op.schedule()
+        assert s['sliced_rows'] and not s['window'], s
+        y, _ = op.matvec(x)
+        assert np.array_equal(y, ref, equal_nan=True), trial
+        WU, _ = op.matmat2(np.stack([x, 2.0 * x[::-1]], axis=1))
+        assert np.array_equal(WU[:, 0], ref, equal_nan=True) and np.array_equal(WU[:, 1], ref2, equal_nan=True), trial
+        op.close()
+        off = amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': '0'})
+        assert not off.schedule()['sliced_rows']
+        assert np.array_equal(off.matvec(x)[0], ref, equal_nan=True)
+        off.close()
+    # a row block with ghost columns: interior slices and slices touching ghosts
+    A = amd['problems'].fem_like_3d(14, 3)
+    n = A.shape[0]
+    x = rng.standard_normal(n)
+    got = np.empty(n)
+    offsets = amd['partition'].even_offsets(n, 3)
+    for r in range(3):
+        lo, hi = int(offsets[r]), int(offsets[r + 1])
+        A_local, ghost_ids = amd['partition'].localize(A[lo:hi], lo, hi)
+        dev = amd['device'].DeviceCSR(A_local)
+        assert dev.schedule()['sliced_rows']
+        got[lo:hi] = dev.matvec_ext(np.concatenate([x[lo:hi], x[ghost_ids]]))
+        dev.close()
+    assert np.array_equal(got, A @ x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant,prec', [('PIPE_PR', None), ('PIPE_P_M', 'jacobi'), ('HS', None), ('PR', 'jacobi'), ('CG_CG', None)])
+def test_sliced_row_kernels_run_every_schedule_of_the_tile_kernels(amd, variant, prec):
+    """Same row epilogues as the CSR-adaptive family: forced single steps of the solver variants on a FEM-like operator
+    agree with the CSR-adaptive kernels (PRCG_SELL=0) bit for bit in every vector and to 1e-12 in the scalars (the inner
+    products are summed slice by slice instead of tile by tile)."""
+    L = amd['L']
+    A = amd['problems'].fem_like_3d(16, 3)
+    n = A.shape[0]
+    b, x0, x_true = amd['problems'].reference_rhs(A, n)
+    inv_diag = (1 / A.diagonal()) if prec else None
+    ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': f}) for f in ('1', '0')]
+    for op in ops:
+        op.begin(getattr(L, variant), b, x0, 40, inv_diag=inv_diag)
+    assert ops[0].schedule()['sliced_rows'] and not ops[1].schedule()['sliced_rows']
+    pipelined = variant.startswith('PIPE')
+    stored = ['x', 'r', 'p', 's'] + (['rt', 'st'] if (prec and variant != 'HS') else (['rt'] if prec else []))
+    if variant == 'CG_CG':
+        stored = ['x', 'r', 'p', 's', 'w']
+    if variant == 'PIPE_P_M':
+        stored += ['w'] + (['wt'] if prec else [])
+    worst = 0.0
+    for k in range(12):
+        st = {v: ops[1].get_vector(v) for v in stored}
+        sc = ops[1].get_scalars(k)
+        for v, a in st.items():
+            ops[0].set_vector(v, a)
+        ops[0].set_scalars(k, sc)
+        ops[0].set_iteration(k)
+        for op in ops:
+            op.iterate(1)
+        for v in stored:
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
+        a, c = ops[0].get_scalars(k + 1)[:5], ops[1].get_scalars(k + 1)[:5]
+        nz = c != 0
+        worst = max(worst, float(np.max(np.abs(a[nz] - c[nz]) / np.abs(c[nz]))))
+    assert worst <= 1e-12, worst
+    assert pipelined == ops[0].schedule()['fused'] or not pipelined
+    for op in ops:
+        op.close()
