@@ -41,8 +41,9 @@ __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) 
 struct Trip { d2_t v[4]; uint2 c[2]; };
 
 __device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip& T) {
-    // chunk index of nonzero u: values u / 2, columns u / 4; a chunk past the slice's width re-reads the last one
-    // (padding is allocated to a whole trip at the end of the arrays; see plan_sell)
+    // chunk index of nonzero u: values u / 2, columns u / 4.  The last trip of a slice may reach past its width: those
+    // chunks belong to the following slice (or to the whole trip of padding the arrays end with, see plan_sell) and are
+    // never used -- the row walk masks by the row's length
     const int64_t vb = (int64_t)d.voff + ((int64_t)(u0 >> 1) * 64 + lane) * 2;
     const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 2) * 64 + lane) * 4;
 #pragma unroll
@@ -87,16 +88,33 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
 
     Trip cur, nxt;
     SDesc d = {0, 0, 0, 0, 0, 0}, dn = {0, 0, 0, 0, 0, 0};
+    int ip0 = 0, ip1 = 0;                  // row pointers of the lane's row in the CURRENT slice (requested a slice ahead)
     if (t < nslices) {
         d = read_sdesc(slices, t);
         load_trip(A, d, 0, lane, cur);
+        const int r0 = d.rb + lane < d.re ? d.rb + lane : d.rb;
+        ip0 = A.indptr[r0]; ip1 = A.indptr[r0 + 1];
         if (t + W < nslices) dn = read_sdesc(slices, t + W);
     }
     while (t < nslices) {
         const int row = d.rb + lane;
         const bool active = row < d.re;
         const int rr = active ? row : d.rb;
-        const int len = active ? A.indptr[rr + 1] - A.indptr[rr] : 0;
+        const int len = active ? ip1 - ip0 : 0;
+        // requested now, used at the end of the slice: the next slice's row pointers and, for the fused iteration, the
+        // row's own operands (the row walk covers their latency)
+        if (t + W < nslices) {
+            const int rn = dn.rb + lane < dn.re ? dn.rb + lane : dn.rb;
+            ip0 = A.indptr[rn]; ip1 = A.indptr[rn + 1];
+        }
+        FusedRowIn q;
+        V own; vzero(own);
+        if constexpr (epi_fused(EPI)) {
+            q.xp = fr.XP[rr];
+            own = X[rr];
+            if constexpr (epi_prec(EPI)) { q.rs = fr.RS[rr]; q.d = fr.D[rr]; }
+            if constexpr (!epi_recompute(EPI)) { q.w = fr.W[rr]; if constexpr (epi_prec(EPI)) q.wt = fr.WT[rr]; }
+        }
         V sum; vzero(sum);
         for (int u0 = 0; u0 < d.width; u0 += 8) {                            // wave-uniform trip count
             // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
@@ -117,7 +135,11 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
             cur = nxt;
         }
         if (d.width == 0 && t + W < nslices) load_trip(A, dn, 0, lane, cur);
-        if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
+        if constexpr (epi_fused(EPI)) {
+            if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
+        } else {
+            if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
+        }
         t += W;
         d = dn;
         if (t + W < nslices) dn = read_sdesc(slices, t + W);
@@ -142,7 +164,7 @@ int sell_grid(K kernel, int nslices, int per_cu) {
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
         }
-        if (occ > 4) occ = 4;
+        if (occ > 2) occ = 2;      // (s4b: 2 workgroups per CU 3955 it/s, 3: 3840, 4: 3813 -- more requests in flight cost bandwidth)
         cached = occ * 1024 + cus;
     }
     int occ = cached / 1024;

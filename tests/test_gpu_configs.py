@@ -435,14 +435,15 @@ def test_short_window_source_is_refused_not_faulted(amd):
 
 @pytest.mark.gpu
 def test_sliced_row_kernels_on_randomised_medium_rows(amd):
-    """The lane-per-row kernels over 64-row slices (prcg_sell.hip; FEM-like operators, config 5): ragged rows of 0..120
-    nonzeros, unsorted and duplicate indices, empty rows, +-0 / inf / nan values, a row block with ghost columns -- the
+    """The lane-per-row kernels over 64-row slices (prcg_sell.hip; FEM-like operators, config 5): ragged rows of 8..125
+    nonzeros (within a quarter of each other: the padding bound), unsorted and duplicate indices, empty rows, +-0 / inf / nan values, a row block with ghost columns -- the
     products are scipy's csr_matvec bit for bit, and bit for bit what the CSR-adaptive kernels (PRCG_SELL=0) give."""
     rng = np.random.default_rng(77)
     for trial in range(4):
         n = int(rng.integers(3000, 20000))
-        lens = rng.integers(0, 121, size=n)
-        lens[rng.integers(0, n, size=n // 50)] = 0
+        lo_len = (64, 100, 8, 81)[trial]
+        lens = rng.integers(lo_len, lo_len + lo_len // 4 + 1, size=n)      # (slices are padded to their longest row: <= 25 % overhead)
+        lens[rng.integers(0, n, size=n // 100)] = 0
         if trial == 3:
             lens[:] = 81                                      # every row full: no padding, no masked slot
         indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -520,7 +521,12 @@ def test_sliced_row_kernels_run_every_schedule_of_the_tile_kernels(amd, variant,
         for op in ops:
             op.iterate(1)
         for v in stored:
-            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
+            if variant == 'CG_CG' and v in ('p', 's'):
+                # Chronopoulos-Gear: b = nu_k / nu_k1 with nu_k summed by the product launch itself (slice by slice here,
+                # tile by tile there): p and s inherit b's rounding
+                np.testing.assert_allclose(ops[0].get_vector(v), ops[1].get_vector(v), rtol=1e-11, atol=1e-16, err_msg=f'{k} {v}')     # (an entry that cancels to ~1e-4 of its terms)
+            else:
+                assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
         a, c = ops[0].get_scalars(k + 1)[:5], ops[1].get_scalars(k + 1)[:5]
         nz = c != 0
         worst = max(worst, float(np.max(np.abs(a[nz] - c[nz]) / np.abs(c[nz]))))
