@@ -370,6 +370,14 @@ def main():
                                    'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg, 'rccl_schedule': rccl_leg,
                                    'single_gpu_us_per_iteration': elapsed / K * 1e6,
                                    'speedup_ceiling_at_8_ranks': (elapsed / K * 1e6) / leg['us_per_iteration'] if leg['us_per_iteration'] > 0 else None}
+                if plain is not None:
+                    # the same for an operator whose values do not repeat (value dictionary off): more bytes per rank and iteration
+                    # against the same fixed costs
+                    legp = comm_leg(A8_loop, halo8, b8, x8, d8, {'PRCG_VALDICT': '0'})
+                    multi['s3_8th']['plain_values'] = {
+                        'comm_us_per_iteration': legp['us_per_iteration'], 'comm': legp,
+                        'single_gpu_us_per_iteration': plain[0] / K * 1e6,
+                        'speedup_ceiling_at_8_ranks': (plain[0] / K * 1e6) / legp['us_per_iteration'] if legp['us_per_iteration'] > 0 else None}
         except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it
             multi = dict(multi or {}, error=str(exc)[:300])
 

@@ -14,10 +14,15 @@ Differences, all at the edges:
   other callable in ``callbacks`` is still honoured, called after every iteration with
   the reference's local names (``x_k``, ``r_k``, ``nu_k`` ...), at the price of a
   device->host copy of the state per iteration;
-* ``preconditioner`` may be any callable that acts as a *diagonal* scaling (the
-  reference's Jacobi lambda ``(1/A.diagonal())*x``, figure_gen.py:43, or the identity
-  default); it is probed once to recover the diagonal.  Anything else raises
-  NotImplementedError: this package has no host solver to fall back to.
+* ``preconditioner``: a callable that acts as a *diagonal* scaling (the reference's Jacobi
+  lambda ``(1/A.diagonal())*x``, figure_gen.py:43, or the identity default) is probed once
+  to recover the diagonal and then applied on the device; any other callable is the
+  caller's code, as it is in the reference, and is called on the host wherever the reference
+  calls ``preconditioner(...)`` (prcg.h: prcg_set_preconditioner) while products, updates
+  and inner products stay on the device;
+* with an error recorder and no ``x_true`` the reference solves for it with a sparse direct
+  solver on the fly (callbacks/error_A_norm.py:36-39); that is done here too up to n = 200,000
+  -- beyond that it would never return, so the call asks for ``x_true`` instead.
 """
 from collections import OrderedDict
 
@@ -29,6 +34,7 @@ from ..device import DeviceCSR
 
 _OPERATORS = OrderedDict()   # small cache: figure_gen runs nine variants on one matrix
 _MAX_CACHED = 2
+_MAX_DIRECT_SOLVE = 200_000   # largest system solved on the host for a missing x_true (the reference's on-the-fly spsolve)
 
 
 def _fingerprint(A):
@@ -124,7 +130,6 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
     if A.format != 'csr':
         A = A.tocsr()
     n = A.shape[0]
-    op = _operator(A, device)
     inv_diag, prec_fn = _diagonal_of(preconditioner, n)
 
     mask = 0
@@ -141,10 +146,14 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
     x_true = kwargs.get('x_true')
     if (mask & (L.HIST_ERROR_A_NORM | L.HIST_ERROR_2_NORM)) and x_true is None:
         # the reference solves for it on the fly (callbacks/error_A_norm.py:36-39)
+        if n > _MAX_DIRECT_SOLVE:
+            raise ValueError(f'error_A_norm / error_2_norm need x_true: solving the n = {n} system with a sparse direct solver on the '
+                             f'host to obtain it (as the reference would) is not feasible beyond n = {_MAX_DIRECT_SOLVE}; pass x_true=')
         import scipy.sparse.linalg as spla
         x_true = spla.spsolve(A.tocsc().astype(np.double), np.asarray(b, dtype=np.double))
         kwargs['x_true'] = x_true
 
+    op = _operator(A, device)
     output = {'name': name, 'max_iter': max_iter}
     op.begin(variant, b, x0, max_iter, x_true=x_true, inv_diag=inv_diag, hist_mask=mask, preconditioner=prec_fn)
 

@@ -1444,7 +1444,9 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     // a lane each -- assembled FEM matrices -- when the padding to the slices' longest rows stays below 25 % ---
     h->sell = false; h->nst_int = h->nst_bnd = 0;
     SellPlan sp;
-    if (!h->win && h->want_sell && n_rows >= 64 && nnz >= 8 * n_rows)
+    // (rows of 24 nonzeros and more: shorter rows that are no window operator keep the CSR-adaptive kernels with their
+    //  narrow column / value encodings -- a lane per row pays once a row is a sizeable share of a tile)
+    if (!h->win && h->want_sell && n_rows >= 64 && nnz >= 24 * n_rows)
         h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, 1.25, sp);
     const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels
 

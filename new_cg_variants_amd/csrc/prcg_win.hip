@@ -641,8 +641,11 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
 // updates and carries on in the fused form -- the GPU counterpart of VecDotBegin ... KSP_MatMult ...
 // VecDotEnd (scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173) inside ONE launch.  The wait is
 // bounded; a timeout sets *err and lets the wave continue (wrong numbers, never a hang).
+// (the deferred dictionary kernels of the 64-row geometries are asked to fit four workgroups per CU -- 128 VGPRs: they
+//  are bound by what one wave can overlap, and a few spilled scalars cost less than a quarter of the resident waves)
+constexpr int win_min_blocks(int m, bool vd, int def) { return (def > 0 && vd && m == 1) ? 4 : 1; }
 template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH, int DEF = 0>
-__global__ __launch_bounds__(64 * WPB) void k_win_tiles(
+__global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_tiles(
     WinDev A, const int4* __restrict__ wt, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,

@@ -352,3 +352,15 @@ def test_preconditioner_routing_diagonal_on_device_anything_else_by_callback():
     assert fn is None and np.array_equal(got, 1 / (1 / d))
     with pytest.raises(ValueError):
         cgv._diagonal_of(lambda v: v[:-1], n)
+
+
+def test_missing_x_true_is_refused_for_large_systems():
+    """The reference obtains a missing x_true with a sparse direct solve inside its error callbacks
+    (callbacks/error_A_norm.py:36-39); beyond n = 200,000 that never returns -- the drop-in asks for x_true instead
+    (checked before any device work, so this runs without a GPU)."""
+    from new_cg_variants_amd import cg_variants
+    from new_cg_variants_amd.callbacks import error_A_norm
+    A = problems.laplace_2d(500, 500)
+    assert A.shape[0] > cg_variants._MAX_DIRECT_SOLVE
+    with pytest.raises(ValueError, match='x_true'):
+        cg_variants.pipe_pr_cg(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), 5, callbacks=[error_A_norm])

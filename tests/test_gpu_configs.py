@@ -435,13 +435,13 @@ def test_short_window_source_is_refused_not_faulted(amd):
 
 @pytest.mark.gpu
 def test_sliced_row_kernels_on_randomised_medium_rows(amd):
-    """The lane-per-row kernels over 64-row slices (prcg_sell.hip; FEM-like operators, config 5): ragged rows of 8..125
+    """The lane-per-row kernels over 64-row slices (prcg_sell.hip; FEM-like operators, config 5): ragged rows of 28..125
     nonzeros (within a quarter of each other: the padding bound), unsorted and duplicate indices, empty rows, +-0 / inf / nan values, a row block with ghost columns -- the
     products are scipy's csr_matvec bit for bit, and bit for bit what the CSR-adaptive kernels (PRCG_SELL=0) give."""
     rng = np.random.default_rng(77)
     for trial in range(4):
         n = int(rng.integers(3000, 20000))
-        lo_len = (64, 100, 8, 81)[trial]
+        lo_len = (64, 100, 28, 81)[trial]
         lens = rng.integers(lo_len, lo_len + lo_len // 4 + 1, size=n)      # (slices are padded to their longest row: <= 25 % overhead)
         lens[rng.integers(0, n, size=n // 100)] = 0
         if trial == 3:
