@@ -200,6 +200,12 @@ struct prcg_handle {
     DevBuf w2;
     bool cg_fused = false;       // Chronopoulos-Gear / Ghysels-Vanroose on a window operator: two launches (product with the window formed as
                                  // r - a s; p, s update that sums the product's partials itself); r double-buffered (cur_r)
+    bool cg_one = false;         // ... in ONE launch per iteration (launch_win_cg_one): the p, s (u) update of an iteration is deferred into the next
+                                 // launch's window formation; s (cg) / t, u (gv) double-buffered as well
+    bool cg_lag = false;         // ... and the update of iteration pend_k is pending (its partials: pend_buf / pend_parts)
+    bool want_cg_one = true;     // PRCG_CG_ONE=0: the two-launch schedule
+    double* cur_u = nullptr; double* cur_t = nullptr;      // (cur_s: above)
+    DevBuf u2, t2;
     bool hs_fused = false;       // Hestenes-Stiefel without reduction launches: 2 launches per iteration on window
                                  // operators (update; product with the direction formed in the staged window), else 3
     double* p_cur = nullptr;     // ... the current direction: p / p2 (the product launch writes the other one)
@@ -273,7 +279,7 @@ struct prcg_handle {
     // every vector a window launch may stage (the pointer handed to the launch lies inside one of them)
     const DevBuf* owner(const void* q) const {
         const DevBuf* all[] = {&tmp_ext, &t1, &x, &xp, &p, &p2, &rs, &rs2, &rst, &rst2, &wu, &wt, &wv, &r, &r2, &s, &s2, &rt, &rt2,
-                               &st, &st2, &b, &xt, &dinv, &e_ext, &w, &w2, &u, &tvec, &ut, &cb_stage};
+                               &st, &st2, &b, &xt, &dinv, &e_ext, &w, &w2, &u, &u2, &tvec, &t2, &ut, &cb_stage};
         const char* c = static_cast<const char*>(q);
         for (const DevBuf* d : all)
             if (d->p && c >= static_cast<const char*>(d->p) && c < static_cast<const char*>(d->p) + d->bytes) return d;
@@ -516,6 +522,7 @@ double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride
 
 void fused_flush(prcg_t* h);
 void hs_flush(prcg_t* h);
+void cg_flush(prcg_t* h);
 int apply_prec(prcg_t* h, const double* src, int sstride, double* dst, int dstride);
 
 // ---- history recorders for the state of iteration k (compute stream) -------------------
@@ -525,6 +532,7 @@ int record(prcg_t* h, int k) {
     if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
     if (h->hs_fused) hs_flush(h);
     if (h->pr_fused) fused_flush(h);
+    if (h->cg_one) cg_flush(h);
     if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     if (h->peer && h->pend_parts > 0) {
         // (peer exchange: the last launch's partials are still to be sent by the next launch's communication wave -- the
@@ -1022,10 +1030,10 @@ CgArgs cg_args(prcg_t* h, int k) {
     a.n = h->n;
     a.x = h->x.d(); a.r = h->cur_r; a.rt = h->prec ? h->rt.d() : nullptr;
     a.w = h->cur_w; a.wt = h->prec ? h->wt.d() : nullptr;
-    a.p = h->p.d(); a.s = h->s.d();
+    a.p = h->p.d(); a.s = h->cur_s;
     a.st_ = (h->prec && h->variant == PRCG_GV) ? h->st.d() : nullptr;
-    a.u = h->variant == PRCG_GV ? h->u.d() : nullptr;
-    a.t = h->tvec.d();
+    a.u = h->variant == PRCG_GV ? h->cur_u : nullptr;
+    a.t = h->cur_t;
     a.z = h->prec ? h->rt.d() : h->cur_r;
     a.d = (h->prec && !h->cb_session) ? h->dinv.d() : nullptr;
     a.dots_prev = k > 0 ? dots_at(h, k - 1) : dots_at(h, 0);
@@ -1083,6 +1091,56 @@ int iterate_gv_fused(prcg_t* h, int k) {
     prof_begin(h, h->ev_upd, h->n_ev_upd, k, on);
     LAUNCHCHK(h, launch_cg_update_ps(h->sc, cg_args(h, k), h->partB.d(), grid));
     prof_end(h, h->ev_upd, h->n_ev_upd, on);
+    return PRCG_OK;
+}
+
+// close the iteration whose p, s (u) update is still pending (one-launch Chronopoulos-Gear / Ghysels-Vanroose): what the
+// next launch would do while forming its window, as a launch of its own -- at the end of a prcg_iterate call, before a recorder
+void cg_flush(prcg_t* h) {
+    if (!h->cg_lag) return;
+    if (h->prec) launch_mul(h->sc, h->rt.d(), 1, h->dinv.d(), 1, h->cur_r, 1, h->n);        // r~ = M^-1 r (the launches keep it in registers)
+    (void)launch_cg_update_ps(h->sc, cg_args(h, h->pend_k), h->pend_buf, h->pend_parts);
+    h->cg_lag = false;
+    h->pend_parts = 0;
+}
+
+// ONE launch per iteration of Chronopoulos-Gear / Ghysels-Vanroose on a window operator (launch_win_cg_one): the launch of
+// iteration k closes iteration k-1 in its prologue (b, mu, a from that launch's partials) and applies its p, s (u) update
+// while forming the window -- the new residual (new w) expressed in old vectors.
+int iterate_cg_one(prcg_t* h, int k) {
+    const bool gv = h->variant == PRCG_GV;
+    if (h->cg_lag && h->pend_k != k - 1) cg_flush(h);
+    FusedPrev f{};
+    if (h->cg_lag) {
+        f.prev_partials = h->pend_buf; f.nprev = h->pend_parts;
+        f.dots_prev_out = dots_at(h, k - 1); f.dots_old = dots_at(h, k - 2); f.lag.coef_prev = coef_at(h, k - 1);
+    } else {
+        f.dots_old = dots_at(h, k - 1);
+    }
+    auto other = [](double* cur, DevBuf& a, DevBuf& b) { return cur == a.d() ? b.d() : a.d(); };
+    double *z0n, *z1n, *z2n;
+    if (gv) {
+        f.lag.z0 = h->cur_w; f.lag.z1 = h->cur_t; f.lag.z2 = h->cur_u;
+        z0n = other(h->cur_w, h->w, h->w2); z1n = other(h->cur_t, h->tvec, h->t2); z2n = other(h->cur_u, h->u, h->u2);
+        f.lag.r = h->r.d(); f.lag.s = h->s.d();
+    } else {
+        f.lag.z0 = h->cur_r; f.lag.z1 = h->cur_w; f.lag.z2 = h->cur_s;
+        z0n = other(h->cur_r, h->r, h->r2); z1n = other(h->cur_w, h->w, h->w2); z2n = other(h->cur_s, h->s, h->s2);
+        f.lag.d = h->prec ? h->dinv.d() : nullptr;
+    }
+    f.lag.z0n = z0n; f.lag.z1n = z1n; f.lag.z2n = z2n;
+    f.lag.x = h->x.d(); f.lag.p = h->p.d();
+    double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
+    SRCCHK2(h, {f.lag.z0, 1}, {f.lag.z1, 1}, {f.lag.z2, 1}, {f.lag.d, 1});
+    bool on = false;
+    prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
+    const int grid = launch_win_cg_one(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f, gv ? 1 : 0, part_out,
+                                       coef_at(h, k), h->win_per_cu);
+    LAUNCHCHK(h, grid);
+    prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+    if (gv) { h->cur_w = z0n; h->cur_t = z1n; h->cur_u = z2n; }
+    else { h->cur_r = z0n; h->cur_w = z1n; h->cur_s = z2n; }
+    h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out; h->cg_lag = true;
     return PRCG_OK;
 }
 
@@ -1156,6 +1214,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_FUSED_COMM") { h->want_fused_comm = v != 0; h->want_fused_comm_rccl = v != 0; }
     else if (k == "PRCG_PEER") h->want_peer = v != 0;
     else if (k == "PRCG_SELL") h->want_sell = v != 0;
+    else if (k == "PRCG_CG_ONE") h->want_cg_one = v != 0;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1170,7 +1229,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1232,9 +1291,9 @@ bool locate(prcg_t* h, int which, double** base, int* stride) {
         case PRCG_VEC_X: *base = h->x.d(); return true;
         case PRCG_VEC_P: *base = h->p.d(); return true;
         case PRCG_VEC_R: *base = h->cur_r; return true;
-        case PRCG_VEC_S: *base = h->s.d(); return true;
+        case PRCG_VEC_S: *base = h->cur_s; return true;
         case PRCG_VEC_W: *base = h->cur_w; return true;
-        case PRCG_VEC_U: if (v != PRCG_GV) return false; *base = h->u.d(); return true;
+        case PRCG_VEC_U: if (v != PRCG_GV) return false; *base = h->cur_u; return true;
         case PRCG_VEC_RT: if (!h->prec) return false; *base = h->rt.d(); return true;
         case PRCG_VEC_WT: if (!h->prec || v != PRCG_GV) return false; *base = h->wt.d(); return true;
         case PRCG_VEC_ST: if (!h->prec || v != PRCG_GV) return false; *base = h->st.d(); return true;
@@ -2066,8 +2125,16 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
         h->cur_r = h->r.d();
         h->cg_fused = h->want_fused && !h->multi() && h->g == 0 && h->win && !h->cb_session;
+        // one launch per iteration: both variants unpreconditioned, Chronopoulos-Gear with Jacobi too
+        h->cg_one = h->cg_fused && h->want_cg_one && (variant == PRCG_CG_CG || !h->prec);
+        h->cg_lag = false;
         HIPCHK(h, h->r2.ensure((h->cg_fused && variant == PRCG_CG_CG) ? (size_t)ne * D : 16, h->sc));
-        HIPCHK(h, h->w2.ensure((h->cg_fused && variant == PRCG_GV) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->w2.ensure((h->cg_fused && (variant == PRCG_GV || h->cg_one)) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->s2.ensure((h->cg_one && variant == PRCG_CG_CG) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->u2.ensure((h->cg_one && variant == PRCG_GV) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->t2.ensure((h->cg_one && variant == PRCG_GV) ? (size_t)ne * D : 16, h->sc));
+        HIPCHK(h, h->partC.ensure(h->cg_one ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
+        h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         HIPCHK(h, h->rt.ensure(h->prec ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->w.ensure((size_t)ne * D, h->sc));
         h->cur_w = h->w.d();
@@ -2075,7 +2142,8 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->s.ensure((size_t)ne * D, h->sc));
         HIPCHK(h, h->st.ensure(h->prec ? (size_t)n * D : 16, h->sc));
         HIPCHK(h, h->u.ensure((size_t)ne * D, h->sc));      // (a window source of the Ghysels-Vanroose product launch)
-        HIPCHK(h, h->tvec.ensure((size_t)n * D, h->sc));
+        HIPCHK(h, h->tvec.ensure((size_t)ne * D, h->sc));   // (... of its one-launch form)
+        h->cur_s = h->s.d(); h->cur_u = h->u.d(); h->cur_t = h->tvec.d();
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x      cg_cg.py:23
         if (h->prec && (rc = apply_prec(h, h->r.d(), 1, h->rt.d(), 1))) return rc;   // r~ = M^-1 r   :89
         double* z = h->prec ? h->rt.d() : h->r.d();
@@ -2201,6 +2269,7 @@ int prcg_iterate(prcg_t* h, int iters) {
         int rc;
         if (is_pipe(h->variant)) rc = iterate_pipe(h, k);
         else if (h->variant == PRCG_HS) rc = h->hs_fused ? iterate_hs_fused(h, k) : iterate_hs(h, k);
+        else if (is_cg_family(h->variant) && h->cg_one) rc = iterate_cg_one(h, k);
         else if (h->variant == PRCG_CG_CG) rc = h->cg_fused ? iterate_cgcg_fused(h, k) : iterate_cgcg(h, k);
         else if (h->variant == PRCG_GV) rc = h->cg_fused ? iterate_gv_fused(h, k) : iterate_gv(h, k);
         else rc = h->pr_fused ? iterate_pr_fused(h, k) : iterate_pr(h, k);
@@ -2211,6 +2280,7 @@ int prcg_iterate(prcg_t* h, int iters) {
     if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
     if (h->hs_fused) hs_flush(h);
     if (h->pr_fused) fused_flush(h);
+    if (h->cg_one) cg_flush(h);
     if (h->fused_comm && h->red_pending) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration
         HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));

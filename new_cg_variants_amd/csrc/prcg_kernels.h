@@ -78,6 +78,15 @@ struct FusedPrev {
         double* x; double* r; double* s; const double* d;
         double* rt; const double* st;      // Ghysels-Vanroose with Jacobi: r~ (updated in place) and s~ of the row
     } pr;
+    // ONE launch per iteration of Chronopoulos-Gear / Ghysels-Vanroose (launch_win_cg_one): the p, s (u) update of the
+    // previous iteration is deferred INTO this launch -- see the comment there.  z0, z1, z2: the three old vectors the
+    // window is formed from (cg: r, w, s; gv: w, t, u), z?n their new buffers (other tiles still stage the old ones);
+    // x, p (and r, s for gv) in place; d: inverse diagonal or null; coef_prev: where a, b of the previous iteration go.
+    struct Lag {
+        const double* z0; const double* z1; const double* z2;
+        double* z0n; double* z1n; double* z2n;
+        double* x; double* p; double* r; double* s; const double* d; double* coef_prev;
+    } lag;
 };
 // State of the one-launch pipelined iteration (pipe_pr_cg.py:61-75 unpreconditioned, :169-187 Jacobi):
 // the two-vector product of the SpMM input pair array `in_old` with the NEXT vector update applied row
@@ -114,12 +123,16 @@ enum SpmvEpilogue {
     kEpiCGWJ = 12,   // ... with Jacobi: d (r - a s)
     kEpiGVW = 13,    // window kernels only: Ghysels-Vanroose product launch, window formed as w - a u (launch_win_gv_w)
     kEpiGVWJ = 14,   // ... with Jacobi: d (w - a u)
+    kEpiCGOne = 15,  // window kernels only: ONE launch per Chronopoulos-Gear iteration (launch_win_cg_one)
+    kEpiCGOneJ = 16, // ... with Jacobi
+    kEpiGVOne = 17,  // window kernels only: ONE launch per Ghysels-Vanroose iteration (unpreconditioned)
 };
 constexpr bool epi_pr_one(int e) { return e == kEpiPROne || e == kEpiPROneJ; }
 constexpr bool epi_cg_w(int e) { return e == kEpiCGW || e == kEpiCGWJ; }
 constexpr bool epi_gv_w(int e) { return e == kEpiGVW || e == kEpiGVWJ; }
 // the launches that form their window from several old vectors and update the row's own vectors (FusedPrev::PrOne)
 constexpr bool epi_rowset(int e) { return epi_pr_one(e) || epi_cg_w(e) || epi_gv_w(e); }
+constexpr bool epi_lag(int e) { return e == kEpiCGOne || e == kEpiCGOneJ || e == kEpiGVOne; }
 constexpr bool epi_fused(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedP || e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_prec(int e) { return e == kEpiPipeFusedJ || e == kEpiPipeFusedPJ; }
 constexpr bool epi_recompute(int e) { return e == kEpiPipeFused || e == kEpiPipeFusedJ; }
@@ -260,6 +273,20 @@ int launch_win_cg_w(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
 // f.pr: z_old = w, zs_old = u, p_old = p, z_new = the other w buffer, zs_new = w~, x, r, s, d, rt, st.
 int launch_win_gv_w(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f,
                     double* t_out, double* partials, double* coef_out, int per_cu);
+// ONE launch per iteration of Chronopoulos-Gear (cg_cg.py:59-68, cg_pcg :116-137) or Ghysels-Vanroose (gv_cg.py:65-81,
+// unpreconditioned).  Their reduction FOLLOWS the product it depends on, so an iteration cannot close inside its own
+// launch -- but its tail can move into the next one: launch k+1 sums launch k's partials (nu_k, eta_k) in its prologue,
+// derives b_k, mu_k = eta_k - (b_k / a_k1) nu_k and a_k = nu_k / mu_k, and applies the p, s (u) update of iteration k
+// while it forms its window, which is the NEW vector of iteration k+1 expressed in old ones:
+//   cg:  s_k = w + b s_old;  window  r_k1 = r - a (w + b s_old)   [times d];   w_k1 = A r~_k1
+//   gv:  u_k = t + b u_old;  window  w_k1 = w - a (t + b u_old);               t_k1 = A w_k1
+// (the reference's mul / add order: `w_k + b_k * s_k1` then `r_k1 - a_k1 * s_k1`).  The lane that summed row i writes
+// x, p, (r, s), the three new buffers and the partials eta (slot 1), nu (3), r.r (4).  f.nprev == 0: p, s (u) are
+// up to date (first launch of a call): no deferred update, a from f.dots_old = the complete scalars of the last
+// iteration; else f.dots_old = the scalars of the iteration BEFORE the one whose partials are pending and
+// f.dots_prev_out / f.lag.coef_prev receive that iteration's scalars and coefficients.  coef_out[0] = a.
+int launch_win_cg_one(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f, int gv,
+                      double* partials, double* coef_out, int per_cu);
 
 // ---- sliced rows: lane-per-row kernels for medium-length rows (prcg_sell.hip) -----------------
 // Planned on the host by plan_sell (prcg_plan.cpp): slices of up to 64 consecutive rows of one class; nonzero u of row

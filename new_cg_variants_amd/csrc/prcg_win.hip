@@ -94,12 +94,15 @@ template <> struct RegV<1> { using type = double; };
 template <> struct RegV<2> { using type = d2_t; };
 typedef double d3_t __attribute__((ext_vector_type(3)));
 template <> struct RegV<3> { using type = d3_t; };
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <> struct RegV<4> { using type = d4_t; };
 // components per staged window entry AS LOADED: the Hestenes-Stiefel product launch loads (z, p_old) and stages
 // p = z + b p_old as one double
 // (one-launch predict-and-recompute: (z, zs, p_old) -> p = (z - a zs) + b p_old)
 // (Chronopoulos-Gear product launch: (r, s[, d]) -> r~ = [d] (r - a s))
 constexpr int win_nw(int nv, int epi) {
-    return (epi == kEpiHS || epi == kEpiCGW || epi == kEpiGVW) ? 2 : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ) ? 3 : nv);
+    return (epi == kEpiHS || epi == kEpiCGW || epi == kEpiGVW) ? 2
+         : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ || epi == kEpiCGOne || epi == kEpiGVOne) ? 3 : (epi == kEpiCGOneJ ? 4 : nv));
 }
 template <int NV, int M, int PG, int CW, bool VD>
 struct WRegs {
@@ -113,6 +116,7 @@ struct WRegs {
     d2_t rsx[M];                        // ... Jacobi: the plain (r,s) of those rows
     double dd[M], ww[M], wwt[M];        // ... Jacobi: 1/diag; 'p' flavours: the stored w, w~
     d3_t zrow[M];                       // one-launch predict-and-recompute: (z, zs, p_old) of those rows; x in xp[].x, (r,s) in rsx[]
+    // one-launch Chronopoulos-Gear / Ghysels-Vanroose: (z0, z1, z2) of those rows in zrow[]; x in xp[].x, p in xp[].y, gv's (r,s) in rsx[], d in dd[]
 };
 
 // Row cache of the dictionary kernels.  Tiles whose stream images are SHARED (prcg_plan.h: share_window_streams --
@@ -150,7 +154,8 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                                             const typename VecT<NV>::type* __restrict__ X, const double* __restrict__ X2,
                                             const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
                                             WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false,
-                                            const typename VecT<NV>::type* G = nullptr, int n_own = 0) {
+                                            const typename VecT<NV>::type* G = nullptr, int n_own = 0,
+                                            const FusedPrev::Lag* lg = nullptr) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -192,6 +197,10 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             else if constexpr (epi_pr_one(EPI)) {
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane]; R.w[p].z = pr.p_old[d.pc[p] + lane];
             }
+            else if constexpr (epi_lag(EPI)) {
+                R.w[p].x = lg->z0[d.pc[p] + lane]; R.w[p].y = lg->z1[d.pc[p] + lane]; R.w[p].z = lg->z2[d.pc[p] + lane];
+                if constexpr (EPI == kEpiCGOneJ) R.w[p].w = lg->d[d.pc[p] + lane];
+            }
             else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) {
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane];
                 if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) R.w[p].z = pr.d[d.pc[p] + lane];
@@ -222,6 +231,12 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         if (!skip_img) {
             R.s[j] = A.rel[d.srcr + jj];                 // row pointers relative to the tile's first nonzero
             R.e[j] = A.rel[d.srcr + jj + 1];
+        }
+        if constexpr (epi_lag(EPI)) {
+            R.zrow[j].x = lg->z0[rr]; R.zrow[j].y = lg->z1[rr]; R.zrow[j].z = lg->z2[rr];
+            R.xp[j].x = lg->x[rr]; R.xp[j].y = lg->p[rr];
+            if constexpr (EPI == kEpiCGOneJ) R.dd[j] = lg->d[rr];
+            if constexpr (EPI == kEpiGVOne) { R.rsx[j].x = lg->r[rr]; R.rsx[j].y = lg->s[rr]; }
         }
         if constexpr (epi_rowset(EPI)) {
             R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr];
@@ -281,6 +296,7 @@ struct WCtx {
     // from this rank's exchange buffer (G = its ghost area of the iteration read, minus n_own), the rows the neighbours
     // need go to THEIR ghost areas of the iteration written (offset gout, in doubles, into every exchange buffer)
     const typename VecT<NV>::type* G; int n_own; const PeerDev* px; long long gout;
+    const FusedPrev::Lag* lg; bool lagged;      // one-launch Chronopoulos-Gear / Ghysels-Vanroose: vectors; a deferred p, s (u) update is pending
 };
 
 // One tile: park its image (R, requested DEPTH tiles ago) in LDS, request tile `dnext` into the
@@ -359,6 +375,13 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
             else if constexpr (epi_pr_one(EPI)) c.sw[p * 64 + lane] = (R.w[p].x - cf.al * R.w[p].y) + cf.bt * R.w[p].z;
             // Chronopoulos-Gear: r -= a s, r~ = M^-1 r (cg_cg.py:60, cg_pcg :117-118), formed here
             // (Ghysels-Vanroose: w -= a u, w~ = M^-1 w, gv_cg.py:67 / :155,161 -- the same form)
+            // one launch per Chronopoulos-Gear / Ghysels-Vanroose iteration: the deferred s = w + b s_old (u = t + b u_old) and
+            // then the new residual r - a s (new w - a u): mul, add, mul, sub as cg_cg.py:66,60 / gv_cg.py:79,67
+            else if constexpr (epi_lag(EPI)) {
+                const double z2n = c.lagged ? R.w[p].y + cf.bt * R.w[p].z : R.w[p].z;
+                const double v = R.w[p].x - cf.al * z2n;
+                if constexpr (EPI == kEpiCGOneJ) c.sw[p * 64 + lane] = R.w[p].w * v; else c.sw[p * 64 + lane] = v;
+            }
             else if constexpr (EPI == kEpiCGW || EPI == kEpiGVW) c.sw[p * 64 + lane] = R.w[p].x - cf.al * R.w[p].y;
             else if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) c.sw[p * 64 + lane] = R.w[p].z * (R.w[p].x - cf.al * R.w[p].y);
             else reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
@@ -370,6 +393,12 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         rs_[j] = R.s[j]; re_[j] = R.e[j];
+        if constexpr (epi_lag(EPI)) {
+            zr[j] = R.zrow[j];
+            fin[j].xp = make_double2(R.xp[j].x, R.xp[j].y);
+            if constexpr (EPI == kEpiCGOneJ) fin[j].d = R.dd[j];
+            if constexpr (EPI == kEpiGVOne) fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y);
+        }
         if constexpr (epi_rowset(EPI)) {
             zr[j] = R.zrow[j];
             fin[j].xp.x = R.xp[j].x;
@@ -400,7 +429,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first && !c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         next_same = same_image<PG>(rc, dnext);
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own, c.lg);
     }
 
     const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
@@ -565,6 +594,42 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                     acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
                 }
             }
+        } else if constexpr (EPI == kEpiCGOne || EPI == kEpiCGOneJ) {
+            // the row's own deferred p = r~ + b p, s = w + b s (cg_cg.py:65-66), then x += a p, r -= a s (:59-60), w = A r~ and
+            // the partials of eta = w.r~, nu = r.r~, r.r (:61-63)
+            if (active) {
+                const double zt_old = EPI == kEpiCGOneJ ? fin[j].d * zr[j].x : zr[j].x;      // r~ of the iteration being closed
+                const double pn = c.lagged ? zt_old + cf.bt * fin[j].xp.y : fin[j].xp.y;
+                const double sn = c.lagged ? zr[j].y + cf.bt * zr[j].z : zr[j].z;
+                const double xn = fin[j].xp.x + cf.al * pn;
+                const double rn = zr[j].x - cf.al * sn;
+                const double ztn = EPI == kEpiCGOneJ ? fin[j].d * rn : rn;
+                c.lg->x[row] = xn;
+                c.lg->p[row] = pn;
+                c.lg->z0n[row] = rn;
+                c.lg->z1n[row] = sum;
+                c.lg->z2n[row] = sn;
+                acc[3] += rn * ztn; acc[1] += sum * ztn; acc[4] += rn * rn;
+            }
+        } else if constexpr (EPI == kEpiGVOne) {
+            // the row's own deferred p = r + b p, s = w + b s, u = t + b u (gv_cg.py:77-79), then x += a p, r -= a s,
+            // w -= a u (:65-67), t = A w and the partials of eta = w.r, nu = r.r (:74-75)
+            if (active) {
+                const double pn = c.lagged ? fin[j].rs.x + cf.bt * fin[j].xp.y : fin[j].xp.y;
+                const double sn = c.lagged ? zr[j].x + cf.bt * fin[j].rs.y : fin[j].rs.y;
+                const double un = c.lagged ? zr[j].y + cf.bt * zr[j].z : zr[j].z;
+                const double xn = fin[j].xp.x + cf.al * pn;
+                const double rn = fin[j].rs.x - cf.al * sn;
+                const double wn = zr[j].x - cf.al * un;
+                c.lg->x[row] = xn;
+                c.lg->p[row] = pn;
+                c.lg->r[row] = rn;
+                c.lg->s[row] = sn;
+                c.lg->z0n[row] = wn;
+                c.lg->z1n[row] = sum;
+                c.lg->z2n[row] = un;
+                acc[3] += rn * rn; acc[1] += wn * rn; acc[4] += rn * rn;
+            }
         } else if constexpr (epi_cg_w(EPI)) {
             // the row's own x += a p, r -= a s, r~ = d r (cg_cg.py:59-60, :117-118), w = A r~ and the partials of
             // eta = w.r~, nu = r.r~, r.r (:61-63)
@@ -670,7 +735,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
                                   reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt, (write_mask & 8) != 0},
-                     fz.pr, lane, nullptr, 0, nullptr, 0};
+                     fz.pr, lane, nullptr, 0, nullptr, 0, &fz.lag, fz.nprev > 0};
     WCtx<NV>& cm = c;
     if constexpr (DEF > 0) {
         if (fz.px) {
@@ -704,6 +769,26 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
     }
 
+    if constexpr (epi_lag(EPI)) {
+        if (fz.nprev > 0) {
+            // the iteration whose partials are pending is closed here (what launch_cg_update_ps does in the two-launch
+            // schedule, same expressions): b = nu / nu_before, mu = eta - (b / a_before) nu (cg_cg.py:64,67), a = nu / mu
+            double m[5];
+            sum_prev_partials<5, WPB>(fz.prev_partials, fz.nprev, 0, m);
+            const double al_before = fz.dots_old[3] / fz.dots_old[0];
+            const double bt = m[3] / fz.dots_old[3];
+            const double mu = m[1] - (bt / al_before) * m[3];
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                fz.dots_prev_out[0] = mu; fz.dots_prev_out[1] = m[1]; fz.dots_prev_out[3] = m[3]; fz.dots_prev_out[4] = m[4];
+                fz.lag.coef_prev[0] = al_before; fz.lag.coef_prev[1] = bt;
+            }
+            cf.bt = bt;
+            cf.al = m[3] / mu;
+        } else {
+            cf.al = fz.dots_old[3] / fz.dots_old[0];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) aux[0] = cf.al;
+    }
     if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) {
         cf.al = fz.dots_old[3] / fz.dots_old[0];                            // a_k1 = nu_k1 / mu_k1   cg_cg.py:58
         if (blockIdx.x == 0 && threadIdx.x == 0) aux[0] = cf.al;
@@ -772,7 +857,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         same[i] = false;
         if (t + i * W < ntiles) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg);
             else pend[i] = true;
         }
     }
@@ -858,7 +943,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         if (pend[0]) {
             if (!acquired) { if (!fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
             same[0] = same_image<PG>(rc, d[0]);
-            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own);
+            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own, c.lg);
             pend[0] = false;
         }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -927,7 +1012,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
 
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
-    else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
+    else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI) || epi_lag(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI != kEpiNone) {
         double a3[3] = {acc[0], acc[1], acc[2]};
@@ -1150,6 +1235,17 @@ int launch_win_gv_w(hipStream_t st, const WinDev& A, const WTile* tiles, int nti
                                        per_cu);
     return launch_win<1, kEpiGVW>(geom, st, A, tiles, ntiles, f.pr.z_old, t_out, 3, nullptr, nullptr, nullptr, partials, coef_out, f,
                                   per_cu);
+}
+
+int launch_win_cg_one(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedPrev& f, int gv,
+                      double* partials, double* coef_out, int per_cu)
+{
+    if (ntiles <= 0) return 0;
+    if (gv)
+        return launch_win<1, kEpiGVOne>(geom, st, A, tiles, ntiles, f.lag.z0, f.lag.z1n, 3, nullptr, nullptr, nullptr, partials, coef_out, f, per_cu);
+    if (f.lag.d)
+        return launch_win<1, kEpiCGOneJ>(geom, st, A, tiles, ntiles, f.lag.z0, f.lag.z1n, 3, nullptr, f.lag.d, nullptr, partials, coef_out, f, per_cu);
+    return launch_win<1, kEpiCGOne>(geom, st, A, tiles, ntiles, f.lag.z0, f.lag.z1n, 3, nullptr, nullptr, nullptr, partials, coef_out, f, per_cu);
 }
 
 int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* rs, double* wu,

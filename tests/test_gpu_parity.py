@@ -526,6 +526,78 @@ def test_fused_and_two_kernel_schedules_agree(amd, matrices, matrix, variant, pr
     print(f'{matrix}/{variant}/{prec}: fused vs two-kernel, 40 forced steps, worst scalar deviation {worst:.2e}')
 
 
+@pytest.mark.parametrize('variant,source,prec,knobs', [
+    ('CG_CG', 'bcsstk03', None, {}), ('CG_CG', 'nos7', 'jacobi', {}), ('CG_CG', 's3_small', None, {'PRCG_VALDICT': '0'}),
+    ('CG_CG', 'lap3d_20', 'jacobi', {}), ('GV', 'bcsstk03', None, {}), ('GV', 'nos7', None, {}), ('GV', 's3_small', None, {}),
+    ('GV', 's1_small', None, {'PRCG_VALDICT': '0'})])
+def test_chronopoulos_gear_and_ghysels_vanroose_in_one_launch(amd, matrices, variant, source, prec, knobs):
+    """cg_cg / cg_pcg / gv_cg on a window operator run ONE launch per iteration: the launch of iteration k+1 closes iteration k in
+    its prologue (b, mu, a from that launch's partials: cg_cg.py:64,67-68) and applies its p, s (u) update while forming its
+    window -- the new residual r - a (w + b s) (gv: the new w - a (t + b u)), cg_cg.py:66,60 / gv_cg.py:79,67.  Two checks:
+    (i) the deferred form against the same kernels driven one iteration per call (every call closes its iteration with the
+    update launch): vectors, scalars, coefficients and histories of 60 iterations BIT FOR BIT -- deferring changes no
+    rounding; (ii) against the two-launch schedule (PRCG_CG_ONE=0) on forced single steps: vectors bit for bit, scalars to
+    1e-12 (another grid, another summation order of eta and nu)."""
+    L = amd['L']
+    if source in matrices:
+        A, z = matrices[source]
+        b, x_true = z['b'], z['x_true']
+    else:
+        A = amd['problems'].laplace_3d(20, 20, 20) if source == 'lap3d_20' else amd['problems'].WORKLOADS[source]['make']()
+        b, _, x_true = amd['problems'].reference_rhs(A, A.shape[0])
+    n = A.shape[0]
+    inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
+    var = getattr(L, variant)
+    names = ['x', 'r', 'p', 's', 'w'] + (['u'] if variant == 'GV' else []) + (['rt'] if prec else [])
+    iters = 60
+    runs = []
+    for chunks in ([1] * iters, [iters], [7, 1, 30, 22]):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        op.begin(var, b, np.zeros(n), iters + 1, x_true=x_true, inv_diag=inv_diag, hist_mask=1)
+        s = op.schedule()
+        if not (s['window'] and s['fused']):
+            op.close()
+            pytest.skip(f'{source} is no window operator')
+        for c in chunks:
+            op.iterate(c)
+        op.sync()
+        runs.append(({v: op.get_vector(v) for v in names}, np.array([op.get_scalars(k) for k in range(iters + 1)]),
+                     np.array([op.get_coefficients(k) for k in range(1, iters + 1)]), op.history()['updated_residual_2_norm']))
+        op.close()
+    for other in runs[1:]:
+        for v in names:
+            assert np.array_equal(other[0][v], runs[0][0][v], equal_nan=True), v
+        assert np.array_equal(other[1][:, :5], runs[0][1][:, :5], equal_nan=True)
+        assert np.array_equal(other[2][:, :2], runs[0][2][:, :2], equal_nan=True)
+        assert np.array_equal(other[3], runs[0][3], equal_nan=True)
+    # (ii) forced steps against the two-launch schedule
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_CG_ONE=f)) for f in ('1', '0')]
+    for op in ops:
+        op.begin(var, b, np.zeros(n), 48, inv_diag=inv_diag)
+    stored = ['x', 'r', 'p', 's', 'w'] + (['u'] if variant == 'GV' else []) + (['rt'] if prec else [])
+    worst = 0.0
+    for k in range(30):
+        st = {v: ops[1].get_vector(v) for v in stored}
+        sc = ops[1].get_scalars(k)
+        for v, a in st.items():
+            ops[0].set_vector(v, a)
+        ops[0].set_scalars(k, sc)
+        ops[0].set_iteration(k)
+        for op in ops:
+            op.iterate(1)
+        for v in ('x', 'r', 'w'):
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v), equal_nan=True), (k, v)
+        for v in ('p', 's') + (('u',) if variant == 'GV' else ()):          # inherit b's rounding
+            np.testing.assert_allclose(ops[0].get_vector(v), ops[1].get_vector(v), rtol=1e-11, atol=1e-300, err_msg=f'{k} {v}')
+        a, c = ops[0].get_scalars(k + 1)[:5], ops[1].get_scalars(k + 1)[:5]
+        nz = c != 0
+        worst = max(worst, float(np.max(np.abs(a[nz] - c[nz]) / np.abs(c[nz]))))
+    assert worst <= 1e-12, worst
+    for op in ops:
+        op.close()
+    print(f'{source}/{variant}/{prec}: one launch per iteration, deferred update bit-identical to per-call closing; vs two launches worst scalar deviation {worst:.1e}')
+
+
 @pytest.mark.parametrize('variant', ['CG_CG', 'GV'])
 @pytest.mark.parametrize('source,prec,knobs', [
     ('bcsstk03', None, {}), ('nos7', 'jacobi', {}), ('494_bus', 'jacobi', {}), ('s3_small', None, {'PRCG_VALDICT': '0'}),
@@ -684,7 +756,7 @@ def test_one_launch_predict_and_recompute(amd, matrices, source, variant, prec, 
         b, _, x_true = amd['problems'].reference_rhs(A, A.shape[0])
     n = A.shape[0]
     inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
-    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f, PRCG_CG_ONE='0')) for f in ('1', '0')]
     for op in ops:
         op.begin(getattr(L, variant), b, np.zeros(n), 64, inv_diag=inv_diag)
     assert ops[0].schedule()['fused'] and ops[0].schedule()['window'] and not ops[1].schedule()['fused']
