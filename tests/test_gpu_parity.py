@@ -619,7 +619,7 @@ def test_chronopoulos_gear_and_ghysels_vanroose_in_two_launches(amd, matrices, s
         b, _, x_true = amd['problems'].reference_rhs(A, A.shape[0])
     n = A.shape[0]
     inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
-    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f, PRCG_CG_ONE='0')) for f in ('1', '0')]      # (the TWO-launch schedule)
     var = getattr(L, variant)
     for op in ops:
         op.begin(var, b, np.zeros(n), 64, inv_diag=inv_diag)
@@ -756,7 +756,7 @@ def test_one_launch_predict_and_recompute(amd, matrices, source, variant, prec, 
         b, _, x_true = amd['problems'].reference_rhs(A, A.shape[0])
     n = A.shape[0]
     inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
-    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f, PRCG_CG_ONE='0')) for f in ('1', '0')]
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
     for op in ops:
         op.begin(getattr(L, variant), b, np.zeros(n), 64, inv_diag=inv_diag)
     assert ops[0].schedule()['fused'] and ops[0].schedule()['window'] and not ops[1].schedule()['fused']
