@@ -244,6 +244,11 @@ def main():
             return spmm2_bytes(n, nnz), 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
         if sched['fused'] and vname == 'pr_cg':
             return spmv_bytes(n, nnz) + 48 * n, 'one-launch predict-and-recompute iteration (k_win_tiles<1,PROne>)'
+        if sched['fused'] and sched['window'] and vname in ('cg_cg', 'gv_cg') and os.environ.get('PRCG_CG_ONE', '1') != '0':
+            # window of three old vectors instead of one input vector (+16 n), the row's x, p (r, s) and three new vectors
+            extra = {'cg_cg': 16 + 2 * 16 + 3 * 8, 'gv_cg': 16 + 4 * 16 + 3 * 8}[vname]
+            return spmv_bytes(n, nnz) - 8 * n + extra * n, ('one launch per ' + ('Chronopoulos-Gear' if vname == 'cg_cg' else 'Ghysels-Vanroose') +
+                                                         ' iteration, deferred p, s update (k_win_tiles<1,' + ('CGOne' if vname == 'cg_cg' else 'GVOne') + '>)')
         return spmv_bytes(n, nnz), 'SpMV launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
 
     def summarize(vname, dev, elapsed, tim, finite, n, nnz):
