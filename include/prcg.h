@@ -290,6 +290,17 @@ int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const
  * window operator, -1 on a bad argument.  Exported for the CPU tests. */
 int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
                             const uint8_t* row_class, int rows_per_tile, int share, int64_t* out);
+/* Sliced rows (lane-per-row kernels for operators with medium-length rows that are no window operators -- assembled FEM
+ * matrices): rows are cut into slices of up to 64 consecutive rows of one class (class-0 slices first); nonzero u of the
+ * row in lane l of a slice is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus
+ * the slice's smallest column); shorter rows are padded (value 0, column 0; never multiplied).  slices_out: 8 int32 per
+ * slice {first row, end row, voff, coff, longest row, smallest column, 0, 0}; stats[0..4) = {class-0 slices, elements of
+ * val, elements of col16, padded nonzeros}.  Returns the number of slices, 0 if the operator does not qualify (a slice's
+ * columns span >= 65536, or padding beyond max_overhead x nnz), -needed if a capacity is too small, -1 on a bad argument.
+ * What prcg_set_csr runs for rows of 24 nonzeros and more; exported for the CPU tests. */
+int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
+                       double max_overhead, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
+                       int64_t array_capacity, int64_t* stats);
 /* Merged exchange of the multi-GPU pipelined loop (small halos ride on the one all-gather per
  * iteration): where in the gathered buffer do this rank's ghost rows lie?  `tables`: every rank's
  * send table, doubles_per_table doubles each: [n_peers, (peer, first row of its list, rows)...];

@@ -2568,6 +2568,23 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
     return 1;
 }
 
+int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
+                       double max_overhead, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
+                       int64_t array_capacity, int64_t* stats) {
+    if (n < 0 || !indptr || (indptr[n] > 0 && (!indices || !data)) || (!slices_out && capacity > 0)) return -1;
+    SellPlan sp;
+    if (!plan_sell(n, indptr, indices, data, row_class, max_overhead, sp)) return 0;
+    const int64_t total = (int64_t)sp.s0.size() + (int64_t)sp.s1.size();
+    if (stats) { stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz; }
+    if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity)) return -total;
+    int64_t o = 0;
+    for (const auto* v : {&sp.s0, &sp.s1})
+        for (const auto& t : *v) { memcpy(slices_out + 8 * o, &t, 8 * sizeof(int32_t)); ++o; }
+    if (val_out) memcpy(val_out, sp.val.data(), sp.val.size() * sizeof(double));
+    if (col_out) memcpy(col_out, sp.col.data(), sp.col.size() * sizeof(uint16_t));
+    return total;
+}
+
 int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int n_peers, const int32_t* peer_rank,
                      const int64_t* recv_ptr, int64_t slot_doubles, int32_t* ghost_src) {
     if (rank < 0 || doubles_per_table < 1 || !tables || n_peers < 0 || slot_doubles < 8 || (slot_doubles & 1)) return -1;

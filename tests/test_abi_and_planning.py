@@ -364,3 +364,86 @@ def test_missing_x_true_is_refused_for_large_systems():
     assert A.shape[0] > cg_variants._MAX_DIRECT_SOLVE
     with pytest.raises(ValueError, match='x_true'):
         cg_variants.pipe_pr_cg(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), 5, callbacks=[error_A_norm])
+
+
+def plan_sell(A, row_class=None, max_overhead=1.25):
+    A = A.tocsr()
+    n = A.shape[0]
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    data = np.ascontiguousarray(A.data, dtype=np.float64)
+    rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
+    stats = np.zeros(4, dtype=np.int64)
+    cap = n // 64 + 8 + (0 if rc is None else int(np.count_nonzero(np.diff(rc.astype(np.int8)))) + 2)
+    slices = np.zeros((cap, 8), dtype=np.int32)
+    arr_cap = int(max_overhead * A.nnz * 1.3) + 64 * 130 * 4 + 4096
+    val = np.zeros(arr_cap)
+    col = np.zeros(arr_cap, dtype=np.uint16)
+    got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), L.ptr(slices), cap,
+                                 L.ptr(val), L.ptr(col), arr_cap, L.ptr(stats))
+    return got, slices[:max(got, 0)], val, col, stats
+
+
+@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts'])
+def test_sliced_row_layout_holds_exactly_the_matrix(name):
+    """Host planner of the lane-per-row kernels (prcg_plan.cpp: plan_sell): every row in exactly one slice (classes apart,
+    class 0 first), and reading the re-laid arrays back with the kernel's index formula gives the caller's CSR rows,
+    values bit for bit and columns exactly, in order; padding is zero."""
+    import scipy.sparse as sp
+    from new_cg_variants_amd import partition
+    rng = np.random.default_rng(9)
+    row_class = None
+    if name == 'fem':
+        A = problems.fem_like_3d(9, 3)
+    elif name == 'ragged':
+        n = 5000
+        lens = rng.integers(40, 51, size=n)
+        lens[rng.integers(0, n, size=60)] = 0
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        r = np.repeat(np.arange(n), lens)
+        A = sp.csr_matrix((rng.standard_normal(r.size), (r + rng.integers(-900, 901, size=r.size)).clip(0, n - 1).astype(np.int32), indptr),
+                          shape=(n, n))
+    else:
+        full = problems.fem_like_3d(10, 3)
+        A, ghost_ids = partition.localize(full[900:2100], 900, 2100)
+        row_class = np.array([(A.indices[A.indptr[i]:A.indptr[i + 1]] >= 1200).any() for i in range(1200)])
+    got, slices, val, col, stats = plan_sell(A, row_class)
+    assert got > 0, got
+    n = A.shape[0]
+    seen = np.zeros(n, dtype=int)
+    used_v = np.zeros(int(stats[1]), dtype=bool)
+    for si, (rb, re, voff, coff, width, cbase, _, _) in enumerate(slices):
+        assert 0 < re - rb <= 64
+        seen[rb:re] += 1
+        if row_class is not None:
+            assert np.all(row_class[rb:re] == (si >= stats[0]))
+        assert width == np.diff(A.indptr[rb:re + 1]).max()
+        for row in range(rb, re):
+            lane = row - rb
+            lo, hi = A.indptr[row], A.indptr[row + 1]
+            u = np.arange(hi - lo)
+            vi = voff + ((u >> 1) * 64 + lane) * 2 + (u & 1)
+            ci = coff + ((u >> 2) * 64 + lane) * 4 + (u & 3)
+            assert np.array_equal(val[vi].view(np.uint64), A.data[lo:hi].view(np.uint64))
+            assert np.array_equal(col[ci].astype(np.int64) + cbase, A.indices[lo:hi])
+            used_v[vi] = True
+    assert np.all(seen == 1)
+    assert np.all(val[:int(stats[1])][~used_v] == 0.0)
+    assert stats[3] <= 1.25 * max(A.nnz, 1)
+    for part in (slices[:stats[0]], slices[stats[0]:]):
+        assert np.all(np.diff(part[:, 0]) > 0)
+
+
+def test_sliced_rows_refuse_wide_and_ragged_operators():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    n = 80_000
+    lens = np.full(n, 30)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    wide = sp.csr_matrix((np.ones(indptr[-1]), rng.integers(0, n, size=indptr[-1]).astype(np.int32), indptr), shape=(n, n))
+    assert plan_sell(wide)[0] == 0                       # a slice's columns span the whole matrix: no 16-bit offsets
+    lens = rng.integers(0, 100, size=4000)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    r = np.repeat(np.arange(4000), lens)
+    ragged = sp.csr_matrix((np.ones(r.size), (r // 2).astype(np.int32), indptr), shape=(4000, 4000))
+    assert plan_sell(ragged)[0] == 0                     # padding to each slice's longest row would double the stream

@@ -7,6 +7,17 @@
 using namespace prcg;
 
 extern "C" int plan_all(long n, long ncols, const int* indptr, const int* indices, const double* data, int rows, int share) {
+    {   // sliced rows (plan_sell): every slice's trip-wise reads stay inside the arrays
+        SellPlan sp;
+        if (plan_sell(n, indptr, indices, data, nullptr, 1.25, sp)) {
+            for (const auto* v : {&sp.s0, &sp.s1})
+                for (const auto& t : *v) {
+                    const long trips = (t.width + 7) / 8;
+                    if (t.voff < 0 || (size_t)t.voff + (size_t)trips * 4 * 128 > sp.val.size() + 0) return -6;
+                    if (t.coff < 0 || (size_t)t.coff + (size_t)trips * 2 * 256 > sp.col.size() + 0) return -7;
+                }
+        }
+    }
     WinPlan wp;
     plan_window_tiles(n, ncols, indptr, indices, nullptr, rows, 1009, rows == 64 ? 4 : 12, wp);
     if (!wp.ok0 || !wp.ok1) return 0;
