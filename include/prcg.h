@@ -119,6 +119,14 @@ int prcg_set_option(prcg_t* h, const char* key, const char* value);
 int prcg_comm_unique_id(const char* rccl_path, void* id128);
 int prcg_comm_init(prcg_t* h, const char* rccl_path, int rank, int nranks, const void* ids, int n_ids);
 
+/* Ghysels-Vanroose residual replacement (gv_cg.py:9,69-71; gv_pcg :93,156-158): `w_replace(k=..., x=..., w=..., r=..., ...)`
+ * is the CALLER's predicate.  fn(ctx, k) is called inside prcg_iterate of a PRCG_GV session after x, r, (r~), w of
+ * iteration k are updated and before t = A w~; it may read the state with prcg_get_vector (x, r, w are the new ones, p, s, u
+ * the old ones -- what the reference passes); a non-zero return replaces w by A r (r, not r~, also with a preconditioner, as
+ * the reference does) before the iteration goes on.  Sessions with a hook run the unfused schedule on one stream. */
+typedef int (*prcg_replace_fn)(void* ctx, int k);
+int prcg_set_replace_hook(prcg_t* h, prcg_replace_fn fn, void* ctx);
+
 /* ---- direct peer exchange over xGMI ----------------------------------------------------
  * The reduction and the halo of the pipelined loop WITHOUT a collective (replaces, inside the loop, the
  * `comm.Allreduce` of scaling_experiments_mpi4py/cg_variants/pipe_pr_cg.py:67 and the neighbour exchange its dense

@@ -66,6 +66,7 @@ _SIGNATURES = {
     'prcg_sync': (C.c_int, [_P]),
     'prcg_iteration': (C.c_int, [_P]),
     'prcg_set_preconditioner': (C.c_int, [_P, _P, _P]),
+    'prcg_set_replace_hook': (C.c_int, [_P, _P, _P]),
     'prcg_schedule': (C.c_int, [_P]),
     'prcg_operator_bytes': (C.c_int64, [_P]),
     'prcg_set_iteration': (C.c_int, [_P, C.c_int]),
@@ -89,7 +90,9 @@ _SIGNATURES = {
     'prcg_debug_layout': (C.c_int64, [_P, _P, C.c_int64]),
 }
 
+REPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 PREC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))   # prcg_prec_fn
+REPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)                                                 # prcg_replace_fn
 
 _lib = None
 

@@ -125,7 +125,7 @@ def _state_vectors(variant, prec):
     return ['x', 'r', 'p', 's', 'w', 'u'] + (['rt', 'st', 'wt', 'ut'] if prec else [])
 
 
-def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
+def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs, w_replace=None):
     device = int(kwargs.get('device', 0))
     if A.format != 'csr':
         A = A.tocsr()
@@ -155,6 +155,22 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
 
     op = _operator(A, device)
     output = {'name': name, 'max_iter': max_iter}
+    if w_replace is not None:
+        # gv_cg.py:9,69-71: the caller's predicate, with the reference's keywords; r_ is the residual of the previous iteration
+        flags = {}
+        prev = {'r': None}
+
+        def hook(k):
+            x, w, r = op.get_vector('x'), op.get_vector('w'), op.get_vector('r')
+            if prev['r'] is None:
+                prev['r'] = np.asarray(b, dtype=np.float64) - A @ np.asarray(x0, dtype=np.float64)
+            fire = w_replace(k=k, A=A, b=b, x=x, w=w, r=r, r_=prev['r'], u=op.get_vector('u'), s=op.get_vector('s'),
+                             p=op.get_vector('p'), wk_replace_flags=flags)
+            prev['r'] = r
+            return fire
+        op.set_replace_hook(hook)
+    else:
+        op.set_replace_hook(None)
     op.begin(variant, b, x0, max_iter, x_true=x_true, inv_diag=inv_diag, hist_mask=mask, preconditioner=prec_fn)
 
     def call_host(k):
@@ -190,19 +206,19 @@ def _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs):
 
 
 def _make(variant, name, preconditioned):
-    def check(kwargs):
-        if kwargs.pop('w_replace', None) is not None:
-            # gv_cg.py:9 takes a residual-replacement predicate; its default never fires
-            raise NotImplementedError('w_replace (residual replacement) is not available on the device')
+    def take_w_replace(kwargs):
+        # gv_cg.py:9 / :93 take a residual-replacement predicate (default: never); the other variants swallow the keyword
+        fn = kwargs.pop('w_replace', None)
+        return fn if variant == L.GV else None
     if preconditioned:
         def f(A, b, x0, max_iter, preconditioner=None, callbacks=[], **kwargs):
-            check(kwargs)
-            return _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs)
+            w_replace = take_w_replace(kwargs)
+            return _run(variant, name, A, b, x0, max_iter, preconditioner, callbacks, kwargs, w_replace)
     else:
         def f(A, b, x0, max_iter, callbacks=[], **kwargs):
-            check(kwargs)
+            w_replace = take_w_replace(kwargs)
             kwargs.pop('preconditioner', None)   # figure_gen.py:59 always passes one
-            return _run(variant, name, A, b, x0, max_iter, None, callbacks, kwargs)
+            return _run(variant, name, A, b, x0, max_iter, None, callbacks, kwargs, w_replace)
     f.__name__ = f.__qualname__ = name
     return f
 

@@ -133,6 +133,7 @@ struct prcg_handle {
     int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
     DevBuf sval, scol, sslices;
+    int win_period = 0;                  // tiles t and t + win_period read the same stream images (0: no such period found)
     bool want_share = true;              // PRCG_WIN_SHARE=0: every window tile keeps its own stream images
     int64_t win_stream_bytes = 0;        // bytes of the encoded operator a product must read at least once (window form)
     bool side_stream = false;            // one GPU: reduce the partials beside the SpMM (PRCG_SIDE_STREAM=1);
@@ -191,6 +192,7 @@ struct prcg_handle {
     // host-callback preconditioner (prcg_set_preconditioner): M^-1 v is computed by the caller's function on host
     // copies of v; sessions that use it run the schedules in which every tilde vector is a stored vector
     prcg_prec_fn cb = nullptr; void* cb_ctx = nullptr; bool cb_session = false;
+    prcg_replace_fn replace_fn = nullptr; void* replace_ctx = nullptr;       // gv_cg's w_replace predicate (prcg_set_replace_hook)
     std::vector<double> cb_in, cb_out;
     DevBuf cb_stage, ut;         // staging for strided operands; u~ = M^-1 u of the pipelined variants
     bool pr_fused = false;       // non-pipelined predict-and-recompute (pr, m) on a window operator: ONE launch per iteration
@@ -244,7 +246,7 @@ struct prcg_handle {
                       b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
                       win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
                       win_vd ? static_cast<const double*>(wvdict.p) : nullptr,
-                      static_cast<const unsigned short*>(wrel.p)};
+                      static_cast<const unsigned short*>(wrel.p), win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p)}; }
@@ -1172,8 +1174,22 @@ int iterate_gv(prcg_t* h, int k) {
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_upd, h->n_ev_upd, on);
     int rc;
+    bool replaced = false;
+    if (h->replace_fn) {
+        // gv_cg.py:69-71: the caller's predicate sees the state as the reference passes it (x, r, w new; p, s, u old)
+        HIPCHK(h, hipStreamSynchronize(h->sc));
+        const int kk = h->k;
+        h->k = k;                                                        // (prcg_get_* inside the hook address iteration k)
+        const int fire = h->replace_fn(h->replace_ctx, k);
+        h->k = kk;
+        if (fire) {
+            if ((rc = dist_spmv(h, h->r.d(), h->cur_w, kEpiNone, nullptr, nullptr, nullptr, nullptr))) return rc;   // w = A r
+            if (h->prec && !h->cb_session) launch_mul(h->sc, h->wt.d(), 1, h->dinv.d(), 1, h->cur_w, 1, h->n);      // w~ = M^-1 w
+            replaced = true;
+        }
+    }
     if (h->cb_session && (rc = apply_prec(h, h->w.d(), 1, h->wt.d(), 1))) return rc;  // w~ = preconditioner(w)  gv_cg.py:161
-    const bool side = h->multi();
+    const bool side = h->multi() && !h->replace_fn;
     if (side) {
         HIPCHK(h, hipEventRecord(h->e_upd, h->sc));
         HIPCHK(h, hipStreamWaitEvent(h->sm, h->e_upd, 0));
@@ -1182,6 +1198,12 @@ int iterate_gv(prcg_t* h, int k) {
         HIPCHK(h, hipEventRecord(h->e_red, h->sm));
     } else {
         launch_reduce_final(h->sc, h->partA.d(), grid, dots_at(h, k), 0, 0, 5);
+        if (replaced) {     // eta = w.r~ with the replaced w (gv_cg.py:75 / :164)
+            const int g2 = launch_dot(h->sc, h->cur_w, h->prec ? h->rt.d() : h->r.d(), h->n, h->partB.d(), 0);
+            LAUNCHCHK(h, g2);
+            launch_reduce_final(h->sc, h->partB.d(), g2, dots_at(h, k), 0, PRCG_S_DELTA, 1);
+        }
+        if (h->multi() && (rc = allreduce(h, dots_at(h, k), 5, h->sc))) return rc;
     }
     double* zt = h->prec ? h->wt.d() : h->w.d();
     int nparts = 0;
@@ -1389,6 +1411,13 @@ int prcg_set_preconditioner(prcg_t* h, prcg_prec_fn fn, void* ctx) {
     if (!h) return PRCG_EINVAL;
     h->cb = fn;
     h->cb_ctx = ctx;
+    return PRCG_OK;
+}
+
+int prcg_set_replace_hook(prcg_t* h, prcg_replace_fn fn, void* ctx) {
+    if (!h) return PRCG_EINVAL;
+    h->replace_fn = fn;
+    h->replace_ctx = ctx;
     return PRCG_OK;
 }
 
@@ -1671,6 +1700,19 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             cw_bytes = cstore.size();
             HIPCHK(h, h->wcw.alloc(cw_bytes));
             HIPCHK(h, hipMemcpy(h->wcw.p, cstore.data(), cw_bytes, hipMemcpyHostToDevice));
+        }
+        // period of the images over the interior tiles (a stencil on a regular grid: a grid line, a grid plane): the
+        // smallest P with image(t + P) == image(t) for every t of a long stretch in the middle of the table
+        h->win_period = 0;
+        if (h->want_share && h->win_vd && wp.t0.size() > 4096) {
+            const size_t nt0 = wp.t0.size(), t0 = nt0 / 3;
+            for (size_t P = 2; P <= 4096 && t0 + 3 * P < nt0; ++P) {
+                if (wall[t0 + P].spare != wall[t0].spare || wall[t0].spare == 0) continue;
+                bool ok = true;
+                for (size_t j = 0; j < 2 * P && ok; ++j) ok = wall[t0 + j + P].spare == wall[t0 + j].spare;
+                if (ok) { h->win_period = (int)P; break; }
+            }
+            if (wall[t0 + 1].spare == wall[t0].spare && wall[t0 + 2].spare == wall[t0].spare) h->win_period = 0;   // (period 1: nothing to align)
         }
         HIPCHK(h, h->wrel.alloc(rstore.size() * sizeof(uint16_t)));
         HIPCHK(h, hipMemcpy(h->wrel.p, rstore.data(), rstore.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -2124,7 +2166,8 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         h->p_cur = h->p.d();
         HIPCHK(h, h->r.ensure((size_t)ne * D, h->sc));
         h->cur_r = h->r.d();
-        h->cg_fused = h->want_fused && !h->multi() && h->g == 0 && h->win && !h->cb_session;
+        h->cg_fused = h->want_fused && !h->multi() && h->g == 0 && h->win && !h->cb_session &&
+                      !(variant == PRCG_GV && h->replace_fn);      // (the predicate is called between the update and the product)
         // one launch per iteration: both variants unpreconditioned, Chronopoulos-Gear with Jacobi too
         h->cg_one = h->cg_fused && h->want_cg_one && (variant == PRCG_CG_CG || !h->prec);
         h->cg_lag = false;

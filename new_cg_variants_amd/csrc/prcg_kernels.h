@@ -217,15 +217,18 @@ struct WinDev {
     const unsigned char* vidx8;    // null: plain values
     const double* vdict;
     const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r)
+    int period;                    // > 1: tiles t and t + period read the same stream images (host: the launch picks a wave
+                                   // count that is a multiple of it, so that a wave meets the same image tile after tile)
 };
 // geometry id of a class planned with rows_per_tile (64 | 128) whose tiles need at most most_pages
-// pages: 0 = 64 rows / 2 pages / 8-bit indices, 1 = 64 / 4 / 8-bit, 2 = 128 / 8 / 16-bit, 3 = 128 / 12 / 16-bit
+// pages: 0 = 64 rows / 2 pages / 8-bit indices, 1 = 64 / 4 / 8-bit, 2 = 128 / 8 / 16-bit, 3 = 128 / 12 / 16-bit,
+// 4 = 64 / 8 / 16-bit (3-D stencils in 64-row tiles: images repeat with the period of a grid plane)
 inline int win_geometry(int rows_per_tile, int most_pages) {
-    if (rows_per_tile == 64) return most_pages <= 2 ? 0 : (most_pages <= 4 ? 1 : -1);
+    if (rows_per_tile == 64) return most_pages <= 2 ? 0 : (most_pages <= 4 ? 1 : (most_pages <= 8 ? 4 : -1));
     if (rows_per_tile == 128) return most_pages <= 8 ? 2 : (most_pages <= 12 ? 3 : -1);
     return -1;
 }
-inline int win_max_pages(int rows_per_tile) { return rows_per_tile == 64 ? 4 : 12; }
+inline int win_max_pages(int rows_per_tile) { return rows_per_tile == 64 ? 8 : 12; }
 // same contracts as launch_spmv / launch_spmm2 / launch_pipe_fused below; per_cu > 0 overrides the
 // number of workgroups launched per CU (experiments)
 int launch_win_spmv(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const double* x, double* y,

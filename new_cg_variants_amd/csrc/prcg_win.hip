@@ -128,7 +128,8 @@ struct WRegs {
 // entries are wave-uniform scalars and the value is a select, no LDS read.  Same products, same order.
 // (64-row tiles with 1-byte window indices only: the 128-row stencil geometries rarely see the same image twice in a
 //  row -- S2's images repeat every 729 tiles -- and lose occupancy to the cache registers: S2 -17 %, S1 -5 % when tried)
-constexpr int win_row_cache_len(int m, int cw, bool vd) { return (vd && PRCG_WIN_ROW_CACHE && cw == 8 && m == 1) ? 16 : 0; }
+//  the 64-row geometry with 2-byte indices -- 3-D stencils -- caches rows of up to 8 nonzeros)
+constexpr int win_row_cache_len(int m, int cw, bool vd) { return (vd && PRCG_WIN_ROW_CACHE && m == 1) ? (cw == 8 ? 16 : 8) : 0; }
 template <int M, int RL, int CW>
 struct RowCache {
     unsigned c[M][RL > 0 ? RL * (CW / 8) / 4 : 1];   // window indices of row (rb + j*64 + lane), nonzero u at byte / half-word u
@@ -1144,6 +1145,14 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
         const int waves = grid * WPB, rounds = (ntiles + waves - 1) / waves;
         grid = ((ntiles + rounds - 1) / rounds + WPB - 1) / WPB;
     }
+    if (!DEFER && per_cu < 1 && A.period > 1) {
+        // the stream images repeat every `period` tiles: with a wave count that is a multiple of the period (and of the
+        // workgroup size) every wave meets the SAME image tile after tile and keeps its rows decoded in registers
+        long unit = A.period;
+        while (unit % WPB) unit += A.period;
+        const long waves = (long)grid * WPB, aligned = waves / unit * unit;
+        if (aligned > 0 && aligned * 4 >= waves * 3) grid = (int)(aligned / WPB);
+    }
     if (done)
         hipExtLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), 0, st, nullptr, done, 0, A, reinterpret_cast<const int4*>(tiles), ntiles,
                               x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz);
@@ -1163,6 +1172,7 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
     case 1: return launch_win_g<NV, EPI, 1, 4, 8, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     case 2: return launch_win_g<NV, EPI, 2, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     case 3: return launch_win_g<NV, EPI, 2, 12, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
+    case 4: return launch_win_g<NV, EPI, 1, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     default: return -1;
     }
 }
@@ -1170,12 +1180,13 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
 }  // namespace
 
 int win_fused_waves_per_block(int geom, bool value_dict, bool deferred) {
-    if (deferred) return wpb_defer(geom < 2 ? 1 : 2);
+    if (deferred) return wpb_defer((geom < 2 || geom == 4) ? 1 : 2);
     switch (geom) {
     case 0: return waves_per_block(2, 2, 8, value_dict);
     case 1: return waves_per_block(2, 4, 8, value_dict);
     case 2: return waves_per_block(2, 8, 16, value_dict);
     case 3: return waves_per_block(2, 12, 16, value_dict);
+    case 4: return waves_per_block(2, 8, 16, value_dict);
     default: return 0;
     }
 }

@@ -194,6 +194,24 @@ class DeviceCSR:
                                                L.ptr(xt), L.ptr(dv), int(hist_mask)))
         self.max_iter, self.hist_mask = int(max_iter), int(hist_mask)
 
+    def set_replace_hook(self, fn):
+        """Ghysels-Vanroose residual replacement (prcg.h: prcg_set_replace_hook): fn(k) -> truthy replaces w by A r in
+        iteration k; None removes the hook.  Set before begin()."""
+        if fn is None:
+            self._replace_fn = None
+            self._check(self._lib.prcg_set_replace_hook(self._h, None, None))
+            return
+
+        def call(_ctx, k):
+            try:
+                return 1 if fn(int(k)) else 0
+            except Exception:          # noqa: BLE001 -- a failing predicate does not replace; the traceback is shown
+                import traceback
+                traceback.print_exc()
+                return 0
+        self._replace_fn = L.REPLACE_FN(call)          # keep the trampoline alive
+        self._check(self._lib.prcg_set_replace_hook(self._h, C.cast(self._replace_fn, C.c_void_p), None))
+
     def iterate(self, iters):
         self._check(self._lib.prcg_iterate(self._h, int(iters)))
 

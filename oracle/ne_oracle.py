@@ -321,13 +321,19 @@ def gv_start(A, b, x0, prec=None, dot=np.dot):
     return st
 
 
-def gv_advance(A, st, prec=None, dot=np.dot):
+def gv_advance(A, st, prec=None, dot=np.dot, w_replace=None, b=None, flags=None):
+    """w_replace: the reference's residual-replacement predicate (gv_cg.py:9,69-71 / :93,156-158), called with the
+    reference's keywords after x, r, w are updated; True replaces w by A @ r (also in gv_pcg: r, not r~)."""
     a = st.alpha
     nu_old = st.nu
+    r_prev = st.r
     st.x = st.x + a * st.p                                     # :65 / :152
     st.r = st.r - a * st.s                                     # :66 / :153
     if prec is None:
         st.w = st.w - a * st.u                                 # :67
+        if w_replace is not None and w_replace(k=st.k + 1, A=A, b=b, x=st.x, w=st.w, r=st.r, r_=r_prev, u=st.u, s=st.s, p=st.p,
+                                                wk_replace_flags=flags):          # :69
+            st.w = A @ st.r                                    # :71
         t = A @ st.w                                           # :73
         st.nu = dot(st.r, st.r)                                # :74
         st.eta = dot(st.w, st.r)                               # :75
@@ -335,6 +341,9 @@ def gv_advance(A, st, prec=None, dot=np.dot):
     else:
         st.rt = st.rt - a * st.st                              # :154
         st.w = st.w - a * st.u                                 # :155
+        if w_replace is not None and w_replace(k=st.k + 1, A=A, b=b, x=st.x, w=st.w, r=st.r, r_=r_prev, u=st.u, s=st.s, p=st.p,
+                                                wk_replace_flags=flags):          # :156
+            st.w = A @ st.r                                    # :158
         st.wt = np.array(prec(st.w), copy=True)                # :161
         t = A @ st.wt                                          # :162
         st.nu = dot(st.r, st.rt)                               # :163
@@ -392,7 +401,7 @@ FAMILIES = {
 
 
 def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
-        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None, square=_pow2, dot0=None):
+        x_true=None, dot=np.dot, tap: Optional[Callable] = None, name=None, square=_pow2, dot0=None, w_replace=None):
     """Free-running solve with the reference's loop shape: recorders fire on the
     initial state (index 0) and after each of the ``max_iter - 1`` iterations
     (NE/cg_variants/hs_cg.py:33-36,39,64-65).  ``tap(state)`` sees every state.  ``dot0``: inner-product
@@ -402,6 +411,7 @@ def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
     for q in recorders:
         out[q] = np.zeros(max_iter)
     st = start(A, b, x0, prec=prec, dot=dot0 or dot)
+    flags = {}      # the reference's wk_replace_flags: storage a w_replace predicate may use between iterations
 
     def record():
         for q in recorders:
@@ -414,6 +424,8 @@ def run(family, A, b, x0, max_iter, flavour=None, prec=None, recorders=(),
         for _ in range(1, max_iter):
             if has_flavour:
                 advance(A, st, flavour, prec=prec, dot=dot, square=square)
+            elif family == 'gv' and w_replace is not None:
+                advance(A, st, prec=prec, dot=dot, w_replace=w_replace, b=b, flags=flags)
             else:
                 advance(A, st, prec=prec, dot=dot)
             record()
@@ -428,7 +440,7 @@ def _public(family, flavour, ref_name, preconditioned):
         out = run(family, A, b, x0, max_iter, flavour=flavour, prec=prec,
                   recorders=tuple(callbacks), x_true=kwargs.get('x_true'),
                   dot=kwargs.get('dot', np.dot), tap=kwargs.get('tap'), name=ref_name,
-                  square=kwargs.get('square', _pow2), dot0=kwargs.get('dot0'))
+                  square=kwargs.get('square', _pow2), dot0=kwargs.get('dot0'), w_replace=kwargs.get('w_replace'))
         return out
     f.__name__ = ref_name
     return f

@@ -131,6 +131,39 @@ def run_pair(matrix, A, method, max_iter, prec_name, state_ks):
     print(f'  {tag:44s} max_iter={max_iter:5d} its={its:5d} log10min={acc:7.2f} states={len(states)}  [oracle == reference, bitwise]')
 
 
+def w_replace_goldens():
+    """gv_cg / gv_pcg with a residual-replacement predicate (gv_cg.py:9,69-71): the default never fires, so the hook is
+    pinned with one that does -- every 7th iteration and at its 3rd and 40th call (counted in the wk_replace_flags storage)."""
+    def make_pred():
+        # (decisions depend on k and on the call count kept in wk_replace_flags only: a run whose inner products are summed
+        #  in another order takes the same decisions)
+        def pred(**kw):
+            fl = kw['wk_replace_flags']
+            fl['calls'] = fl.get('calls', 0) + 1
+            assert kw['r'].shape == kw['r_'].shape == kw['w'].shape
+            return kw['k'] % 7 == 0 or fl['calls'] in (3, 40)
+        return pred
+    for matrix, method, prec_name, max_iter in (('bcsstk03', 'gv_cg', 'None', 700), ('bcsstk03', 'gv_pcg', 'jacobi', 200), ('nos7', 'gv_pcg', 'jacobi', 120)):
+        A = load_matrix(matrix)
+        b, x0, x_true = problem(A)
+        kwargs, okw = {}, {}
+        if prec_name == 'jacobi':
+            kwargs['preconditioner'] = lambda x: (1 / A.diagonal()) * x
+            okw['preconditioner'] = orc.jacobi(A)
+        with np.errstate(all='ignore'):
+            ref_out = getattr(ref_cg, method)(A, b, x0, max_iter, w_replace=make_pred(), callbacks=REF_CALLBACKS, x_true=x_true, **kwargs)
+            my_out = getattr(orc, method)(A, b, x0, max_iter, w_replace=make_pred(), callbacks=FOUR, x_true=x_true, **okw)
+        fx = {'max_iter': np.int64(max_iter)}
+        for q in FOUR:
+            assert np.array_equal(ref_out[q], my_out[q], equal_nan=True), f'{matrix}/{method}: oracle with w_replace differs from the reference in {q}'
+            fx['hist_' + q] = ref_out[q]
+        its, acc = orc.convergence_summary(ref_out['error_A_norm'])
+        fx['iters_to_1e-5'] = np.int64(its)
+        fx['log10_min_rel_error_A'] = np.float64(acc)
+        np.savez_compressed(os.path.join(HERE, f'wreplace_{matrix}_{method}_{prec_name}.npz'), **fx)
+        print(f'  w_replace {matrix}/{method}/{prec_name}: max_iter={max_iter} its={its} log10min={acc:.2f}  [oracle == reference, bitwise]')
+
+
 def pairs(ks):
     """teacher forcing needs state k and k+1"""
     out = set()
@@ -259,6 +292,9 @@ def paper_table():
 
 def main():
     print('numpy', np.__version__, 'scipy', scipy.__version__)
+    if sys.argv[1:] == ['w_replace']:
+        w_replace_goldens()
+        return
     if sys.argv[1:] == ['table']:
         paper_table()
         return

@@ -534,3 +534,32 @@ def test_sliced_row_kernels_run_every_schedule_of_the_tile_kernels(amd, variant,
     assert pipelined == ops[0].schedule()['fused'] or not pipelined
     for op in ops:
         op.close()
+
+
+@pytest.mark.gpu
+def test_64_row_tiles_for_3d_stencils(amd):
+    """PRCG_WIN_ROWS=64 on 3-D stencils: 64-row tiles with up to eight pages and 2-byte window indices (geometry 4; the default
+    keeps 128-row tiles, which measured within 4 % on S2 and 25 % better on S1).  Their stream images repeat with the period
+    of a grid plane, the launch picks a wave count that is a multiple of it, and the row cache applies: products bit-exact
+    vs SciPy, solves identical to the default geometry's to rounding."""
+    L, P = amd['L'], amd['problems']
+    rng = np.random.default_rng(5)
+    for A in (P.laplace_3d(64, 48, 40), P.laplace_3d(216, 30, 20)):
+        n = A.shape[0]
+        x = rng.standard_normal(n)
+        b, x0, _ = P.reference_rhs(A, n)
+        hist = []
+        for knobs in ({'PRCG_WIN_ROWS': '64'}, {'PRCG_WIN_ROWS': '64', 'PRCG_VALDICT': '0'}, {}):
+            op = amd['device'].DeviceCSR(A, knobs=knobs)
+            s = op.schedule()
+            assert s['window'] and s['col_bytes'] == 2, s
+            if knobs:
+                assert op.layout()['rows_per_tile'] == 64 and op.layout()['geometry'] == 4, op.layout()
+            products_bitexact(op, A, x, f'lap3d {knobs}')
+            op.begin(L.PIPE_PR, b, x0, 30, hist_mask=1)
+            op.iterate(29)
+            op.sync()
+            hist.append(op.history()['updated_residual_2_norm'])
+            op.close()
+        for h in hist[:2]:
+            np.testing.assert_allclose(h, hist[2], rtol=1e-10)

@@ -1111,3 +1111,43 @@ def test_scaling_tests_driver_matches_the_published_errors(amd, tmp_path, monkey
         assert lo <= np.log10(saved['error']) <= hi, (name, saved['error'], spread)
         assert lo <= np.log10(err_pub) <= hi, (name, err_pub, spread)
     assert res.keys() == published.keys()
+
+
+@pytest.mark.parametrize('matrix,method,prec', [('bcsstk03', 'gv_cg', 'None'), ('bcsstk03', 'gv_pcg', 'jacobi'), ('nos7', 'gv_pcg', 'jacobi')])
+def test_ghysels_vanroose_residual_replacement_hook_on_the_device(amd, matrices, matrix, method, prec):
+    """`gv_cg(A, b, x0, max_iter, w_replace=predicate, ...)` (gv_cg.py:9,69-71; gv_pcg :93,156-158): the predicate is the
+    caller's code and is called on the host with the reference's keywords between the x, r, w update and the product
+    t = A w~ of every iteration; True replaces w by A r on the device.  Against the reference-generated fixture (pinned
+    with the same predicate): the histories agree on the prefix like any free-running comparison (the replacement at
+    k = 3 and k = 7 lies inside it); the predicate sees r_ = the previous call's r, x / w / r of the current iteration."""
+    import os
+    from conftest import GOLDEN
+    A, z = matrices[matrix]
+    n = A.shape[0]
+    fx = np.load(os.path.join(GOLDEN, f'wreplace_{matrix}_{method}_{prec}.npz'))
+    max_iter = int(fx['max_iter'])
+    seen = []
+
+    def pred(**kw):
+        fl = kw['wk_replace_flags']
+        fl['calls'] = fl.get('calls', 0) + 1
+        if fl['calls'] <= 12:
+            seen.append((kw['k'], kw['r'].copy(), kw['r_'].copy(), kw['x'].copy(), kw['w'].copy(), kw['u'].copy()))
+        return kw['k'] % 7 == 0 or fl['calls'] in (3, 40)
+    kw = {'preconditioner': (lambda v: (1 / A.diagonal()) * v)} if prec == 'jacobi' else {}
+    cbs = [getattr(amd['cbs'], q) for q in FOUR]
+    out = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), max_iter, w_replace=pred, callbacks=cbs, x_true=z['x_true'], **kw)
+    assert [s[0] for s in seen] == list(range(1, 13))
+    assert np.array_equal(seen[0][2], z['b'])                                   # r_ of the first call: r_0 = b - A 0
+    for a, c in zip(seen[:-1], seen[1:]):
+        assert np.array_equal(c[2], a[1])                                       # r_ = the previous iteration's r
+    np.testing.assert_allclose(np.linalg.norm(seen[0][1]), fx['hist_updated_residual_2_norm'][1], rtol=1e-12)
+    ref = fx['hist_updated_residual_2_norm']
+    got = out['updated_residual_2_norm']
+    first = first_k_beyond(got, ref, 1e-11)
+    print(f'{matrix}/{method}/{prec} with w_replace: recurrence residual within 1e-11 of the reference for k < {first} (replacements at k = 3, 7)')
+    assert first >= (9 if prec == "None" else 4), first
+    # without a predicate that fires the same call is the plain method (the keyword is accepted and unused)
+    plain = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), 40, w_replace=lambda **kw: False, callbacks=cbs, x_true=z['x_true'], **kw)
+    base = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), 40, callbacks=cbs, x_true=z['x_true'], **kw)
+    np.testing.assert_allclose(plain['updated_residual_2_norm'][:8], base['updated_residual_2_norm'][:8], rtol=1e-11)

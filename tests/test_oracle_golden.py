@@ -157,3 +157,26 @@ def test_device_order_dot_is_a_valid_summation():
         exact = float(np.dot(a.astype(np.longdouble), b.astype(np.longdouble)))
         scale = float(np.dot(np.abs(a), np.abs(b)))
         assert abs(device_dot(a, b) - exact) <= 1e-13 * scale
+
+
+def wreplace_predicate():
+    """the predicate tests/golden/make_golden.py::w_replace_goldens pinned the oracle with (fires on k % 7 == 0 and at its 3rd
+    and 40th call, counted in the reference's wk_replace_flags storage)"""
+    def pred(**kw):
+        fl = kw['wk_replace_flags']
+        fl['calls'] = fl.get('calls', 0) + 1
+        return kw['k'] % 7 == 0 or fl['calls'] in (3, 40)
+    return pred
+
+
+@pytest.mark.parametrize('matrix,method,prec', [('bcsstk03', 'gv_cg', 'None'), ('bcsstk03', 'gv_pcg', 'jacobi'), ('nos7', 'gv_pcg', 'jacobi')])
+def test_ghysels_vanroose_residual_replacement_hook(matrices, matrix, method, prec):
+    """gv_cg's w_replace predicate (gv_cg.py:9,69-71 / :93,156-158; the default never fires): the oracle with a predicate
+    that does reproduces the reference-generated histories bit for bit."""
+    A, z = matrices[matrix]
+    fx = np.load(os.path.join(GOLDEN, f'wreplace_{matrix}_{method}_{prec}.npz'))
+    kw = {'preconditioner': orc.jacobi(A)} if prec == 'jacobi' else {}
+    out = getattr(orc, method)(A, z['b'], np.zeros(A.shape[0]), int(fx['max_iter']), w_replace=wreplace_predicate(),
+                               callbacks=FOUR, x_true=z['x_true'], **kw)
+    for q in FOUR:
+        assert np.array_equal(out[q], fx['hist_' + q], equal_nan=True), q
