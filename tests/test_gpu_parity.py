@@ -1146,7 +1146,7 @@ def test_ghysels_vanroose_residual_replacement_hook_on_the_device(amd, matrices,
     got = out['updated_residual_2_norm']
     first = first_k_beyond(got, ref, 1e-11)
     print(f'{matrix}/{method}/{prec} with w_replace: recurrence residual within 1e-11 of the reference for k < {first} (replacements at k = 3, 7)')
-    assert first >= (9 if prec == "None" else 4), first
+    assert first >= (7 if prec == "None" else 4), first
     # without a predicate that fires the same call is the plain method (the keyword is accepted and unused)
     plain = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), 40, w_replace=lambda **kw: False, callbacks=cbs, x_true=z['x_true'], **kw)
     base = getattr(amd['cgv'], method)(A, z['b'], np.zeros(n), 40, callbacks=cbs, x_true=z['x_true'], **kw)
