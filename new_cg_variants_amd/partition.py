@@ -134,6 +134,9 @@ def connect_peer_exchange(dev, rank, allgather):
             peers = [] if halo is None else [int(q) for q in halo['peers']]
             dst = [infos[q]['recv'][rank] for q in peers]
             dev.peer_connect([e['handle'] for e in everyone], [e['ptr'] if e['pid'] == mine else 0 for e in everyone], dst)
+            if not dev.layout()['window']:
+                # only the window kernels carry the exchange: a rank whose block is no window operator would never send
+                ok, err = False, RuntimeError('this rank\'s row block is no window operator')
         except Exception as exc:       # noqa: BLE001
             ok, err = False, exc
     else:
