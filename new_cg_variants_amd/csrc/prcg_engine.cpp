@@ -268,7 +268,7 @@ struct prcg_handle {
     int ghost_cap = 0;                   // ghost rows per parity in EVERY rank's buffer (largest ghost count of any rank)
     std::vector<void*> peer_opened;      // other ranks' buffers opened with hipIpcOpenMemHandle
     PeerDev peer_host{};
-    DevBuf peer_dev, peer_ents, peer_tile_send, peer_ticket;
+    DevBuf peer_dev, peer_ents, peer_tile_send;
     bool peer_ok = false;                // connected: every rank's buffer is mapped, send entries planned
     bool peer = false;                   // this session uses it
     uint64_t peer_epoch = 0;
@@ -1885,11 +1885,9 @@ int prcg_peer_connect(prcg_t* h, const void* ipc_handles, void* const* same_proc
     HIPCHK(h, hipMemcpy(h->peer_tile_send.p, tsend.data(), tsend.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(h, h->peer_ents.alloc(flat.size() * sizeof(int32_t)));
     HIPCHK(h, hipMemcpy(h->peer_ents.p, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(h, h->peer_ticket.alloc(64));
     HIPCHK(h, h->peer_dev.alloc(sizeof(PeerDev)));
     P.tile_send = static_cast<const int2*>(h->peer_tile_send.p);
     P.send_ent = static_cast<const int4*>(h->peer_ents.p);
-    P.ticket = static_cast<unsigned*>(h->peer_ticket.p);
     P.n_send = (int)ents.size();
     HIPCHK(h, hipMemcpy(h->peer_dev.p, &P, sizeof P, hipMemcpyHostToDevice));
     if (h->win) {

@@ -42,7 +42,6 @@ struct PeerDev {
     double* peer[kMaxPeerRanks];        // every rank's exchange buffer as mapped here (peer[rank] == mine)
     const int2* tile_send;              // per tile of the table in use: [first, end) of its entries in send_ent
     const int4* send_ent;               // {local row, destination rank, index in the destination's ghost area, 0}, by tile
-    unsigned* ticket;                   // arrival counter of a launch's workgroups (zero between launches)
     int rank, nranks, n_own, ghost_cap;
     unsigned long long epoch;
     int n_send;                         // entries in send_ent

@@ -425,7 +425,8 @@ def test_whole_trajectory_against_device_ordered_oracle(amd, matrices, matrix, f
 
 
 @pytest.mark.parametrize('matrix,method,max_iter', [
-    ('bcsstk03', 'pipe_pr_cg', 1250), ('nos7', 'pipe_pr_cg', 3000), ('bcsstk03', 'pipe_p_cg', 600), ('nos7', 'pipe_pr_m_cg', 600)])
+    ('bcsstk03', 'pipe_pr_cg', 1250), ('nos7', 'pipe_pr_cg', 3000), ('bcsstk03', 'pipe_p_cg', 600), ('nos7', 'pipe_pr_m_cg', 600),
+    ('s3_small', 'pipe_pr_cg', 300), ('lap2d_300', 'pipe_pr_cg', 200), ('lap3d_40', 'pipe_p_m_cg', 150)])
 def test_whole_trajectory_of_the_one_launch_schedule(amd, matrices, matrix, method, max_iter):
     """The strongest parity test, on the schedule that ships (one launch per iteration: what bench.py times and every
     solve uses by default; PRCG_SMALL=0 keeps the one-workgroup solver of tiny systems out of the way).  The oracle
@@ -435,7 +436,15 @@ def test_whole_trajectory_of_the_one_launch_schedule(amd, matrices, matrix, meth
     recorder histories of every k to rounding of one norm (the iterates are then identical; the norms are summed in
     another order by the recorder kernels)."""
     L = amd['L']
-    A, z = matrices[matrix]
+    if matrix in matrices:
+        A, z = matrices[matrix]
+    else:
+        # tens to hundreds of workgroups: the XCD remap, several tiles per wave and (stencils) 128-row tiles with two rows per lane
+        P = amd['problems']
+        A = {'s3_small': lambda: P.WORKLOADS['s3_small']['make'](), 'lap2d_300': lambda: P.laplace_2d(300, 200),
+             'lap3d_40': lambda: P.laplace_3d(40, 40, 40)}[matrix]()
+        b_, _, xt_ = P.reference_rhs(A, A.shape[0])
+        z = {'b': b_, 'x_true': xt_}
     n = A.shape[0]
     op = amd['device'].DeviceCSR(A, knobs={'PRCG_SMALL': '0'})
     variant = getattr(L, VARIANT_OF[method])
