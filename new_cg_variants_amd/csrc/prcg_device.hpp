@@ -143,25 +143,28 @@ __device__ __forceinline__ void block_reduce_store_final(double (&acc)[NQ], doub
 template <int NQ, int NWAVES>
 __device__ __forceinline__ void sum_prev_partials(const double* __restrict__ prev, int nprev, int slot0, double (&out)[NQ]) {
     constexpr int kTreeWaves = 4;
-    static_assert(kTreeWaves % NWAVES == 0, "1, 2 or 4 waves per block");
-    constexpr int R = kTreeWaves / NWAVES;
+    static_assert(kTreeWaves % NWAVES == 0 || NWAVES % kTreeWaves == 0, "1, 2, 4 or a multiple of 4 waves per block");
+    constexpr int R = NWAVES >= kTreeWaves ? 1 : kTreeWaves / NWAVES;
+    constexpr int TW = NWAVES >= kTreeWaves ? kTreeWaves : NWAVES;         // waves of this block that play tree threads
     __shared__ double redp[kTreeWaves][NQ];
     __shared__ double tot_s[NQ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (NWAVES <= kTreeWaves || wv < kTreeWaves) {                          // (larger blocks: their first four waves are the tree)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         double tot[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
-        for (int j = threadIdx.x + r * 64 * NWAVES; j < nprev; j += 64 * kTreeWaves) {
+        for (int j = threadIdx.x + r * 64 * TW; j < nprev; j += 64 * kTreeWaves) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) tot[q] += prev[(size_t)j * kPartialStride + slot0 + q];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const double v = wave_sum(tot[q]);
-            if (lane == 0) redp[wv + r * NWAVES][q] = v;
+            if (lane == 0) redp[wv + r * TW][q] = v;
         }
+    }
     }
     __syncthreads();
     if (threadIdx.x < NQ) {

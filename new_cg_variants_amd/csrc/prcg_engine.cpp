@@ -133,6 +133,8 @@ struct prcg_handle {
     int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
     DevBuf sval, scol, sslices;
+    int win_order = 0;                   // 1: XCD-chunked tile order of the window launches (opt-in: PRCG_WIN_ORDER=1)
+    int win_order_override = -1;
     int win_period = 0;                  // tiles t and t + win_period read the same stream images (0: no such period found)
     bool want_share = true;              // PRCG_WIN_SHARE=0: every window tile keeps its own stream images
     int64_t win_stream_bytes = 0;        // bytes of the encoded operator a product must read at least once (window form)
@@ -246,7 +248,7 @@ struct prcg_handle {
                       b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
                       win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
                       win_vd ? static_cast<const double*>(wvdict.p) : nullptr,
-                      static_cast<const unsigned short*>(wrel.p), win_period};
+                      static_cast<const unsigned short*>(wrel.p), win_order, win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p)}; }
@@ -1237,6 +1239,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_PEER") h->want_peer = v != 0;
     else if (k == "PRCG_SELL") h->want_sell = v != 0;
     else if (k == "PRCG_CG_ONE") h->want_cg_one = v != 0;
+    else if (k == "PRCG_WIN_ORDER") h->win_order_override = v != 0;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1251,7 +1254,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1714,6 +1717,10 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             }
             if (wall[t0 + 1].spare == wall[t0].spare && wall[t0 + 2].spare == wall[t0].spare) h->win_period = 0;   // (period 1: nothing to align)
         }
+        // tile order: PRCG_WIN_ORDER=1 lets every XCD sweep one contiguous eighth of the table (a 3-D stencil's plane neighbours
+        // then meet in one XCD's L2: S2 reads 0.39 instead of 0.67 GB per launch through the fabric) -- measured 2 % SLOWER at S2
+        // (profiles/r03_sweeps.md H: the 128-row stencil kernels are not bound by bytes), so the chip-wide front stays the default
+        h->win_order = h->win_order_override > 0 ? 1 : 0;
         HIPCHK(h, h->wrel.alloc(rstore.size() * sizeof(uint16_t)));
         HIPCHK(h, hipMemcpy(h->wrel.p, rstore.data(), rstore.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIPCHK(h, h->wtiles.alloc((wall.size() + 1) * sizeof(WTile)));
@@ -2645,7 +2652,7 @@ int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity) {
     out[4] = h->last_grid;                                                        // workgroups of the last one-launch iteration
     out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm) : 4;
     out[6] = h->win ? h->nwt_int : h->nt_int;
-    out[7] = 0;
+    out[7] = h->win ? h->win_order : 0;
     std::vector<int32_t> rows((size_t)nt * 2);
     if (h->win) {
         std::vector<WTile> t((size_t)nt);

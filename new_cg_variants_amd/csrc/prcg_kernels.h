@@ -216,6 +216,7 @@ struct WinDev {
     const unsigned char* vidx8;    // null: plain values
     const double* vdict;
     const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r)
+    int order;                     // 1: XCD-chunked tile order (each XCD sweeps one contiguous eighth of the table), 0: chip-wide front
     int period;                    // > 1: tiles t and t + period read the same stream images (host: the launch picks a wave
                                    // count that is a multiple of it, so that a wave meets the same image tile after tile)
 };

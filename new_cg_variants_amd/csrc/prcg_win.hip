@@ -48,6 +48,9 @@ namespace {
 #ifndef PRCG_WIN_UNIFORM_ROWS
 #define PRCG_WIN_UNIFORM_ROWS 1  // 0: no scalar-value / scalar-offset row walk (A/B builds)
 #endif
+#ifndef PRCG_WIN_WPB_MAX
+#define PRCG_WIN_WPB_MAX 4        // largest workgroup (waves) of the non-deferred window kernels (A/B builds: 8, 16)
+#endif
 #ifndef PRCG_WIN_ROW_CACHE
 #define PRCG_WIN_ROW_CACHE 1      // 0: the dictionary kernels re-read their shared stream images for every tile (A/B builds)
 #endif
@@ -814,6 +817,23 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
     const int nblk = gridDim.x;
     int W = nblk * WPB;
     int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
+    int tend = ntiles;                       // the wave's tiles: t, t + W, ... below tend
+    if constexpr (DEF == 0) {
+        if (A.order == 1) {
+            // XCD-chunked order: the workgroups of one XCD (round-robin dispatch: workgroup b runs on XCD b % 8) sweep ONE
+            // contiguous eighth of the tile table, front by front, instead of every eighth tile-range of a chip-wide front.
+            // A 3-D stencil's plane neighbours (+-365 tiles at S2) are then rows the SAME XCD staged a round earlier or will
+            // own a round later -- they meet in its L2 instead of being read through the fabric by three XCDs (S2: 0.67 -> 0.39 GB read
+            // per launch, but 2 % slower: opt-in, PRCG_WIN_ORDER=1).
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = nblk >> 3, r = nblk & 7;
+            const int nbx = q + (xcd < r ? 1 : 0);
+            const int before = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            const int lo = (int)((long long)ntiles * before / nblk);
+            tend = (int)((long long)ntiles * (before + nbx) / nblk);
+            W = nbx * WPB;
+            t = lo + idx * WPB + wv;
+        }
+    }
     bool relay = false;
     if constexpr (DEF > 0) {
         if (fz.px) {
@@ -856,13 +876,13 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         d[i] = WDesc<PG>{};
         pend[i] = false;
         same[i] = false;
-        if (t + i * W < ntiles) {
+        if (t + i * W < tend) {
             d[i] = read_desc<PG>(wt, t + i * W);
             if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg);
             else pend[i] = true;
         }
     }
-    if (t + DEPTH * W < ntiles) dn = read_desc<PG>(wt, t + DEPTH * W);
+    if (t + DEPTH * W < tend) dn = read_desc<PG>(wt, t + DEPTH * W);
 
     if constexpr (DEF > 0) {
         static_assert(DEPTH == 1, "the deferred form keeps one image per wave");
@@ -993,19 +1013,19 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         }
     }
 
-    while (t < ntiles) {
+    while (t < tend) {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) {
-            if (t < ntiles) {
+            if (t < tend) {
                 const WDesc<PG> dcur = d[i];
                 const int tnext = t + DEPTH * W;
-                const bool have_next = tnext < ntiles;
+                const bool have_next = tnext < tend;
                 d[i] = dn;
                 const bool acq = DEF > 0 && have_next && tnext >= safe && !acquired;
                 same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], nullptr, acq, t);
                 if (acq) acquired = true;
                 // descriptor of the tile after that one: loaded now, looked at one step later
-                if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
+                if (tnext + W < tend) dn = read_desc<PG>(wt, tnext + W);
                 t += W;
             }
         }
@@ -1033,7 +1053,12 @@ constexpr int waves_per_block(int nv, int pg, int cw, bool vd) {
 #ifdef PRCG_WIN_WPB
     return PRCG_WIN_WPB;
 #else
-    return 4 * lds_bytes_per_wave(nv, pg, cw, vd) <= 80 * 1024 ? 4 : 2;
+    // (PRCG_WIN_WPB_MAX > 4: all the waves that stream best on one CU -- 16 dictionary, 8 plain -- in ONE or two workgroups,
+    //  where their LDS slices fit the CU)
+    const int per = lds_bytes_per_wave(nv, pg, cw, vd), resident = vd ? 16 : 8;
+    for (int w = PRCG_WIN_WPB_MAX; w > 4; w /= 2)
+        if (w <= resident && resident * per <= 156 * 1024) return w;
+    return 4 * per <= 80 * 1024 ? 4 : 2;
 #endif
 }
 // ... of the deferred form: one wave on EACH SIMD of the CU (see defer_grid_per_cu) for the 64-row geometries; the 128-row

@@ -17,6 +17,7 @@ bench.py times and every solve uses by default): its inner products are summed
   lane l of wave (block b, wave v): rows rb + j*64 + l (j = 0..M-1) of tiles  slot, slot + W, slot + 2W, ...
                                     with slot = xcd_remap(b) * WPB + v,  W = grid * WPB  (in that order)
   wave  : xor butterfly             block : waves 0..WPB-1 in order  ->  one partial per workgroup
+  (XCD-chunked order, layout['xcd_chunked']: workgroup b sweeps the share of XCD b % 8 of the table instead)
   final : the 256-thread tree over the workgroups' partials (thread t: partials t, t+256, ...; butterfly;
           4 waves in order) -- by every workgroup of the NEXT launch in its prologue (sum_prev_partials) or
           by k_reduce_final when a prcg_iterate call ends: the same tree either way
@@ -118,20 +119,29 @@ class OneLaunchTree:
         M = int(layout['rows_per_tile']) // 64
         nt = tiles.shape[0]
         W = grid * wpb
-        per_wave = (nt + W - 1) // W
+        chunked = bool(layout.get('xcd_chunked', False))
+        per_wave = (nt + W - 1) // W + (2 if chunked else 0)
         # idx[b, v, step, lane] = row summed by that lane at that step, -1: none
         idx = -np.ones((grid, wpb, per_wave * M, 64), dtype=np.int64)
         lane = np.arange(64)
         for b in range(grid):
             for v in range(wpb):
-                slot = xcd_remap(b, grid) * wpb + v
-                for i, t in enumerate(range(slot, nt, W)):
+                if chunked:
+                    # XCD-chunked order (k_win_tiles, A.order == 1): XCD b % 8 sweeps its contiguous share of the table
+                    xcd, ix, q, r = b & 7, b >> 3, grid >> 3, grid & 7
+                    nbx = q + (1 if xcd < r else 0)
+                    before = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+                    lo, hi = nt * before // grid, nt * (before + nbx) // grid
+                    seq = range(lo + ix * wpb + v, hi, nbx * wpb)
+                else:
+                    seq = range(xcd_remap(b, grid) * wpb + v, nt, W)
+                for i, t in enumerate(seq):
                     rb, re = tiles[t]
                     for j in range(M):
                         rows = rb + j * 64 + lane
                         idx[b, v, i * M + j] = np.where(rows < re, rows, -1)
         self.idx = idx
-        self.grid, self.wpb = grid, wpb
+        self.grid, self.wpb, self.chunked = grid, wpb, chunked
         covered = np.sort(idx[idx >= 0])
         assert np.array_equal(covered, np.arange(tiles[:, 0].min(), tiles[:, 1].max())), 'every row summed exactly once'
 

@@ -426,7 +426,8 @@ def test_whole_trajectory_against_device_ordered_oracle(amd, matrices, matrix, f
 
 @pytest.mark.parametrize('matrix,method,max_iter', [
     ('bcsstk03', 'pipe_pr_cg', 1250), ('nos7', 'pipe_pr_cg', 3000), ('bcsstk03', 'pipe_p_cg', 600), ('nos7', 'pipe_pr_m_cg', 600),
-    ('s3_small', 'pipe_pr_cg', 300), ('lap2d_300', 'pipe_pr_cg', 200), ('lap3d_40', 'pipe_p_m_cg', 150)])
+    ('s3_small', 'pipe_pr_cg', 300), ('lap2d_300', 'pipe_pr_cg', 200), ('lap3d_40', 'pipe_p_m_cg', 150),
+    ('lap3d_40_chunked', 'pipe_pr_cg', 150), ('lap2d_300_chunked', 'pipe_pr_m_cg', 100)])
 def test_whole_trajectory_of_the_one_launch_schedule(amd, matrices, matrix, method, max_iter):
     """The strongest parity test, on the schedule that ships (one launch per iteration: what bench.py times and every
     solve uses by default; PRCG_SMALL=0 keeps the one-workgroup solver of tiny systems out of the way).  The oracle
@@ -441,12 +442,16 @@ def test_whole_trajectory_of_the_one_launch_schedule(amd, matrices, matrix, meth
     else:
         # tens to hundreds of workgroups: the XCD remap, several tiles per wave and (stencils) 128-row tiles with two rows per lane
         P = amd['problems']
+        # (..._chunked: the XCD-chunked tile order that 3-D stencils with far plane neighbours get by themselves, forced here)
         A = {'s3_small': lambda: P.WORKLOADS['s3_small']['make'](), 'lap2d_300': lambda: P.laplace_2d(300, 200),
-             'lap3d_40': lambda: P.laplace_3d(40, 40, 40)}[matrix]()
+             'lap3d_40': lambda: P.laplace_3d(40, 40, 40)}[matrix.replace('_chunked', '')]()
         b_, _, xt_ = P.reference_rhs(A, A.shape[0])
         z = {'b': b_, 'x_true': xt_}
     n = A.shape[0]
-    op = amd['device'].DeviceCSR(A, knobs={'PRCG_SMALL': '0'})
+    knobs = {'PRCG_SMALL': '0'}
+    if matrix.endswith('_chunked'):
+        knobs['PRCG_WIN_ORDER'] = '1'
+    op = amd['device'].DeviceCSR(A, knobs=knobs)
     variant = getattr(L, VARIANT_OF[method])
     # (a) all four recorders: a reduction launch after every iteration
     op.begin(variant, z['b'], np.zeros(n), max_iter, x_true=z['x_true'], hist_mask=15)
@@ -458,6 +463,7 @@ def test_whole_trajectory_of_the_one_launch_schedule(amd, matrices, matrix, meth
     got = np.array([op.get_scalars(k)[[L.S_MU, L.S_DELTA, L.S_GAMMA, L.S_NU]] for k in range(max_iter)])
     hist = op.history()
     tree = OneLaunchTree(op.layout())
+    assert tree.chunked == matrix.endswith('_chunked')
     # (b) no recorder but the recurrence residual: partials summed by the next launch's prologue, calls of any length
     op.begin(variant, z['b'], np.zeros(n), max_iter, hist_mask=1)
     assert op.schedule()['fused'] and not op.schedule()['small']
