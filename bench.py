@@ -383,6 +383,29 @@ def main():
                         'comm_us_per_iteration': legp['us_per_iteration'], 'comm': legp,
                         'single_gpu_us_per_iteration': plain[0] / K * 1e6,
                         'speedup_ceiling_at_8_ranks': (plain[0] / K * 1e6) / legp['us_per_iteration'] if legp['us_per_iteration'] > 0 else None}
+                # one rank's share of S2 (BASELINE config 4) on 8 GPUs: 27 grid planes, a halo of one 216 x 216 plane per side
+                # (746 KB of pairs each way) -- the same two schedules, dictionary and plain values
+                wl2 = problems.WORKLOADS['s2_8th']
+                A2 = wl2['make']()
+                b2, x2, _ = problems.reference_rhs(A2, wl2['n'])
+                d2 = (1.0 / A2.diagonal()) if inv_diag is not None else None
+                A2_loop, halo2, _ = partition.loopback_problem(A2, 216 * 216, cut=13 * 216 * 216)
+                rec2 = {'what': "one rank's share of S2 on 8 GPUs (216 x 216 x 27, n = 1,259,712) on this GPU: plain one-launch schedule, "
+                                'and the multi-rank schedule with a loopback halo of one grid plane per side'}
+                for key, kn in (('dict', None), ('plain_values', {'PRCG_VALDICT': '0'})):
+                    if key == 'plain_values' and plain is None:
+                        continue
+                    dp = DeviceCSR(A2, device=local_rank, knobs=kn)
+                    ep, _, _, _, _ = timed_run(dp, variant, b2, x2, d2)
+                    dp.close()
+                    leg2 = comm_leg(A2_loop, halo2, b2, x2, d2, kn)
+                    r2 = {'plain_us_per_iteration': ep / K * 1e6, 'comm_us_per_iteration': leg2['us_per_iteration'], 'comm': leg2}
+                    if key == 'dict':
+                        rec2.update(r2)
+                    else:
+                        rec2['plain_values'] = r2
+                multi['s2_8th'] = rec2
+                del A2, A2_loop
         except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it
             multi = dict(multi or {}, error=str(exc)[:300])
 

@@ -221,6 +221,8 @@ int prcg_iteration(const prcg_t* h);
                                       for the reduced inner products of the previous iteration */
 #define PRCG_SCHED_SELL 32768  /* lane-per-row kernels over 64-row slices (medium-length rows: assembled FEM matrices) */
 #define PRCG_SCHED_PEER 16384  /* ... through the direct peer exchange (prcg_peer_setup / prcg_peer_connect): no collective in the loop */
+#define PRCG_SCHED_PATTERN 65536 /* ... window kernels over PATTERN tiles (constant-coefficient stencils): no per-nonzero stream at all --
+                                    per tile one pattern record (slot offsets + values) and the rows' 16-bit slot masks */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
 /* A preconditioner that is not a diagonal scaling: `fn(ctx, n, v, out)` must write M^-1 v to out (host buffers,
@@ -298,6 +300,17 @@ int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const
  * window operator, -1 on a bad argument.  Exported for the CPU tests. */
 int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices,
                             const uint8_t* row_class, int rows_per_tile, int share, int64_t* out);
+/* Pattern tiles (what prcg_set_csr tries first for short rows; csrc/prcg_plan.h: plan_window_patterns): 64-row window
+ * tiles of at most 6 pages whose rows share one sequence of <= 16 slots (window offset relative to the lane + value)
+ * and differ only in which slots they have -- a constant-coefficient stencil.  tiles_out: 24 int32 per tile (the 20 of
+ * prcg_plan_window, then pattern id, 0, first mask of the tile in masks_out, 1 if every row has every slot);
+ * pat_out: 72 bytes per pattern {int32 slots, uint32 value selectors (2 bits per slot), int16 offset[16], double
+ * value[4]}; masks_out: uint16 per row of the tiles with incomplete rows.  counts_out[0..3) = {tiles, patterns, masks}.
+ * Returns 1, 0 if the operator does not qualify, -needed tiles if a capacity is too small, -1 on a bad argument.
+ * The kernels read nothing else of the operator: the CPU test rebuilds the matrix from these arrays. */
+int64_t prcg_plan_window_patterns(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const double* data,
+                                  const uint8_t* row_class, int32_t* tiles_out, int64_t tile_capacity, void* pat_out,
+                                  int64_t pat_capacity, uint16_t* masks_out, int64_t mask_capacity, int64_t* counts_out);
 /* Sliced rows (lane-per-row kernels for operators with medium-length rows that are no window operators -- assembled FEM
  * matrices): rows are cut into slices of up to 64 consecutive rows of one class (class-0 slices first); nonzero u of the
  * row in lane l of a slice is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus

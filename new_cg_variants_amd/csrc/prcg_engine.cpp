@@ -124,6 +124,9 @@ struct prcg_handle {
     bool win = false;
     int win_geom = 0, win_rows = 0;
     bool win_vd = false;
+    bool win_pat = false;        // pattern tiles (geometry 5): no index streams, the rows' slot masks in wrel, records in wpat
+    bool want_pat = true;        // PRCG_WIN_PAT=0: constant-coefficient stencils keep the stream geometries
+    DevBuf wpat;
     int nwt_int = 0, nwt_bnd = 0;
     DevBuf wtiles, wcw, wvidx, wvdict, wrel;
     // ---- sliced rows (lane-per-row kernels for medium-length rows, prcg_sell.hip): all rows of the operator or none ----
@@ -133,6 +136,7 @@ struct prcg_handle {
     int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
     DevBuf sval, scol, sslices;
+    bool want_big = true;                // PRCG_WIN_BIG=0: short launches keep the small workgroups too
     int win_order = 0;                   // 1: XCD-chunked tile order of the window launches (opt-in: PRCG_WIN_ORDER=1)
     int win_order_override = -1;
     int win_period = 0;                  // tiles t and t + win_period read the same stream images (0: no such period found)
@@ -248,7 +252,8 @@ struct prcg_handle {
                       b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
                       win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
                       win_vd ? static_cast<const double*>(wvdict.p) : nullptr,
-                      static_cast<const unsigned short*>(wrel.p), win_order, win_period};
+                      static_cast<const unsigned short*>(wrel.p), static_cast<const PatRec*>(wpat.p), want_big ? 1 : 0, win_order,
+                      win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
     SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p)}; }
@@ -1240,6 +1245,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL") h->want_sell = v != 0;
     else if (k == "PRCG_CG_ONE") h->want_cg_one = v != 0;
     else if (k == "PRCG_WIN_ORDER") h->win_order_override = v != 0;
+    else if (k == "PRCG_WIN_BIG") h->want_big = v != 0;
+    else if (k == "PRCG_WIN_PAT") h->want_pat = v != 0;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1254,7 +1261,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1514,7 +1521,25 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     std::vector<WTile> wall;
     std::vector<uint8_t> wvidx;
     std::vector<double> wvdict;
-    if (h->want_win && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)h->win_max_mean * n_rows) {
+    // pattern tiles first (constant-coefficient stencils: 64-row tiles, at most kWinPatPages pages, every tile one pattern --
+    // prcg_plan.h: plan_window_patterns): no per-nonzero stream at all
+    h->win_pat = false;
+    std::vector<PatRec> pats;
+    std::vector<uint16_t> pmasks;
+    if (h->want_win && h->want_pat && h->want_vdict && !h->win_rows_override && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)kPatSlots * n_rows) {
+        WinPlan wq;
+        plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, 64, kWinCapNnz, kWinPatPages, wq);
+        if (wq.ok0 && wq.ok1 && wq.t0.size() + wq.t1.size() < (size_t)(1 << 26)) {
+            std::vector<WTile> wa(wq.t0);
+            wa.insert(wa.end(), wq.t1.begin(), wq.t1.end());
+            if (plan_window_patterns(wa, ip.data(), wq.cw.data(), data, pats, pmasks)) {
+                h->win = true; h->win_pat = true; h->win_vd = true; h->win_geom = kWinPatGeom; h->win_rows = 64;
+                wall.swap(wa);
+                wp.t0.swap(wq.t0); wp.t1.swap(wq.t1);
+            }
+        }
+    }
+    if (!h->win_pat && h->want_win && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)h->win_max_mean * n_rows) {
         const int rows = h->win_rows_override ? h->win_rows_override : (nnz < 10 * n_rows ? 128 : 64);
         plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, rows, kWinCapNnz,
                           win_max_pages(rows), wp);
@@ -1688,7 +1713,16 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         std::vector<uint8_t> vstore;
         std::vector<uint16_t> rstore;
         size_t cw_bytes = 0;
-        if (h->win_geom >= 2) {
+        if (h->win_pat) {
+            // pattern tiles: the rows' slot masks take the place of the row pointers; no window-index / value-index images
+            rstore.swap(pmasks);
+            rstore.resize(rstore.size() + 64, 0);
+            HIPCHK(h, h->wcw.alloc(64));
+            HIPCHK(h, h->wpat.alloc((pats.size() + 1) * sizeof(PatRec)));
+            HIPCHK(h, hipMemcpy(h->wpat.p, pats.data(), pats.size() * sizeof(PatRec), hipMemcpyHostToDevice));
+            cw_bytes = pats.size() * sizeof(PatRec);
+            vstore.assign(64, 0);
+        } else if (h->win_geom >= 2) {
             std::vector<uint16_t> cstore;
             share_window_streams<uint16_t>(wall, ip.data(), wp.cw.data(), h->win_vd ? wvidx.data() : nullptr, h->want_share,
                                            cstore, vstore, rstore);
@@ -1707,7 +1741,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         // period of the images over the interior tiles (a stencil on a regular grid: a grid line, a grid plane): the
         // smallest P with image(t + P) == image(t) for every t of a long stretch in the middle of the table
         h->win_period = 0;
-        if (h->want_share && h->win_vd && wp.t0.size() > 4096) {
+        if (h->want_share && h->win_vd && !h->win_pat && wp.t0.size() > 4096) {
             const size_t nt0 = wp.t0.size(), t0 = nt0 / 3;
             for (size_t P = 2; P <= 4096 && t0 + 3 * P < nt0; ++P) {
                 if (wall[t0 + P].spare != wall[t0].spare || wall[t0].spare == 0) continue;
@@ -1726,7 +1760,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         HIPCHK(h, h->wtiles.alloc((wall.size() + 1) * sizeof(WTile)));
         HIPCHK(h, hipMemcpy(h->wtiles.p, wall.data(), wall.size() * sizeof(WTile), hipMemcpyHostToDevice));
         h->win_stream_bytes = (int64_t)(wall.size() * sizeof(WTile) + cw_bytes + rstore.size() * sizeof(uint16_t)) +
-                              (h->win_vd ? (int64_t)(vstore.size() + wvdict.size() * sizeof(double)) : (int64_t)nnz * 8);
+                              (h->win_pat ? 0 : (h->win_vd ? (int64_t)(vstore.size() + wvdict.size() * sizeof(double)) : (int64_t)nnz * 8));
         if (h->win_vd) {
             HIPCHK(h, h->wvidx.alloc(vstore.size()));
             HIPCHK(h, hipMemcpy(h->wvidx.p, vstore.data(), vstore.size(), hipMemcpyHostToDevice));
@@ -2378,7 +2412,7 @@ int prcg_schedule(const prcg_t* h) {
            (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
-           (h->win ? (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16) | PRCG_SCHED_WINDOW
+           (h->win ? (h->win_pat ? PRCG_SCHED_PATTERN : (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16)) | PRCG_SCHED_WINDOW
                    : (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0)));
 }
 
@@ -2591,6 +2625,29 @@ int64_t prcg_plan_window(int64_t n, int64_t n_cols, const int32_t* indptr, const
     return total;
 }
 
+int64_t prcg_plan_window_patterns(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const double* data,
+                                  const uint8_t* row_class, int32_t* tiles_out, int64_t tile_capacity, void* pat_out,
+                                  int64_t pat_capacity, uint16_t* masks_out, int64_t mask_capacity, int64_t* counts_out) {
+    if (n < 0 || n_cols < n || !indptr || (indptr[n] > 0 && (!indices || !data)) || !counts_out) return -1;
+    WinPlan wp;
+    plan_window_tiles(n, n_cols, indptr, indices, row_class, 64, kWinCapNnz, kWinPatPages, wp);
+    if (!wp.ok0 || !wp.ok1) return 0;
+    std::vector<WTile> all(wp.t0);
+    all.insert(all.end(), wp.t1.begin(), wp.t1.end());
+    std::vector<PatRec> pats;
+    std::vector<uint16_t> masks;
+    if (!plan_window_patterns(all, indptr, wp.cw.data(), data, pats, masks)) return 0;
+    counts_out[0] = (int64_t)all.size(); counts_out[1] = (int64_t)pats.size(); counts_out[2] = (int64_t)masks.size();
+    if ((int64_t)all.size() > tile_capacity || (int64_t)pats.size() > pat_capacity || (int64_t)masks.size() > mask_capacity ||
+        !tiles_out || !pat_out || !masks_out)
+        return -(int64_t)all.size();
+    static_assert(sizeof(WTile) == 24 * sizeof(int32_t), "24 int32 per tile");
+    memcpy(tiles_out, all.data(), all.size() * sizeof(WTile));
+    memcpy(pat_out, pats.data(), pats.size() * sizeof(PatRec));
+    memcpy(masks_out, masks.data(), masks.size() * sizeof(uint16_t));
+    return 1;
+}
+
 int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const uint8_t* row_class,
                             int rows_per_tile, int share, int64_t* out) {
     if (n < 0 || n_cols < n || !indptr || (indptr[n] > 0 && !indices) || (rows_per_tile != 64 && rows_per_tile != 128) || !out)
@@ -2650,7 +2707,7 @@ int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity) {
     out[2] = h->win ? h->win_rows : 0;
     out[3] = nt;
     out[4] = h->last_grid;                                                        // workgroups of the last one-launch iteration
-    out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm) : 4;
+    out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm, h->nwt_int + h->nwt_bnd, h->want_big) : 4;
     out[6] = h->win ? h->nwt_int : h->nt_int;
     out[7] = h->win ? h->win_order : 0;
     std::vector<int32_t> rows((size_t)nt * 2);

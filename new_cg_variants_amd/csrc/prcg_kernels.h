@@ -208,6 +208,19 @@ struct alignas(16) WTile {
 };
 #endif
 static_assert(sizeof(WTile) == 96, "the kernels read a window tile descriptor as six int4");
+#ifndef PRCG_PATREC_DEFINED
+#define PRCG_PATREC_DEFINED
+// pattern tiles (prcg_plan.h: plan_window_patterns): constant-coefficient stencils without index streams
+constexpr int kPatSlots = 16;
+constexpr int kPatValues = 4;
+struct alignas(8) PatRec {
+    int nslots;
+    unsigned vsel;
+    short cb[kPatSlots];
+    double val[kPatValues];
+};
+static_assert(sizeof(PatRec) == 72, "the kernels read a pattern record with scalar loads");
+#endif
 struct WinDev {
     const int* indptr;
     const double* val;
@@ -215,7 +228,9 @@ struct WinDev {
     const unsigned short* cw16;    // geometry 2, 3
     const unsigned char* vidx8;    // null: plain values
     const double* vdict;
-    const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r)
+    const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r); geometry 5: the rows' slot masks
+    const PatRec* pat;             // geometry 5: the pattern records (tile.src_c = pattern id)
+    int big_ok;                    // short launches of the one-launch iteration may take big workgroups (PRCG_WIN_BIG=0: never)
     int order;                     // 1: XCD-chunked tile order (each XCD sweeps one contiguous eighth of the table), 0: chip-wide front
     int period;                    // > 1: tiles t and t + period read the same stream images (host: the launch picks a wave
                                    // count that is a multiple of it, so that a wave meets the same image tile after tile)
@@ -223,6 +238,9 @@ struct WinDev {
 // geometry id of a class planned with rows_per_tile (64 | 128) whose tiles need at most most_pages
 // pages: 0 = 64 rows / 2 pages / 8-bit indices, 1 = 64 / 4 / 8-bit, 2 = 128 / 8 / 16-bit, 3 = 128 / 12 / 16-bit,
 // 4 = 64 / 8 / 16-bit (3-D stencils in 64-row tiles: images repeat with the period of a grid plane)
+// 5 = 64 rows / 6 pages / PATTERN tiles (constant-coefficient stencils, no index streams; chosen by prcg_set_csr when every
+//     tile qualifies, prcg_plan.h: plan_window_patterns)
+constexpr int kWinPatGeom = 5, kWinPatPages = 6;
 inline int win_geometry(int rows_per_tile, int most_pages) {
     if (rows_per_tile == 64) return most_pages <= 2 ? 0 : (most_pages <= 4 ? 1 : (most_pages <= 8 ? 4 : -1));
     if (rows_per_tile == 128) return most_pages <= 8 ? 2 : (most_pages <= 12 ? 3 : -1);
@@ -238,7 +256,7 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
 int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
                           int per_cu);
 // waves per workgroup of that launch (the inner products' summation order depends on it: prcg_debug_layout)
-int win_fused_waves_per_block(int geom, bool value_dict, bool deferred);
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok);
 // Second of the TWO launches of a Hestenes-Stiefel iteration on a window operator (hs_cg.py:57-61,
 // hs_pcg :120-124).  The first (launch_hs_update_xr with `prev`) left nu_k = <r~,r> as block partials;
 // every workgroup of this launch sums them in the same fixed order, b_k = nu_k / nu_k1, and the window of

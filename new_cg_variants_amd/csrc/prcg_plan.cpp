@@ -237,6 +237,150 @@ bool plan_window_dict(std::vector<WTile>& tiles, const double* data, int dict_ma
 
 namespace {
 
+// one tile's pattern record and slot masks; false: the tile is no pattern tile
+bool pattern_of_tile(const WTile& t, const int32_t* indptr, const uint16_t* cw, const double* data, PatRec& rec, uint16_t (&m)[64],
+                     bool& full) {
+    if (t.re - t.rb > 64 || t.re <= t.rb) return false;
+    // slots: the distinct d = window index - lane over the tile; one value per slot; `succ`: slot a directly precedes slot b
+    // in some row (the rows' own order is what the sum follows -- in a row block ghost columns are numbered behind the
+    // owned ones, so a row's columns need not ascend)
+    int nd = 0;
+    int dv[kPatSlots];
+    uint64_t bits[kPatSlots];
+    unsigned succ[kPatSlots];
+    for (int u = 0; u < kPatSlots; ++u) succ[u] = 0u;
+    for (int r = t.rb; r < t.re; ++r) {
+        const int lane = r - t.rb;
+        int before = -1;
+        unsigned seen = 0u;
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int d = (int)cw[q] - lane;
+            uint64_t b;
+            memcpy(&b, &data[q], sizeof b);
+            int u = 0;
+            while (u < nd && dv[u] != d) ++u;
+            if (u == nd) {
+                if (nd == kPatSlots) return false;
+                dv[nd] = d; bits[nd] = b; ++nd;
+            } else if (bits[u] != b) {
+                return false;                                         // the slot's value differs between rows
+            }
+            if (seen & (1u << u)) return false;                       // a column twice in one row
+            seen |= 1u << u;
+            if (before >= 0) succ[before] |= 1u << u;
+            before = u;
+        }
+    }
+    // one order of the slots that every row follows: topological (ties: ascending d); a cycle = rows disagree
+    int order[kPatSlots];
+    {
+        unsigned placed = 0u;
+        for (int k = 0; k < nd; ++k) {
+            int pick = -1;
+            for (int u = 0; u < nd; ++u) {
+                if (placed & (1u << u)) continue;
+                bool ready = true;
+                for (int v = 0; v < nd && ready; ++v)
+                    if (!(placed & (1u << v)) && v != u && (succ[v] & (1u << u))) ready = false;
+                if (ready && (pick < 0 || dv[u] < dv[pick])) pick = u;
+            }
+            if (pick < 0) return false;
+            order[k] = pick;
+            placed |= 1u << pick;
+        }
+    }
+    memset(&rec, 0, sizeof rec);
+    rec.nslots = nd;
+    int nvals = 0;
+    uint64_t vbits[kPatValues];
+    for (int k = 0; k < nd; ++k) {
+        const int u = order[k];
+        if (dv[u] < -32768 || dv[u] > 32767) return false;
+        rec.cb[k] = (short)dv[u];
+        int v = 0;
+        while (v < nvals && vbits[v] != bits[u]) ++v;
+        if (v == nvals) {
+            if (nvals == kPatValues) return false;
+            vbits[nvals++] = bits[u];
+        }
+        rec.vsel |= (unsigned)v << (2 * k);
+    }
+    for (int v = 0; v < nvals; ++v) memcpy(&rec.val[v], &vbits[v], sizeof(double));
+    // masks of the rows (lanes past the tile's last row: 0)
+    memset(m, 0, sizeof m);
+    full = (t.re - t.rb) == 64;
+    const unsigned all = nd >= 16 ? 0xffffu : ((1u << nd) - 1u);
+    for (int r = t.rb; r < t.re; ++r) {
+        const int lane = r - t.rb;
+        unsigned mk = 0;
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int d = (int)cw[q] - lane;
+            int k = 0;
+            while (rec.cb[k] != d) ++k;
+            mk |= 1u << k;
+        }
+        m[lane] = (uint16_t)mk;
+        if (mk != all) full = false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool plan_window_patterns(std::vector<WTile>& tiles, const int32_t* indptr, const uint16_t* cw, const double* data,
+                          std::vector<PatRec>& patterns, std::vector<uint16_t>& masks) {
+    struct Plan { int pat; int64_t mask_at; int full; int nslots; };
+    PatRec rec;
+    uint16_t m[64];
+    bool full = false;
+    // a few tiles first (a band whose diagonal varies only near one end fails at that end)
+    if (tiles.empty()) return false;
+    for (size_t k = 0; k <= 8; ++k) {
+        const size_t ti = (tiles.size() - 1) * k / 8;
+        if (!pattern_of_tile(tiles[ti], indptr, cw, data, rec, m, full)) return false;
+    }
+    std::vector<Plan> plan(tiles.size());
+    std::unordered_map<uint64_t, std::vector<int>> pat_index;            // hash of a record -> pattern ids
+    std::unordered_map<uint64_t, std::vector<int64_t>> mask_index;        // hash of 64 masks -> positions
+    std::vector<PatRec> pats;
+    std::vector<uint16_t> mstore;
+    for (size_t ti = 0; ti < tiles.size(); ++ti) {
+        if (!pattern_of_tile(tiles[ti], indptr, cw, data, rec, m, full)) return false;
+        // identical records / mask images are stored once
+        int pid = -1;
+        {
+            const uint64_t key = hash_bytes(&rec, sizeof rec, 0x51ED270B7A1F3C55ull);
+            auto& v = pat_index[key];
+            for (int id : v) if (memcmp(&pats[id], &rec, sizeof rec) == 0) { pid = id; break; }
+            if (pid < 0) { pid = (int)pats.size(); pats.push_back(rec); v.push_back(pid); }
+        }
+        int64_t at = 0;
+        if (!full) {
+            const uint64_t key = hash_bytes(m, sizeof m, 0x2545F4914F6CDD1Dull);
+            auto& v = mask_index[key];
+            at = -1;
+            for (int64_t pos : v) if (memcmp(mstore.data() + pos, m, sizeof m) == 0) { at = pos; break; }
+            if (at < 0) { at = (int64_t)mstore.size(); mstore.insert(mstore.end(), m, m + 64); v.push_back(at); }
+        }
+        if (at > INT32_MAX - 64 || pats.size() > (size_t)1 << 20) return false;
+        plan[ti] = Plan{pid, at, full ? 1 : 0, rec.nslots};
+    }
+    for (size_t ti = 0; ti < tiles.size(); ++ti) {
+        tiles[ti].src_c = plan[ti].pat;
+        tiles[ti].src_v = 0;
+        tiles[ti].src_r = (int)plan[ti].mask_at;
+        tiles[ti].spare = plan[ti].full;
+        tiles[ti].maxlen = plan[ti].nslots;
+        tiles[ti].vd_first = tiles[ti].vd_count = 0;
+    }
+    if (mstore.empty()) mstore.assign(64, 0);
+    patterns.swap(pats);
+    masks.swap(mstore);
+    return true;
+}
+
+namespace {
+
 // images already in a store: hash -> positions of their first element
 using ImageIndex = std::unordered_map<uint64_t, std::vector<int64_t>>;
 

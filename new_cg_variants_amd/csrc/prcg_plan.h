@@ -68,6 +68,35 @@ StreamStats share_window_streams(std::vector<WTile>& tiles, const int32_t* indpt
                                  bool share, std::vector<CW>& cw_store, std::vector<uint8_t>& vidx_store,
                                  std::vector<uint16_t>& rel_store);
 
+// ---- pattern tiles: constant-coefficient stencils without index streams --------------------------------
+// A 64-row window tile is a PATTERN tile if its rows share one sequence of at most kPatSlots "slots": slot u is the
+// nonzero at window index (lane + cb[u]) with value val[u], the same for every row that has it; a row is then its
+// 16-bit presence mask over the slots (rows at the edge of a grid lack neighbours).  Sorted, duplicate-free rows only
+// (a row's slots ascend with its columns, so the left-to-right sum of csr_matvec is the sum over its present slots in
+// slot order); at most kPatValues distinct bit patterns among a tile's values.  Lossless: (pattern, masks, pages)
+// reproduce every nonzero's column and value bits exactly -- tests/test_abi_and_planning.py rebuilds the matrix.
+// A 5- / 7- / 9-point stencil with constant coefficients qualifies tile by tile (few patterns in all); an operator is
+// taken as a whole or not at all.  The kernels then read NO per-nonzero stream: per tile the pattern (scalar loads, a few
+// records for the whole operator) and, for tiles with incomplete rows, 128 bytes of masks (shared between identical
+// tiles like the other stream images).
+#ifndef PRCG_PATREC_DEFINED
+#define PRCG_PATREC_DEFINED
+constexpr int kPatSlots = 16;
+constexpr int kPatValues = 4;
+struct alignas(8) PatRec {
+    int nslots;                 // U
+    unsigned vsel;              // 2 bits per slot: which of val[] the slot's value is
+    short cb[kPatSlots];        // slot u sits at window index lane + cb[u]  (may be negative for lanes without the slot)
+    double val[kPatValues];     // the caller's doubles, bit for bit
+};
+static_assert(sizeof(PatRec) == 72, "the kernels read a pattern record with scalar loads");
+#endif
+// tiles: window tiles planned with 64 rows per tile (geo, page_col set), cw: their window indices.  On success every
+// tile's src_c = pattern id, src_r = start of its 64 masks in `masks`, spare = 1 if all 64 rows have every slot (no
+// mask needed) else 0, maxlen = number of slots.  Returns false if some tile does not qualify (tiles unchanged then).
+bool plan_window_patterns(std::vector<WTile>& tiles, const int32_t* indptr, const uint16_t* cw, const double* data,
+                          std::vector<PatRec>& patterns, std::vector<uint16_t>& masks);
+
 // ---- sliced rows (prcg_sell.hip) ---------------------------------------------------------------
 // Slices of up to 64 consecutive rows of one class (interior slices first).  Within a slice of width w (its longest
 // row), nonzero u of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4]

@@ -48,9 +48,6 @@ namespace {
 #ifndef PRCG_WIN_UNIFORM_ROWS
 #define PRCG_WIN_UNIFORM_ROWS 1  // 0: no scalar-value / scalar-offset row walk (A/B builds)
 #endif
-#ifndef PRCG_WIN_WPB_MAX
-#define PRCG_WIN_WPB_MAX 4        // largest workgroup (waves) of the non-deferred window kernels (A/B builds: 8, 16)
-#endif
 #ifndef PRCG_WIN_ROW_CACHE
 #define PRCG_WIN_ROW_CACHE 1      // 0: the dictionary kernels re-read their shared stream images for every tile (A/B builds)
 #endif
@@ -132,7 +129,7 @@ struct WRegs {
 // (64-row tiles with 1-byte window indices only: the 128-row stencil geometries rarely see the same image twice in a
 //  row -- S2's images repeat every 729 tiles -- and lose occupancy to the cache registers: S2 -17 %, S1 -5 % when tried)
 //  the 64-row geometry with 2-byte indices -- 3-D stencils -- caches rows of up to 8 nonzeros)
-constexpr int win_row_cache_len(int m, int cw, bool vd) { return (vd && PRCG_WIN_ROW_CACHE && m == 1) ? (cw == 8 ? 16 : 8) : 0; }
+constexpr int win_row_cache_len(int m, int cw, bool vd) { return (vd && PRCG_WIN_ROW_CACHE && m == 1 && cw != 32) ? (cw == 8 ? 16 : 8) : 0; }
 template <int M, int RL, int CW>
 struct RowCache {
     unsigned c[M][RL > 0 ? RL * (CW / 8) / 4 : 1];   // window indices of row (rb + j*64 + lane), nonzero u at byte / half-word u
@@ -147,6 +144,36 @@ struct RowCache {
     unsigned cbase[RL > 0 ? RL / 4 : 1];              // lane 0's packed window indices = the offsets cbase[u]
     unsigned vmask;                                   // bit u: value index of nonzero u (vdc <= 2)
 };
+// Pattern tiles (CW == 32; prcg_plan.h: plan_window_patterns): the wave's current pattern, wave-uniform (scalar registers),
+// re-read with scalar loads when a tile names another one (a stencil has a few patterns in all: grid edges)
+struct PatState {
+    int id, nslots;
+    unsigned vsel;
+    unsigned cb[kPatSlots / 2];            // two 16-bit signed offsets per word
+    double val[kPatValues];
+};
+__device__ __forceinline__ void load_pattern(const PatRec* __restrict__ pat, int id, PatState& ps) {
+    const unsigned* w = reinterpret_cast<const unsigned*>(pat + id);
+    ps.id = id;
+    ps.nslots = __builtin_amdgcn_readfirstlane((int)w[0]);
+    ps.vsel = __builtin_amdgcn_readfirstlane(w[1]);
+#pragma unroll
+    for (int k = 0; k < kPatSlots / 2; ++k) ps.cb[k] = __builtin_amdgcn_readfirstlane(w[2 + k]);
+#pragma unroll
+    for (int k = 0; k < kPatValues; ++k) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane(w[2 + kPatSlots / 2 + 2 * k]), hi = __builtin_amdgcn_readfirstlane(w[3 + kPatSlots / 2 + 2 * k]);
+        ps.val[k] = __hiloint2double((int)hi, (int)lo);
+    }
+}
+__device__ __forceinline__ int pat_offset(const PatState& ps, int u) {          // u: compile-time after unrolling
+    const unsigned w = ps.cb[u >> 1];
+    return (u & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+}
+__device__ __forceinline__ double pat_value(const PatState& ps, int u) {
+    const unsigned sel = (ps.vsel >> (2 * u)) & 3u;
+    return sel == 0u ? ps.val[0] : (sel == 1u ? ps.val[1] : (sel == 2u ? ps.val[2] : ps.val[3]));
+}
+
 template <int PG, int M, int RL, int CW>
 __device__ __forceinline__ bool same_image(const RowCache<M, RL, CW>& rc, const WDesc<PG>& d) {
     if constexpr (RL == 0) return false;
@@ -167,6 +194,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
     // branch-free: a lane whose chunk lies past the image re-reads its first chunk (hot line)
     const int len = (d.lo & 15) + (d.hi - d.lo);
     const int o16 = lane * 16 < len ? lane * 16 : 0;
+    if constexpr (CW == 32) {
+        // pattern tile: no index streams; the rows' slot masks unless every row has every slot (d.img)
+        static_assert(M == 1, "pattern tiles have 64 rows");
+        if (d.img == 0) R.s[0] = A.rel[d.srcr + lane];                      // wave-uniform
+    } else
     if (!skip_img) {                                                        // wave-uniform
     if constexpr (VD) {
         R.vi = *reinterpret_cast<const u4_t*>(A.vidx8 + d.srcv + o16);
@@ -232,7 +264,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
         const int row = d.rb + j * 64 + lane;
         const int rr = row < d.re ? row : d.rb;
         const int jj = row < d.re ? j * 64 + lane : 0;
-        if (!skip_img) {
+        if (CW != 32 && !skip_img) {
             R.s[j] = A.rel[d.srcr + jj];                 // row pointers relative to the tile's first nonzero
             R.e[j] = A.rel[d.srcr + jj + 1];
         }
@@ -343,7 +375,7 @@ template <int NV, int EPI, int M, int PG, int CW, bool VD, int RL, bool STASH = 
 __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
                                          double (&acc)[5], const Coefs& cf, RowCache<M, RL, CW>& rc, bool same_cur,
-                                         double2* stash = nullptr, bool acquire_first = false, int tcur = 0)
+                                         PatState& ps, double2* stash = nullptr, bool acquire_first = false, int tcur = 0)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -352,6 +384,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     const int pad = dcur.lo & 15;          // the staged stream starts at the 16-aligned nonzero below the tile's first
     // ---- park the tile's image in LDS (this is where the wave waits for ITS loads only: the
     //      loads of the tiles requested after it stay in flight) ----
+    if constexpr (CW == 32) {
+        if (dcur.srcc != ps.id) load_pattern(A.pat, dcur.srcc, ps);         // wave-uniform
+    } else
     if (!same_cur) {                                                        // wave-uniform
     if constexpr (VD) {
         *reinterpret_cast<u4_t*>(c.svi + lane * 16) = R.vi;
@@ -365,7 +400,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     }
     if constexpr (CW == 8) {
         *reinterpret_cast<u4_t*>(c.sc + lane * 16) = R.c[0];
-    } else {
+    } else if constexpr (CW == 16) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) *reinterpret_cast<u4_t*>(c.sc + (k * 512 + lane * 8) * 2) = R.c[k];
     }
@@ -547,7 +582,35 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                 }
             }
         }
-        for (int j0 = 0; j0 < (cached ? 0 : dcur.maxlen); j0 += kU) {
+        if constexpr (CW == 32) {
+            // pattern tile: slot u of every row that has it is val[u] * window[lane + cb[u]] -- scalar value, scalar offset, no
+            // index byte; rows at a grid edge skip the slots their mask lacks (same left-to-right sum over what the row has)
+            const bool full = dcur.img != 0;                                // wave-uniform
+            const unsigned mk = full ? 0xffffu : (unsigned)rs_[j];
+            const int cb0 = pat_offset(ps, 0);
+#pragma unroll
+            for (int u0 = 0; u0 < kPatSlots; u0 += 4) {
+                if (u0 < ps.nslots) {                                       // wave-uniform
+                    V g[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int cb = u0 + k < ps.nslots ? pat_offset(ps, u0 + k) : cb0;
+                        int idx = cb + lane;
+                        if (!full) idx = idx < 0 ? 0 : (idx > PG * 64 - 1 ? PG * 64 - 1 : idx);     // lanes without the slot: any valid entry
+                        g[k] = c.sw[idx];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (u0 + k < ps.nslots) {                           // wave-uniform
+                            const double a = pat_value(ps, u0 + k);
+                            if (full) vacc(sum, vmul(a, g[k]));
+                            else if ((mk >> (u0 + k)) & 1u) vacc(sum, vmul(a, g[k]));
+                        }
+                    }
+                }
+            }
+        }
+        for (int j0 = 0; j0 < ((cached || CW == 32) ? 0 : dcur.maxlen); j0 += kU) {
             int ci[kU];
             double a[kU];
             V g[kU];
@@ -723,14 +786,16 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
     using V = typename VecT<NV>::type;
     constexpr bool FUSED = epi_fused(EPI);
     static_assert(!FUSED || NV == 2, "the fused iteration works on (r,s) pairs");
-    static_assert(PG * 64 <= (CW == 8 ? 256 : 65536), "window index does not fit");
+    static_assert(PG * 64 <= (CW == 8 ? 256 : 32768), "window index does not fit");
     static_assert(DEPTH >= 1 && DEPTH <= 3, "one to three tiles in flight per wave");
     static_assert(DEF == 0 || (FUSED && DEF % DEPTH == 0), "the deferred tiles are whole turns of the image ring");
     __shared__ __attribute__((aligned(16))) double2 s_stash[WPB][DEF > 0 ? DEF * M * 64 : 1];
+    constexpr bool PAT = CW == 32;       // pattern tiles: no per-nonzero stream is parked at all
+    static_assert(!PAT || (VD && M == 1), "pattern tiles: 64 rows, values in the pattern records");
     __shared__ __attribute__((aligned(16))) double s_val[WPB][VD ? 2 : kWinSlots];
-    __shared__ __attribute__((aligned(16))) unsigned char s_vi[WPB][VD ? kWinSlots : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char s_col[WPB][kWinSlots * (CW / 8)];
-    __shared__ __attribute__((aligned(16))) double s_dict[WPB][VD ? kWinDictMax : 2];
+    __shared__ __attribute__((aligned(16))) unsigned char s_vi[WPB][(VD && !PAT) ? kWinSlots : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_col[WPB][PAT ? 16 : kWinSlots * (CW / 8)];
+    __shared__ __attribute__((aligned(16))) double s_dict[WPB][(VD && !PAT) ? kWinDictMax : 2];
     __shared__ __attribute__((aligned(16))) V s_win[WPB][PG * 64];
 
     const int lane = threadIdx.x & 63;
@@ -753,6 +818,52 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         }
     }
 
+    const int nblk = gridDim.x;
+    int W = nblk * WPB;
+    int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
+    int tend = ntiles;                       // the wave's tiles: t, t + W, ... below tend
+    if constexpr (DEF == 0) {
+        if (A.order == 1) {
+            // XCD-chunked order: the workgroups of one XCD (round-robin dispatch: workgroup b runs on XCD b % 8) sweep ONE
+            // contiguous eighth of the tile table, front by front, instead of every eighth tile-range of a chip-wide front.
+            // A 3-D stencil's plane neighbours (+-365 tiles at S2) are then rows the SAME XCD staged a round earlier or will
+            // own a round later -- they meet in its L2 instead of being read through the fabric by three XCDs (S2: 0.67 -> 0.39 GB read
+            // per launch, but 2 % slower: opt-in, PRCG_WIN_ORDER=1).
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = nblk >> 3, r = nblk & 7;
+            const int nbx = q + (xcd < r ? 1 : 0);
+            const int before = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            const int lo = (int)((long long)ntiles * before / nblk);
+            tend = (int)((long long)ntiles * (before + nbx) / nblk);
+            W = nbx * WPB;
+            t = lo + idx * WPB + wv;
+        }
+    }
+    bool relay = false;
+    if constexpr (DEF > 0) {
+        if (fz.px) {
+            // direct peer exchange: wave 0 of workgroup 0 is the launch's COMMUNICATION WAVE and takes no tiles -- it sends this
+            // rank's partial sums of the previous launch to every rank, waits for everybody's, and publishes the sums
+            // to the other waves, all while those compute the part of the iteration that needs neither
+            relay = t == 0;
+            W -= 1;
+            t = relay ? ntiles : t - 1;
+        }
+    }
+    // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
+    WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
+    WDesc<PG> d[DEPTH], dn = {};
+    // row cache (one image in flight per wave only: the cache then describes the tile processed just before)
+    constexpr int RL = DEPTH == 1 ? win_row_cache_len(M, CW, VD) : 0;
+    RowCache<M, RL, CW> rc;
+    rc.img = 0;
+    PatState ps;
+    ps.id = -1; ps.nslots = 0; ps.vsel = 0u;
+    bool same[DEPTH];
+    // deferred form: tiles from `safe` on read ghost rows that arrive with the publication -- their loads are
+    // postponed (pend) until the wave has seen it
+    const int safe = DEF > 0 ? (fz.nt_int < ntiles ? fz.nt_int : ntiles) : ntiles;
+    bool pend[DEPTH];
+    bool acquired = false;
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
     constexpr bool PR1 = epi_pr_one(EPI);
@@ -812,39 +923,6 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         if (blockIdx.x == 0 && threadIdx.x == 0) aux[1] = cf.bt;
     }
 
-    // (the first tiles are requested AFTER the prologue: vmcnt is in order, so partial rows requested behind the
-    //  images would wait for the images' HBM latency -- measured 1-4 % slower the other way round)
-    const int nblk = gridDim.x;
-    int W = nblk * WPB;
-    int t = xcd_remap(blockIdx.x, nblk) * WPB + wv;
-    int tend = ntiles;                       // the wave's tiles: t, t + W, ... below tend
-    if constexpr (DEF == 0) {
-        if (A.order == 1) {
-            // XCD-chunked order: the workgroups of one XCD (round-robin dispatch: workgroup b runs on XCD b % 8) sweep ONE
-            // contiguous eighth of the tile table, front by front, instead of every eighth tile-range of a chip-wide front.
-            // A 3-D stencil's plane neighbours (+-365 tiles at S2) are then rows the SAME XCD staged a round earlier or will
-            // own a round later -- they meet in its L2 instead of being read through the fabric by three XCDs (S2: 0.67 -> 0.39 GB read
-            // per launch, but 2 % slower: opt-in, PRCG_WIN_ORDER=1).
-            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = nblk >> 3, r = nblk & 7;
-            const int nbx = q + (xcd < r ? 1 : 0);
-            const int before = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-            const int lo = (int)((long long)ntiles * before / nblk);
-            tend = (int)((long long)ntiles * (before + nbx) / nblk);
-            W = nbx * WPB;
-            t = lo + idx * WPB + wv;
-        }
-    }
-    bool relay = false;
-    if constexpr (DEF > 0) {
-        if (fz.px) {
-            // direct peer exchange: wave 0 of workgroup 0 is the launch's COMMUNICATION WAVE and takes no tiles -- it sends this
-            // rank's partial sums of the previous launch to every rank, waits for everybody's, and publishes the sums
-            // to the other waves, all while those compute the part of the iteration that needs neither
-            relay = t == 0;
-            W -= 1;
-            t = relay ? ntiles : t - 1;
-        }
-    }
     __shared__ double s_mine[5];
     if constexpr (DEF > 0) {
         if (fz.px && blockIdx.x == 0 && fz.nprev > 0) {
@@ -858,19 +936,9 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         }
     }
 
-    // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
-    WRegs<win_nw(NV, EPI), M, PG, CW, VD> R[DEPTH];
-    WDesc<PG> d[DEPTH], dn = {};
-    // row cache (one image in flight per wave only: the cache then describes the tile processed just before)
-    constexpr int RL = DEPTH == 1 ? win_row_cache_len(M, CW, VD) : 0;
-    RowCache<M, RL, CW> rc;
-    rc.img = 0;
-    bool same[DEPTH];
-    // deferred form: tiles from `safe` on read ghost rows that arrive with the publication -- their loads are
-    // postponed (pend) until the wave has seen it
-    const int safe = DEF > 0 ? (fz.nt_int < ntiles ? fz.nt_int : ntiles) : ntiles;
-    bool pend[DEPTH];
-    bool acquired = false;
+    // the wave's first tiles: requested AFTER the prologue (vmcnt is in order: partial rows requested behind the images would
+    // wait for the images' HBM latency -- measured 1-4 % slower; requesting them right behind the partial rows, or the
+    // descriptors before the prologue, gains nothing either: profiles/r03_sweeps.md I)
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
         d[i] = WDesc<PG>{};
@@ -898,7 +966,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
             const bool have_next = tnext < safe;
             d[0] = dn;
             pend[0] = tnext < ntiles && !have_next;
-            same[0] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[0], dcur, have_next, d[0], acc, cf, rc, same[0],
+            same[0] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[0], dcur, have_next, d[0], acc, cf, rc, same[0], ps,
                                                                  s_stash[wv] + it * M * 64);
             if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
             t += W;
@@ -1022,7 +1090,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
                 const bool have_next = tnext < tend;
                 d[i] = dn;
                 const bool acq = DEF > 0 && have_next && tnext >= safe && !acquired;
-                same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], nullptr, acq, t);
+                same[i] = win_step<NV, EPI, M, PG, CW, VD, RL>(A, c, R[i], dcur, have_next, d[i], acc, cf, rc, same[i], ps, nullptr, acq, t);
                 if (acq) acquired = true;
                 // descriptor of the tile after that one: loaded now, looked at one step later
                 if (tnext + W < tend) dn = read_desc<PG>(wt, tnext + W);
@@ -1047,19 +1115,45 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
 // number of resident waves (S3 +4 %, S1 +14 %, S3/8 +25 %, profiles/r02_sweeps.md) -- unless a four-wave
 // workgroup's LDS no longer lets two of them share a CU (the 12-page plain geometry: S2 plain -16 %), then two.
 constexpr int lds_bytes_per_wave(int nv, int pg, int cw, bool vd) {
+    if (cw == 32) return 16 + 16 + 16 + 16 + pg * 64 * 8 * nv;             // pattern tiles: the window only
     return (vd ? 16 : kWinSlots * 8) + (vd ? kWinSlots : 16) + kWinSlots * (cw / 8) + (vd ? kWinDictMax * 8 : 16) + pg * 64 * 8 * nv;
 }
 constexpr int waves_per_block(int nv, int pg, int cw, bool vd) {
 #ifdef PRCG_WIN_WPB
     return PRCG_WIN_WPB;
 #else
-    // (PRCG_WIN_WPB_MAX > 4: all the waves that stream best on one CU -- 16 dictionary, 8 plain -- in ONE or two workgroups,
-    //  where their LDS slices fit the CU)
-    const int per = lds_bytes_per_wave(nv, pg, cw, vd), resident = vd ? 16 : 8;
-    for (int w = PRCG_WIN_WPB_MAX; w > 4; w /= 2)
-        if (w <= resident && resident * per <= 156 * 1024) return w;
-    return 4 * per <= 80 * 1024 ? 4 : 2;
+    return 4 * lds_bytes_per_wave(nv, pg, cw, vd) <= 80 * 1024 ? 4 : 2;
 #endif
+}
+// SHORT launches (few rounds of tiles: one rank's share of a strong-scaling run, S1) are dominated by what every launch pays
+// once -- tools/fixed_cost.py: 12.5 us + 2.3 us per round with 1024 four-wave workgroups, 9.4 us with 256 sixteen-wave ones:
+// the B x B reads of the prologue.  For them ALL the waves that stream best on one CU (16 dictionary, 8 plain, fewer where
+// their LDS slices do not fit) form ONE workgroup; B <= 256 also lets the first tiles travel while the partial rows are
+// summed (prev_partials_request / _finish).  Long launches keep the small workgroups (S3: 3 % faster with them).
+constexpr int waves_per_block_big(int nv, int pg, int cw, bool vd) {
+    int fit = (160 * 1024 - 1024) / lds_bytes_per_wave(nv, pg, cw, vd);
+    const int resident = vd ? 16 : 8;
+    if (fit > resident) fit = resident;
+    fit -= fit % 4;
+    const int base = waves_per_block(nv, pg, cw, vd);
+    // (never fewer resident waves than the small workgroups give: 2-wave workgroups of the 12-page plain geometry pack 6)
+    int packed = (160 * 1024) / (base * lds_bytes_per_wave(nv, pg, cw, vd)) * base;
+    if (packed > resident) packed = resident;
+    return (fit > base && fit >= packed) ? fit : base;
+}
+#ifndef PRCG_WIN_BIG_ROUNDS
+#define PRCG_WIN_BIG_ROUNDS 12     // launches of at most this many rounds of tiles take the big workgroups
+#endif
+// (one definition for the launch and for prcg_debug_layout: the summation order of the inner products depends on it)
+inline bool win_big_workgroups(int ntiles, bool vd) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = c > 0 ? c : 256;
+    }
+    const long waves = (long)cus * (vd ? 16 : 8);
+    return (long)ntiles <= (long)PRCG_WIN_BIG_ROUNDS * waves;
 }
 // ... of the deferred form: one wave on EACH SIMD of the CU (see defer_grid_per_cu) for the 64-row geometries; the 128-row
 // ones (12 KB of window per wave + the stashed sums) take two-wave workgroups: a four-wave one needs 86 KB of LDS and would
@@ -1127,7 +1221,7 @@ int defer_grid_per_cu(const void* kernel, bool guest, int wpb) {
 #endif
 constexpr int kDeferTiles = PRCG_DEFER_TILES;     // 64-row tiles whose update waits for the reduction (M = 2: half as many); 6 KB of LDS per wave
 
-template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER>
+template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER, bool BIG = false>
 int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu, hipEvent_t done);
@@ -1137,20 +1231,33 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu, hipEvent_t done = nullptr)
 {
-    if (A.vidx8 != nullptr)
+    if constexpr (epi_fused(EPI) && !DEFER) {
+        // the one-launch pipelined iteration of a SHORT launch: big workgroups (see waves_per_block_big)
+        if (A.big_ok && win_big_workgroups(ntiles, A.vidx8 != nullptr)) {
+            if (A.vidx8 != nullptr || CW == 32)
+                return launch_win_v<NV, EPI, M, PG, CW, true, DEFER, true>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials,
+                                                                           aux, fz, per_cu, done);
+            if constexpr (CW != 32)
+                return launch_win_v<NV, EPI, M, PG, CW, false, DEFER, true>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials,
+                                                                            aux, fz, per_cu, done);
+        }
+    }
+    if (A.vidx8 != nullptr || CW == 32)
         return launch_win_v<NV, EPI, M, PG, CW, true, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz,
                                                              per_cu, done);
-    return launch_win_v<NV, EPI, M, PG, CW, false, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz,
-                                                          per_cu, done);
+    if constexpr (CW != 32)
+        return launch_win_v<NV, EPI, M, PG, CW, false, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz,
+                                                              per_cu, done);
+    return -1;
 }
 
-template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER>
+template <int NV, int EPI, int M, int PG, int CW, bool vd, bool DEFER, bool BIG>
 int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, const void* x, void* y, int write_mask,
                  const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz,
                  int per_cu, hipEvent_t done)
 {
     constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 2) : 0;     // (128-row tiles: two stashed tiles = 16 KB of LDS per workgroup)
-    constexpr int WPB = DEFER ? wpb_defer(M) : waves_per_block(win_nw(NV, EPI), PG, CW, vd);
+    constexpr int WPB = DEFER ? wpb_defer(M) : (BIG ? waves_per_block_big(win_nw(NV, EPI), PG, CW, vd) : waves_per_block(win_nw(NV, EPI), PG, CW, vd));
     auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][2][16] = {};
@@ -1158,6 +1265,7 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
     (void)hipGetDevice(&dev);
     int& cap = cached_ntiles_cap[vd ? 1 : 0][fz.px ? 1 : 0][dev & 15];
     int tuned = (vd ? 16 : 8) / WPB;        // resident waves per CU that stream best (see win_grid)
+    if (tuned < 1) tuned = 1;
     if (DEFER) tuned = defer_grid_per_cu(reinterpret_cast<const void*>(k), fz.px == nullptr, WPB);
     if (cap == 0) cap = win_grid(k, 1 << 30, 0, tuned, WPB);
     int grid = per_cu >= 1 ? win_grid(k, ntiles, per_cu, tuned, WPB) : cap;
@@ -1198,20 +1306,23 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
     case 2: return launch_win_g<NV, EPI, 2, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     case 3: return launch_win_g<NV, EPI, 2, 12, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     case 4: return launch_win_g<NV, EPI, 1, 8, 16, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
+    case 5: return launch_win_g<NV, EPI, 1, kWinPatPages, 32, DEFER>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials, aux, fz, per_cu, done);
     default: return -1;
     }
 }
 
 }  // namespace
 
-int win_fused_waves_per_block(int geom, bool value_dict, bool deferred) {
-    if (deferred) return wpb_defer((geom < 2 || geom == 4) ? 1 : 2);
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok) {
+    if (deferred) return wpb_defer((geom < 2 || geom >= 4) ? 1 : 2);
+    const bool big = big_ok && win_big_workgroups(ntiles, value_dict);
     switch (geom) {
-    case 0: return waves_per_block(2, 2, 8, value_dict);
-    case 1: return waves_per_block(2, 4, 8, value_dict);
-    case 2: return waves_per_block(2, 8, 16, value_dict);
-    case 3: return waves_per_block(2, 12, 16, value_dict);
-    case 4: return waves_per_block(2, 8, 16, value_dict);
+    case 0: return big ? waves_per_block_big(2, 2, 8, value_dict) : waves_per_block(2, 2, 8, value_dict);
+    case 1: return big ? waves_per_block_big(2, 4, 8, value_dict) : waves_per_block(2, 4, 8, value_dict);
+    case 2: return big ? waves_per_block_big(2, 8, 16, value_dict) : waves_per_block(2, 8, 16, value_dict);
+    case 3: return big ? waves_per_block_big(2, 12, 16, value_dict) : waves_per_block(2, 12, 16, value_dict);
+    case 4: return big ? waves_per_block_big(2, 8, 16, value_dict) : waves_per_block(2, 8, 16, value_dict);
+    case 5: return big ? waves_per_block_big(2, kWinPatPages, 32, true) : waves_per_block(2, kWinPatPages, 32, true);
     default: return 0;
     }
 }

@@ -227,8 +227,8 @@ class DeviceCSR:
         s = self._lib.prcg_schedule(self._h)
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
-                'col_bytes': 1 if s & 64 else (2 if s & 128 else 4), 'tile_steps': (s >> 8) & 15,
-                'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384), 'sliced_rows': bool(s & 32768)}
+                'col_bytes': 0 if s & 65536 else (1 if s & 64 else (2 if s & 128 else 4)), 'tile_steps': (s >> 8) & 15,
+                'pattern': bool(s & 65536), 'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384), 'sliced_rows': bool(s & 32768)}
 
     def layout(self):
         """Diagnostic (prcg.h: prcg_debug_layout): what the summation order of the one-launch iteration's inner

@@ -154,16 +154,18 @@ def connect_peer_exchange(dev, rank, allgather):
     return True
 
 
-def loopback_problem(A, k):
+def loopback_problem(A, k, cut=None):
     """One rank's view of a row-block run, on ONE GPU: rewrite A as if it were cut at row n/2 into two
     row blocks whose halo is exchanged with ... itself.  Columns in [n/2-k, n/2) seen from rows >= n/2
     and columns in [n/2, n/2+k) seen from rows < n/2 are reached through ghost slots fed by a self
     exchange.  A_loop @ [x ; x[ghost_ids]] == A @ x with the nonzeros of every row in unchanged order.
+    ``cut``: the row of the cut instead of n/2 (a grid-plane boundary of a 3-D stencil, with k = rows of a plane).
     Returns (A_loop, halo plan, nonzeros that go through a ghost slot).  Used by the tests and by
     bench.py's multi-rank-schedule leg (boundary tiles + ghost rows with a 1-rank communicator)."""
     A = A.tocsr()
     n = A.shape[0]
-    h = n // 2
+    h = n // 2 if cut is None else int(cut)
+    assert k <= h <= n - k
     ghost_ids = np.arange(h - k, h + k)
     slot = -np.ones(n, dtype=np.int64)
     slot[ghost_ids] = n + np.arange(ghost_ids.size)

@@ -153,6 +153,8 @@ WORKLOADS = {
                n=10_000_000, make=lambda rows=None: banded_ex2b(10_000_000, 7, rows=rows)),
     's3_8th': dict(desc='one eighth of S3: ex2b banded n=1.25e6, 15 diagonals', n=1_250_000,
                    make=lambda rows=None: banded_ex2b(1_250_000, 7, rows=rows)),
+    's2_8th': dict(desc='one eighth of S2: 7-pt Laplacian 216 x 216 x 27 (n=1,259,712)', n=216 * 216 * 27,
+                   make=lambda rows=None: laplace_3d(216, 216, 27, rows)),
     's4': dict(desc='S4 stand-in for Queen_4147: irregular symmetric SPD, n=1e6, log-normal row lengths (mean ~76, max 2000), reach 50000, seed 0',
                n=1_000_000, make=lambda rows=None: _row_slice(irregular_standin(1_000_000), rows)),
     's4b': dict(desc='FEM-like stand-in for Queen_4147: 3 dof x 27-point coupling on 80^3 nodes (n=1,536,000, ~81 nnz/row)',

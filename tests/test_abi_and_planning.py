@@ -447,3 +447,122 @@ def test_sliced_rows_refuse_wide_and_ragged_operators():
     r = np.repeat(np.arange(4000), lens)
     ragged = sp.csr_matrix((np.ones(r.size), (r // 2).astype(np.int32), indptr), shape=(4000, 4000))
     assert plan_sell(ragged)[0] == 0                     # padding to each slice's longest row would double the stream
+
+
+def plan_patterns(A_local, row_class=None):
+    A_local = A_local.tocsr()
+    n, n_cols = A_local.shape
+    indptr = np.ascontiguousarray(A_local.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A_local.indices, dtype=np.int32)
+    data = np.ascontiguousarray(A_local.data, dtype=np.float64)
+    rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
+    counts = np.zeros(3, dtype=np.int64)
+    got = L.lib().prcg_plan_window_patterns(n, n_cols, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), None, 0, None, 0, None, 0,
+                                            L.ptr(counts))
+    if got == 0:
+        return None
+    assert got < 0
+    tiles = np.zeros((counts[0], 24), dtype=np.int32)
+    pats = np.zeros(counts[1] * 72, dtype=np.uint8)
+    masks = np.zeros(counts[2], dtype=np.uint16)
+    got = L.lib().prcg_plan_window_patterns(n, n_cols, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), L.ptr(tiles), len(tiles),
+                                            L.ptr(pats), int(counts[1]), L.ptr(masks), len(masks), L.ptr(counts))
+    assert got == 1
+    rec = np.dtype([('nslots', '<i4'), ('vsel', '<u4'), ('cb', '<i2', 16), ('val', '<f8', 4)])
+    assert rec.itemsize == 72
+    return tiles, pats.view(rec), masks
+
+
+def matrix_from_patterns(shape, tiles, pats, masks):
+    """What the pattern kernels compute with: (pages, pattern, masks) -> every nonzero's column and value, row by row IN THE
+    ORDER THE KERNEL ADDS THEM (ascending slot) -- CSR arrays to be compared with the caller's as they are."""
+    per_row = {}
+    for t in tiles:
+        rb, re, npages, page = int(t[0]), int(t[1]), int(t[4]) & 255, t[8:20]
+        p = pats[int(t[20])]
+        U = int(p['nslots'])
+        for lane in range(re - rb):
+            mk = (1 << U) - 1 if t[23] else int(masks[int(t[22]) + lane])
+            ent = []
+            for u in range(U):
+                if (mk >> u) & 1:
+                    w = lane + int(p['cb'][u])
+                    assert 0 <= w < npages * 64
+                    ent.append((int(page[w // 64]) + w % 64, p['val'][(int(p['vsel']) >> (2 * u)) & 3]))
+            assert rb + lane not in per_row
+            per_row[rb + lane] = ent
+    assert sorted(per_row) == list(range(shape[0]))
+    lens = np.array([len(per_row[r]) for r in range(shape[0])])
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.array([c for r in range(shape[0]) for c, _ in per_row[r]], dtype=np.int64)
+    data = np.array([v for r in range(shape[0]) for _, v in per_row[r]], dtype=np.float64)
+    return indptr, indices, data
+
+
+@pytest.mark.parametrize('name', ['lap3d', 'lap2d', 'lap3d_aniso', 'lap3d_block', 'nine_point'])
+def test_pattern_tiles_hold_exactly_the_matrix(name):
+    """Constant-coefficient stencils become PATTERN tiles (csrc/prcg_plan.h: plan_window_patterns): the matrix rebuilt from
+    (pages, pattern records, slot masks) -- all the pattern kernels read of the operator -- equals the CSR, nonzero by nonzero
+    in row order, value bits included; a handful of patterns and mask images serve the whole grid."""
+    import scipy.sparse as sp
+    from new_cg_variants_amd import partition
+    row_class = None
+    if name == 'lap3d':
+        A = problems.laplace_3d(24, 20, 13)
+    elif name == 'lap2d':
+        A = problems.laplace_2d(150, 70)
+    elif name == 'lap3d_aniso':
+        # three different couplings + the diagonal: four value patterns, the most a pattern holds
+        nx, ny, nz = 17, 11, 9
+        ex, ey, ez = (np.ones(k) for k in (nx, ny, nz))
+        T = lambda k, c: sp.diags([-c * np.ones(k - 1), 2 * c * np.ones(k), -c * np.ones(k - 1)], [-1, 0, 1])
+        A = (sp.kron(sp.eye(nz), sp.kron(sp.eye(ny), T(nx, 1.0))) + sp.kron(sp.eye(nz), sp.kron(T(ny, 0.25), sp.eye(nx))) +
+             sp.kron(T(nz, 3.0), sp.eye(ny * nx))).tocsr()
+        A.sort_indices()
+    elif name == 'lap3d_block':
+        # a rank's row block with ghost columns on both sides
+        Afull = problems.laplace_3d(16, 16, 12)
+        lo, hi = 16 * 16 * 4, 16 * 16 * 8
+        A, ghosts = partition.localize(Afull[lo:hi], lo, hi)
+        rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+        row_class = np.zeros(A.shape[0], dtype=np.uint8)
+        row_class[np.unique(rows[A.indices >= A.shape[0]])] = 1
+    else:
+        n1, n2 = 90, 40
+        T = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+        S = sp.diags([np.ones(n2 - 1), np.ones(n2), np.ones(n2 - 1)], [-1, 0, 1])
+        A = (-sp.kron(S, T) + 9.0 * sp.eye(n1 * n2)).tocsr()
+        A.sort_indices()
+    got = plan_patterns(A, row_class)
+    assert got is not None, 'a constant-coefficient stencil must qualify'
+    tiles, pats, masks = got
+    indptr, indices, data = matrix_from_patterns(A.shape, tiles, pats, masks)
+    assert np.array_equal(indptr, A.indptr) and np.array_equal(indices, A.indices)         # the rows' own order (ghosts: not ascending)
+    assert np.array_equal(data.view(np.uint64), A.data.view(np.uint64))
+    # every row in exactly one tile, classes apart
+    cover = np.concatenate([np.arange(t[0], t[1]) for t in tiles])
+    assert np.array_equal(np.sort(cover), np.arange(A.shape[0]))
+    assert len(pats) <= 64 and len(masks) // 64 <= len(tiles)
+    print(name, len(tiles), 'tiles', len(pats), 'patterns', len(masks) // 64, 'mask images', int(tiles[:, 23].sum()), 'full tiles')
+
+
+def test_pattern_tiles_refuse_what_is_no_constant_stencil():
+    """Varying coefficients (one value per slot is the rule), unsorted or duplicate columns, rows of more than 16 nonzeros,
+    more than four distinct values: no pattern operator -- the stream geometries take it."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    A = problems.laplace_2d(80, 40).tocsr()
+    B = A.copy(); B.data = B.data * (1.0 + 1e-3 * rng.standard_normal(B.nnz))
+    assert plan_patterns(B) is None
+    assert plan_patterns(problems.banded_ex2b(4096, 7)) is None        # ex2b: the diagonal varies near the end
+    C1 = A.copy()
+    r = 1000
+    C1.indices[C1.indptr[r]:C1.indptr[r + 1]] = C1.indices[C1.indptr[r]:C1.indptr[r + 1]][::-1].copy()     # unsorted row
+    C1.data[C1.indptr[r]:C1.indptr[r + 1]] = C1.data[C1.indptr[r]:C1.indptr[r + 1]][::-1].copy()
+    assert plan_patterns(C1) is None
+    D = sp.diags([np.ones(5000 - abs(k)) for k in range(-9, 10)], list(range(-9, 10))).tocsr()               # 19 per row
+    assert plan_patterns(D) is None
+    E = sp.diags([np.full(3000 - abs(k), 1.0 + abs(k)) for k in range(-3, 4)], list(range(-3, 4))).tocsr()    # 4 values: fine
+    assert plan_patterns(E) is not None
+    F = sp.diags([np.full(3000 - abs(k), 1.0 + k) for k in range(-3, 4)], list(range(-3, 4))).tocsr()         # 7 values: too many
+    assert plan_patterns(F) is None

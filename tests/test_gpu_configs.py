@@ -48,8 +48,8 @@ def test_window_kernels_selected_for_bands_and_stencils_only(amd):
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     wide = sp.csr_matrix((rng.standard_normal(indptr[-1]), rng.integers(0, n, size=indptr[-1]).astype(np.int32), indptr),
                          shape=(n, n))
-    expect = {'band': (P.banded_ex2b(100_000, 7), True, 1), 'lap2d': (P.laplace_2d(300, 200), True, 2),
-              'lap3d': (P.laplace_3d(40, 30, 20), True, 2), 'wide': (wide, False, 4),
+    expect = {'band': (P.banded_ex2b(100_000, 7), True, 1), 'lap2d': (P.laplace_2d(300, 200), True, 0),
+              'lap3d': (P.laplace_3d(40, 30, 20), True, 0), 'wide': (wide, False, 4),
               'tiny': (P.laplace_2d(7, 8), False, 1), 'fem': (P.fem_like_3d(12, 3), False, 2)}
     for name, (A, window, col_bytes) in expect.items():
         op = amd['device'].DeviceCSR(A)
@@ -549,11 +549,11 @@ def test_64_row_tiles_for_3d_stencils(amd):
         x = rng.standard_normal(n)
         b, x0, _ = P.reference_rhs(A, n)
         hist = []
-        for knobs in ({'PRCG_WIN_ROWS': '64'}, {'PRCG_WIN_ROWS': '64', 'PRCG_VALDICT': '0'}, {}):
+        for knobs in ({'PRCG_WIN_ROWS': '64'}, {'PRCG_WIN_ROWS': '64', 'PRCG_VALDICT': '0'}, {'PRCG_WIN_PAT': '0'}):
             op = amd['device'].DeviceCSR(A, knobs=knobs)
             s = op.schedule()
             assert s['window'] and s['col_bytes'] == 2, s
-            if knobs:
+            if 'PRCG_WIN_ROWS' in knobs:
                 assert op.layout()['rows_per_tile'] == 64 and op.layout()['geometry'] == 4, op.layout()
             products_bitexact(op, A, x, f'lap3d {knobs}')
             op.begin(L.PIPE_PR, b, x0, 30, hist_mask=1)
@@ -563,3 +563,72 @@ def test_64_row_tiles_for_3d_stencils(amd):
             op.close()
         for h in hist[:2]:
             np.testing.assert_allclose(h, hist[2], rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_pattern_tiles_for_constant_coefficient_stencils(amd):
+    """Constant-coefficient stencils run as PATTERN tiles (geometry 5; csrc/prcg_plan.h: plan_window_patterns): no per-nonzero
+    stream, per tile one pattern record (slot offsets + values) and, where rows are incomplete, their slot masks.  Products
+    bit-exact vs SciPy -- grid edges, rows of a last partial tile, inf / nan / signed zeros in x, an anisotropic stencil with
+    four values, a 9-point stencil, a row block with ghost columns (rows not ascending in local numbering); every solver
+    family agrees with the stream geometries (PRCG_WIN_PAT=0) from identical state: vectors bit for bit."""
+    L, P, partition = amd['L'], amd['problems'], amd['partition']
+    rng = np.random.default_rng(77)
+    T = lambda k, c: sp.diags([-c * np.ones(k - 1), 2 * c * np.ones(k), -c * np.ones(k - 1)], [-1, 0, 1])
+    nx, ny, nz = 33, 21, 17
+    aniso = (sp.kron(sp.eye(nz), sp.kron(sp.eye(ny), T(nx, 1.0))) + sp.kron(sp.eye(nz), sp.kron(T(ny, 0.25), sp.eye(nx))) +
+             sp.kron(T(nz, 3.0), sp.eye(ny * nx))).tocsr()
+    aniso.sort_indices()
+    n1, n2 = 130, 77
+    S1 = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+    S2 = sp.diags([np.ones(n2 - 1), np.ones(n2), np.ones(n2 - 1)], [-1, 0, 1])
+    nine = (-sp.kron(S2, S1) + 9.0 * sp.eye(n1 * n2)).tocsr()
+    nine.sort_indices()
+    cases = [('lap3d 70^3', P.laplace_3d(70, 70, 70)), ('lap3d 216x31x9', P.laplace_3d(216, 31, 9)), ('lap2d 1000x77', P.laplace_2d(1000, 77)),
+             ('lap2d 37x29', P.laplace_2d(37, 29)), ('aniso', aniso), ('nine-point', nine)]
+    for name, A in cases:
+        n = A.shape[0]
+        op = amd['device'].DeviceCSR(A)
+        s = op.schedule()
+        assert s['window'] and s['pattern'] and s['value_dict'], (name, s)
+        assert op.layout()['geometry'] == 5 and op.layout()['rows_per_tile'] == 64, op.layout()
+        x = rng.standard_normal(n)
+        products_bitexact(op, A, x, name)
+        xs = x.copy()
+        xs[rng.integers(0, n, 40)] = np.inf
+        xs[rng.integers(0, n, 40)] = np.nan
+        xs[rng.integers(0, n, 200)] = -0.0
+        xs[rng.integers(0, n, 200)] = 0.0
+        with np.errstate(invalid='ignore'):
+            ref = A @ xs
+        y, _ = op.matvec(xs)
+        assert np.array_equal(y, ref, equal_nan=True) and np.array_equal(np.signbit(y), np.signbit(ref)), name
+        # solver families from identical state against the stream geometries
+        b, x0, _ = P.reference_rhs(A, n)
+        other = amd['device'].DeviceCSR(A, knobs={'PRCG_WIN_PAT': '0'})
+        assert not other.schedule()['pattern']
+        for variant, prec in (('PIPE_PR', None), ('PIPE_P', 1 / A.diagonal()), ('HS', None), ('PR', 1 / A.diagonal()), ('CG_CG', None), ('GV', None)):
+            hs = []
+            for o in (op, other):
+                o.begin(getattr(L, variant), b, x0, 26, inv_diag=prec, hist_mask=1)
+                o.iterate(25)
+                o.sync()
+                hs.append((o.get_vector('x'), o.history()['updated_residual_2_norm']))
+            # same rows, same order of the row sums; the inner products are summed over other tile shapes: rounding only
+            np.testing.assert_allclose(hs[0][1], hs[1][1], rtol=1e-9, err_msg=f'{name} {variant}')
+            assert np.max(np.abs(hs[0][0] - hs[1][0])) <= 1e-9 * np.max(np.abs(hs[1][0])), (name, variant)
+        op.close(); other.close()
+    # a rank's row block (ghost columns numbered behind the owned ones: its rows are not ascending): block products with the
+    # caller's ghost entries reassemble the global product
+    A = P.laplace_3d(40, 32, 24)
+    n = A.shape[0]
+    x = rng.standard_normal(n)
+    ref = A @ x
+    offsets, blocks = partition.split_serial(A, 3, offsets=np.array([0, 40 * 32 * 8, 40 * 32 * 16, n]))
+    for r, (A_loc, ghosts, halo) in enumerate(blocks):
+        op = amd['device'].DeviceCSR(A_loc)
+        assert op.schedule()['pattern'], (r, op.schedule())
+        lo, hi = int(offsets[r]), int(offsets[r + 1])
+        y = op.matvec_ext(np.concatenate([x[lo:hi], x[ghosts]]))
+        assert np.array_equal(y, ref[lo:hi]), r
+        op.close()
