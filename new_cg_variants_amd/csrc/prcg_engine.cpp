@@ -1540,10 +1540,22 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         }
     }
     if (!h->win_pat && h->want_win && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)h->win_max_mean * n_rows) {
-        const int rows = h->win_rows_override ? h->win_rows_override : (nnz < 10 * n_rows ? 128 : 64);
+        int rows = h->win_rows_override ? h->win_rows_override : (nnz < 10 * n_rows ? 128 : 64);
         plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, rows, kWinCapNnz,
                           win_max_pages(rows), wp);
-        const int most = wp.pages0 > wp.pages1 ? wp.pages0 : wp.pages1;
+        int most = wp.pages0 > wp.pages1 ? wp.pages0 : wp.pages1;
+        if (!h->win_rows_override && rows == 128 && wp.ok0 && wp.ok1 && most > 8) {
+            // short rows whose 128-row tiles need more than eight pages (a 3-D stencil: its plane neighbours): 64-row tiles of
+            // at most eight pages stream better (S2: +6 % with the dictionary, +4.5 % plain; r03_sweeps.md J), where they qualify
+            WinPlan w64;
+            plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, 64, kWinCapNnz, win_max_pages(64), w64);
+            const int m64 = w64.pages0 > w64.pages1 ? w64.pages0 : w64.pages1;
+            if (w64.ok0 && w64.ok1 && win_geometry(64, m64) >= 0) {
+                wp.t0.swap(w64.t0); wp.t1.swap(w64.t1); wp.cw.swap(w64.cw);
+                wp.pages0 = w64.pages0; wp.pages1 = w64.pages1;
+                rows = 64; most = m64;
+            }
+        }
         const int geom = win_geometry(rows, most);
         if (wp.ok0 && wp.ok1 && geom >= 0 && wp.t0.size() + wp.t1.size() < (size_t)(1 << 26)) {
             h->win = true; h->win_geom = geom; h->win_rows = rows;

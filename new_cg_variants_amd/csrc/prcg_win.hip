@@ -228,7 +228,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
     }
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
+#ifdef PRCG_DEBUG_SKIP_PAGES
+        if (p < d.np - PRCG_DEBUG_SKIP_PAGES) {                             // TIMING EXPERIMENT ONLY (wrong products): the last pages are not loaded
+#else
         if (p < d.np) {                                                     // wave-uniform branch
+#endif
             if constexpr (EPI == kEpiHS) { R.w[p].x = X[d.pc[p] + lane]; R.w[p].y = X2[d.pc[p] + lane]; }
             else if constexpr (epi_pr_one(EPI)) {
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane]; R.w[p].z = pr.p_old[d.pc[p] + lane];
@@ -1158,7 +1162,11 @@ inline bool win_big_workgroups(int ntiles, bool vd) {
 // ... of the deferred form: one wave on EACH SIMD of the CU (see defer_grid_per_cu) for the 64-row geometries; the 128-row
 // ones (12 KB of window per wave + the stashed sums) take two-wave workgroups: a four-wave one needs 86 KB of LDS and would
 // be alone on its CU
-constexpr int wpb_defer(int m) { return m == 1 ? 4 : 2; }
+// (64-row geometries whose four-wave workgroup would be alone on its CU -- plain values with eight 2-byte-index pages:
+//  22 KB per wave with the stash -- take two-wave workgroups too: three of them share a CU)
+constexpr int wpb_defer(int m, int nv = 2, int pg = 2, int cw = 8, bool vd = true) {
+    return (m == 1 && 4 * (lds_bytes_per_wave(nv, pg, cw, vd) + 3 * 64 * 16) <= 80 * 1024) ? 4 : 2;
+}
 
 // Workgroups per CU.  Upper bounds: what is truly co-resident (160 KiB of LDS per CU; the occupancy API
 // knows the register limit) -- a persistent strided grid with queued workgroups grows a serial tail (S3
@@ -1257,7 +1265,7 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
                  int per_cu, hipEvent_t done)
 {
     constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 2) : 0;     // (128-row tiles: two stashed tiles = 16 KB of LDS per workgroup)
-    constexpr int WPB = DEFER ? wpb_defer(M) : (BIG ? waves_per_block_big(win_nw(NV, EPI), PG, CW, vd) : waves_per_block(win_nw(NV, EPI), PG, CW, vd));
+    constexpr int WPB = DEFER ? wpb_defer(M, win_nw(NV, EPI), PG, CW, vd) : (BIG ? waves_per_block_big(win_nw(NV, EPI), PG, CW, vd) : waves_per_block(win_nw(NV, EPI), PG, CW, vd));
     auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][2][16] = {};
@@ -1314,7 +1322,15 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
 }  // namespace
 
 int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok) {
-    if (deferred) return wpb_defer((geom < 2 || geom >= 4) ? 1 : 2);
+    if (deferred) {
+        switch (geom) {
+        case 0: return wpb_defer(1, 2, 2, 8, value_dict);
+        case 1: return wpb_defer(1, 2, 4, 8, value_dict);
+        case 4: return wpb_defer(1, 2, 8, 16, value_dict);
+        case 5: return wpb_defer(1, 2, kWinPatPages, 32, true);
+        default: return wpb_defer(2);
+        }
+    }
     const bool big = big_ok && win_big_workgroups(ntiles, value_dict);
     switch (geom) {
     case 0: return big ? waves_per_block_big(2, 2, 8, value_dict) : waves_per_block(2, 2, 8, value_dict);

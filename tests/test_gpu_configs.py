@@ -246,18 +246,21 @@ def test_s3_full_size_as_benchmarked(amd):
 
 @pytest.mark.gpu
 def test_s2_full_size(amd):
-    """S2 = 7-point Laplacian 216^3 (BASELINE.json configs[3]): far neighbours at +-46656, 12-page windows,
-    2-byte window indices."""
+    """S2 = 7-point Laplacian 216^3 (BASELINE.json configs[3]): far neighbours at +-46656.  Pattern tiles by default; with
+    PRCG_WIN_PAT=0 or plain values 64-row tiles of six pages and 2-byte window indices (geometry 4); PRCG_WIN_ROWS=128: the
+    12-page 128-row geometry."""
     P = amd['problems']
     A = P.WORKLOADS['s2']['make']()
     n = A.shape[0]
     assert (n, A.nnz) == (216 ** 3, 70_263_936)
     x = np.random.default_rng(32).standard_normal(n)
     ones = np.ones(n)
-    for knobs in ({}, {'PRCG_VALDICT': '0'}, {'PRCG_WIN': '0'}):
+    for knobs, geom in (({}, 5), ({'PRCG_VALDICT': '0'}, 4), ({'PRCG_WIN_PAT': '0'}, 4), ({'PRCG_WIN_PAT': '0', 'PRCG_WIN_ROWS': '128'}, 3),
+                        ({'PRCG_WIN': '0'}, -1)):
         op = amd['device'].DeviceCSR(A, knobs=knobs)
         s = op.schedule()
         assert s['window'] == ('PRCG_WIN' not in knobs), s
+        assert op.layout()['geometry'] == geom, (knobs, op.layout()['geometry'])
         y1, _ = op.matvec(ones)
         assert np.array_equal(y1, A @ ones)
         products_bitexact(op, A, x, f's2 {knobs}')
