@@ -45,6 +45,9 @@ namespace {
 #ifndef PRCG_NT_LOADS
 #define PRCG_NT_LOADS 0
 #endif
+#ifndef PRCG_NT_VALUES
+#define PRCG_NT_VALUES 0          // 1: the plain value stream (8 B per nonzero, read once per launch) with nontemporal loads (A/B builds)
+#endif
 #ifndef PRCG_WIN_UNIFORM_ROWS
 #define PRCG_WIN_UNIFORM_ROWS 1  // 0: no scalar-value / scalar-offset row walk (A/B builds)
 #endif
@@ -52,6 +55,7 @@ namespace {
 #define PRCG_WIN_ROW_CACHE 1      // 0: the dictionary kernels re-read their shared stream images for every tile (A/B builds)
 #endif
 constexpr int kU = PRCG_WIN_UNROLL;
+constexpr int kRelayTiles = 8;     // boundary tiles the communication wave of the peer exchange takes itself (no more: it is ONE wave)
 
 // wave-uniform view of one tile descriptor
 template <int PG>
@@ -213,7 +217,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
 #pragma unroll
         for (int st = 0; st < kWinSlots / 128; ++st) {
             const int q = alo + st * 128 + lane * 2;
+#if PRCG_NT_VALUES
+            R.v[st] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(A.val + (q < d.hi ? q : alo)));   // read once per launch
+#else
             R.v[st] = *reinterpret_cast<const d2_t*>(A.val + (q < d.hi ? q : alo));
+#endif
         }
     }
     if constexpr (CW == 8) {
@@ -851,6 +859,13 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
             relay = t == 0;
             W -= 1;
             t = relay ? ntiles : t - 1;
+            // a handful of boundary tiles (a band: the rows next to the cuts) go to the communication wave, after it has
+            // published: they read ghost rows with system-scope loads (the slowest tile step of the launch) and would
+            // otherwise end the launch one tile step late for everybody; a stencil's plane of boundary tiles stays with all
+            if (ntiles - fz.nt_int <= kRelayTiles && fz.nt_int < ntiles) {
+                tend = fz.nt_int;
+                if (relay) { t = fz.nt_int; W = 1; tend = ntiles; }
+            }
         }
     }
     // ring of DEPTH images: image i holds tile t + i*W; dn = descriptor of the tile to request next
@@ -969,10 +984,10 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
             const int tnext = t + W;
             const bool have_next = tnext < safe;
             d[0] = dn;
-            pend[0] = tnext < ntiles && !have_next;
+            pend[0] = tnext < tend && !have_next;
             same[0] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[0], dcur, have_next, d[0], acc, cf, rc, same[0], ps,
                                                                  s_stash[wv] + it * M * 64);
-            if (tnext + W < ntiles) dn = read_desc<PG>(wt, tnext + W);
+            if (tnext + W < tend) dn = read_desc<PG>(wt, tnext + W);
             t += W;
             ++n_def;
         }
