@@ -311,6 +311,16 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
 int64_t prcg_plan_window_patterns(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const double* data,
                                   const uint8_t* row_class, int32_t* tiles_out, int64_t tile_capacity, void* pat_out,
                                   int64_t pat_capacity, uint16_t* masks_out, int64_t mask_capacity, int64_t* counts_out);
+/* Sweep order of the pattern tiles for a stencil on a regular grid without ghost columns (csrc/prcg_plan.h: plan_sweep_tiles;
+ * what prcg_set_csr tries before prcg_plan_window_patterns): the tile TABLE is ordered so that the tiles one wave takes one
+ * after the other are the same rows of consecutive grid planes, and a page the wave's previous tile left in LDS is not loaded
+ * again.  Outputs as prcg_plan_window_patterns; tiles_out[6] of a tile = LDS slot of each logical page (3 bits each) |
+ * carried pages << 18 | (1 << 24 if slots are addressed through the slot table); empty tiles (row_begin == row_end) pad the
+ * table.  counts_out[0..6) = {tiles, patterns, masks, waves the carry bits assume, rows of a grid plane, rows per tile}.
+ * max_waves: most waves the launch may run.  Returns 1, 0 if the operator does not qualify, -tiles if a capacity is too small. */
+int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, int max_waves,
+                        int32_t* tiles_out, int64_t tile_capacity, void* pat_out, int64_t pat_capacity, uint16_t* masks_out,
+                        int64_t mask_capacity, int64_t* counts_out);
 /* Sliced rows (lane-per-row kernels for operators with medium-length rows that are no window operators -- assembled FEM
  * matrices): rows are cut into slices of up to 64 consecutive rows of one class (class-0 slices first); nonzero u of the
  * row in lane l of a slice is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus
@@ -335,7 +345,7 @@ int prcg_plan_gather(int rank, int doubles_per_table, const double* tables, int 
 /* Diagnostic (tests): how the resident operator is laid out for the one-launch iteration, i.e. everything the summation
  * order of its inner products depends on.  out[0..8) = {1 if window operator, window geometry id, rows per window tile,
  * number of tiles T, workgroups of the last one-launch iteration (0: none yet), waves per workgroup of that launch,
- * interior tiles, 0}, then T pairs (first row, end row) in table order.  Returns the number of int64 written, -needed
+ * interior tiles, (1 if XCD-chunked tile order) | (waves a sweep table assumes) << 8}, then T pairs (first row, end row) in table order.  Returns the number of int64 written, -needed
  * if capacity is too small, -1 on a bad argument.  tests/device_order.py rebuilds the launch's reduction tree from it. */
 int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity);
 /* Capacity rule of every vector a matrix-product launch reads (window pages are whole 64-column blocks, the narrow

@@ -85,6 +85,7 @@ _SIGNATURES = {
     'prcg_plan_window': (C.c_int64, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int)]),
     'prcg_plan_window_images': (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.c_int, _P]),
+    'prcg_plan_sweep': (C.c_int64, [C.c_int64, _P, _P, _P, C.c_int, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P]),
     'prcg_plan_window_patterns': (C.c_int64, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P]),
     'prcg_tile_caps': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'prcg_window_source_ok': (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int64]),

@@ -126,6 +126,10 @@ struct prcg_handle {
     bool win_vd = false;
     bool win_pat = false;        // pattern tiles (geometry 5): no index streams, the rows' slot masks in wrel, records in wpat
     bool want_pat = true;        // PRCG_WIN_PAT=0: constant-coefficient stencils keep the stream geometries
+    int want_sweep = 1;          // PRCG_WIN_SWEEP=0: pattern tiles in row order (no page carried from tile to tile); 2: sweep tables
+                                 // for operators of any size (default: 5e6 rows and more -- below, the row order with big workgroups wins)
+    int sweep_waves = 0, sweep_tiles = 0;
+    int sweep_max_waves = 6144;  // PRCG_SWEEP_WAVES: most waves a sweep table may ask for
     DevBuf wpat;
     int nwt_int = 0, nwt_bnd = 0;
     DevBuf wtiles, wcw, wvidx, wvdict, wrel;
@@ -252,7 +256,7 @@ struct prcg_handle {
                       b16 ? static_cast<const unsigned short*>(wcw.p) : nullptr,
                       win_vd ? static_cast<const unsigned char*>(wvidx.p) : nullptr,
                       win_vd ? static_cast<const double*>(wvdict.p) : nullptr,
-                      static_cast<const unsigned short*>(wrel.p), static_cast<const PatRec*>(wpat.p), want_big ? 1 : 0, win_order,
+                      static_cast<const unsigned short*>(wrel.p), static_cast<const PatRec*>(wpat.p), sweep_waves, sweep_tiles, want_big ? 1 : 0, win_order,
                       win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
@@ -1247,6 +1251,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN_ORDER") h->win_order_override = v != 0;
     else if (k == "PRCG_WIN_BIG") h->want_big = v != 0;
     else if (k == "PRCG_WIN_PAT") h->want_pat = v != 0;
+    else if (k == "PRCG_WIN_SWEEP") h->want_sweep = (v >= 0 && v <= 2) ? (int)v : 1;
+    else if (k == "PRCG_SWEEP_WAVES") h->sweep_max_waves = (v >= 64 && v <= 16384) ? (int)v : 6144;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1261,7 +1267,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1526,7 +1532,21 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     h->win_pat = false;
     std::vector<PatRec> pats;
     std::vector<uint16_t> pmasks;
-    if (h->want_win && h->want_pat && h->want_vdict && !h->win_rows_override && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)kPatSlots * n_rows) {
+    h->sweep_waves = h->sweep_tiles = 0;
+    if (h->want_win && h->want_pat && (h->want_sweep == 2 || (h->want_sweep == 1 && n_rows >= 5000000)) && h->want_vdict &&
+        !h->win_rows_override && n_ghost == 0 && nnz > 0 && nnz <= (int64_t)kPatSlots * n_rows) {
+        // a stencil on a regular grid, long launches: sweep order (a wave's consecutive tiles = the same rows of consecutive grid
+        // planes; the pages they share stay in LDS -- prcg_plan.h: plan_sweep_tiles), then the pattern check as for any tiling
+        SweepPlan sw;
+        if (plan_sweep_tiles(n_rows, ncols, ip.data(), indices, kWinPatPages, h->sweep_max_waves, sw) &&
+            plan_window_patterns(sw.tiles, ip.data(), sw.cw.data(), data, pats, pmasks)) {
+            h->win = true; h->win_pat = true; h->win_vd = true; h->win_geom = kWinPatGeom; h->win_rows = 64;
+            h->sweep_waves = sw.waves; h->sweep_tiles = (int)sw.tiles.size();
+            wall.swap(sw.tiles);
+            wp.t0 = wall; wp.t1.clear();
+        }
+    }
+    if (!h->win_pat && h->want_win && h->want_pat && h->want_vdict && !h->win_rows_override && n_rows >= 64 && nnz > 0 && nnz <= (int64_t)kPatSlots * n_rows) {
         WinPlan wq;
         plan_window_tiles(n_rows, ncols, ip.data(), indices, n_ghost > 0 ? cls.data() : nullptr, 64, kWinCapNnz, kWinPatPages, wq);
         if (wq.ok0 && wq.ok1 && wq.t0.size() + wq.t1.size() < (size_t)(1 << 26)) {
@@ -2660,6 +2680,26 @@ int64_t prcg_plan_window_patterns(int64_t n, int64_t n_cols, const int32_t* indp
     return 1;
 }
 
+int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, int max_waves,
+                        int32_t* tiles_out, int64_t tile_capacity, void* pat_out, int64_t pat_capacity, uint16_t* masks_out,
+                        int64_t mask_capacity, int64_t* counts_out) {
+    if (n < 0 || !indptr || (indptr[n] > 0 && (!indices || !data)) || !counts_out) return -1;
+    SweepPlan sw;
+    std::vector<PatRec> pats;
+    std::vector<uint16_t> masks;
+    if (!plan_sweep_tiles(n, n, indptr, indices, kWinPatPages, max_waves, sw)) return 0;
+    if (!plan_window_patterns(sw.tiles, indptr, sw.cw.data(), data, pats, masks)) return 0;
+    counts_out[0] = (int64_t)sw.tiles.size(); counts_out[1] = (int64_t)pats.size(); counts_out[2] = (int64_t)masks.size();
+    counts_out[3] = sw.waves; counts_out[4] = sw.plane; counts_out[5] = sw.rows_per_tile;
+    if ((int64_t)sw.tiles.size() > tile_capacity || (int64_t)pats.size() > pat_capacity || (int64_t)masks.size() > mask_capacity ||
+        !tiles_out || !pat_out || !masks_out)
+        return -(int64_t)sw.tiles.size();
+    memcpy(tiles_out, sw.tiles.data(), sw.tiles.size() * sizeof(WTile));
+    memcpy(pat_out, pats.data(), pats.size() * sizeof(PatRec));
+    memcpy(masks_out, masks.data(), masks.size() * sizeof(uint16_t));
+    return 1;
+}
+
 int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, const uint8_t* row_class,
                             int rows_per_tile, int share, int64_t* out) {
     if (n < 0 || n_cols < n || !indptr || (indptr[n] > 0 && !indices) || (rows_per_tile != 64 && rows_per_tile != 128) || !out)
@@ -2719,9 +2759,9 @@ int64_t prcg_debug_layout(const prcg_t* h, int64_t* out, int64_t capacity) {
     out[2] = h->win ? h->win_rows : 0;
     out[3] = nt;
     out[4] = h->last_grid;                                                        // workgroups of the last one-launch iteration
-    out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm, h->nwt_int + h->nwt_bnd, h->want_big) : 4;
+    out[5] = h->win ? win_fused_waves_per_block(h->win_geom, h->win_vd, h->fused_comm, h->nwt_int + h->nwt_bnd, h->want_big, h->sweep_waves) : 4;
     out[6] = h->win ? h->nwt_int : h->nt_int;
-    out[7] = h->win ? h->win_order : 0;
+    out[7] = h->win ? (int64_t)h->win_order | ((int64_t)h->sweep_waves << 8) : 0;    // bit 0: XCD-chunked tile order; >> 8: waves of a sweep table
     std::vector<int32_t> rows((size_t)nt * 2);
     if (h->win) {
         std::vector<WTile> t((size_t)nt);

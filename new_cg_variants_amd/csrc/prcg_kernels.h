@@ -230,6 +230,7 @@ struct WinDev {
     const double* vdict;
     const unsigned short* rel;     // row pointers relative to the tile's first nonzero (tile.src_r); geometry 5: the rows' slot masks
     const PatRec* pat;             // geometry 5: the pattern records (tile.src_c = pattern id)
+    int sweep_waves, sweep_tiles;  // geometry 5, sweep table (prcg_plan.h: plan_sweep_tiles): the waves / tiles the carry bits assume (0: none)
     int big_ok;                    // short launches of the one-launch iteration may take big workgroups (PRCG_WIN_BIG=0: never)
     int order;                     // 1: XCD-chunked tile order (each XCD sweeps one contiguous eighth of the table), 0: chip-wide front
     int period;                    // > 1: tiles t and t + period read the same stream images (host: the launch picks a wave
@@ -256,7 +257,7 @@ int launch_win_spmm2(hipStream_t st, const WinDev& A, const WTile* tiles, int nt
 int launch_win_pipe_fused(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles, int geom, const FusedState& f,
                           int per_cu);
 // waves per workgroup of that launch (the inner products' summation order depends on it: prcg_debug_layout)
-int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok);
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok, int sweep_waves);
 // Second of the TWO launches of a Hestenes-Stiefel iteration on a window operator (hs_cg.py:57-61,
 // hs_pcg :120-124).  The first (launch_hs_update_xr with `prev`) left nu_k = <r~,r> as block partials;
 // every workgroup of this launch sums them in the same fixed order, b_k = nu_k / nu_k1, and the window of

@@ -3,6 +3,7 @@
 #include "prcg_plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <map>
 #include <climits>
@@ -240,7 +241,13 @@ namespace {
 // one tile's pattern record and slot masks; false: the tile is no pattern tile
 bool pattern_of_tile(const WTile& t, const int32_t* indptr, const uint16_t* cw, const double* data, PatRec& rec, uint16_t (&m)[64],
                      bool& full) {
-    if (t.re - t.rb > 64 || t.re <= t.rb) return false;
+    if (t.re - t.rb > 64 || t.re < t.rb) return false;
+    if (t.re == t.rb) {                                                   // an empty tile (padding of a sweep table): no slots, no rows
+        memset(&rec, 0, sizeof rec);
+        memset(m, 0, sizeof m);
+        full = false;
+        return true;
+    }
     // slots: the distinct d = window index - lane over the tile; one value per slot; `succ`: slot a directly precedes slot b
     // in some row (the rows' own order is what the sum follows -- in a row block ghost columns are numbered behind the
     // owned ones, so a row's columns need not ascend)
@@ -371,11 +378,196 @@ bool plan_window_patterns(std::vector<WTile>& tiles, const int32_t* indptr, cons
         tiles[ti].src_r = (int)plan[ti].mask_at;
         tiles[ti].spare = plan[ti].full;
         tiles[ti].maxlen = plan[ti].nslots;
-        tiles[ti].vd_first = tiles[ti].vd_count = 0;
+        // LDS slot of each page: as a sweep planner set it (bit 25), else every page in its own order
+        if (!(tiles[ti].vd_first & (1 << 25))) {
+            int perm = 1 << 25;
+            for (int p = 0; p < 6; ++p) perm |= p << (3 * p);
+            tiles[ti].vd_first = perm;
+        }
+        tiles[ti].vd_count = 0;
     }
     if (mstore.empty()) mstore.assign(64, 0);
     patterns.swap(pats);
     masks.swap(mstore);
+    return true;
+}
+
+bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, int max_pages, int max_waves,
+                      SweepPlan& out) {
+    if (n < 4096 || n_cols != n || max_pages > 6 || max_pages < 3) return false;
+    {   // cheap look first: a row in the middle must reach at least 256 rows away, symmetrically, with n a multiple of that
+        const int64_t r = n / 2;
+        int64_t lo_o = 0, hi_o = 0;
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            lo_o = std::min<int64_t>(lo_o, (int64_t)indices[q] - r);
+            hi_o = std::max<int64_t>(hi_o, (int64_t)indices[q] - r);
+        }
+        if (hi_o < 256 || lo_o != -hi_o || n % hi_o != 0) return false;
+    }
+    // the operator's distinct offsets col - row
+    int nd = 0;
+    int64_t off[kPatSlots];
+    for (int64_t r = 0; r < n; ++r) {
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int64_t o = (int64_t)indices[q] - r;
+            int u = 0;
+            while (u < nd && off[u] != o) ++u;
+            if (u == nd) {
+                if (nd == kPatSlots) return false;
+                off[nd++] = o;
+            }
+        }
+    }
+    if (nd < 3) return false;
+    std::sort(off, off + nd);
+    const int64_t Z = off[nd - 1];
+    if (off[0] != -Z || Z < 256 || Z > (1 << 24) || n % Z != 0 || n / Z < 8) return false;
+    // clusters of offsets that one page serves (gap <= 16 joins); the own cluster holds 0
+    int ng = 0, gmin[8], gmax[8], own = -1;
+    for (int u = 0; u < nd; ++u) {
+        if (ng > 0 && off[u] - gmax[ng - 1] <= 16) { gmax[ng - 1] = (int)off[u]; }
+        else {
+            if (ng == max_pages) return false;
+            gmin[ng] = gmax[ng] = (int)off[u]; ++ng;
+        }
+    }
+    int span = 0;
+    for (int g = 0; g < ng; ++g) {
+        if (gmin[g] <= 0 && gmax[g] >= 0) own = g;
+        span = std::max(span, gmax[g] - gmin[g]);
+    }
+    if (own < 0 || span > 16) return false;
+    const int R = 64 - span;                                             // rows per tile: a cluster's columns fit one page
+    // a cluster's page starts at rb + centre + (own cluster's minimum): the own page of one plane is the z page of the next
+    int centre[8];
+    for (int g = 0; g < ng; ++g) {
+        // any centre in [gmax - max_own, gmin - min_own] lets the page serve the cluster; the middle of the cluster makes the
+        // z clusters' centres exactly +-Z (their pages then ARE the own pages of the neighbouring planes)
+        const int lo_c = gmax[g] - gmax[own], hi_c = gmin[g] - gmin[own];
+        if (lo_c > hi_c) return false;                                            // wider than the own cluster
+        int c = (gmin[g] + gmax[g]) / 2;
+        c = c < lo_c ? lo_c : (c > hi_c ? hi_c : c);
+        centre[g] = c;
+        if (g > 0 && centre[g] - centre[g - 1] < 64) return false;               // pages of neighbouring clusters must not meet
+    }
+    const int64_t P = n / Z;
+    const int C = (int)((Z + R - 1) / R);
+    // every block of rows of a plane (C of them) is swept by `chunks` waves, each over a run of consecutive planes: as many
+    // chunks as max_waves allows with runs of >= 8 planes; runs differ by one plane at most (the shorter ones end with an
+    // empty tile), the waves are rounded up to a multiple of 4 by slots that hold empty tiles only
+    int chunks = (int)std::min<int64_t>(max_waves / C, P / 8);
+    if (chunks < 1 || (int64_t)C * chunks < max_waves / 8) return false;
+    const int W = (C * chunks + 3) & ~3;
+    const int64_t K = (P + chunks - 1) / chunks;
+    const int64_t ntab = (int64_t)W * K;
+    if (ntab >= (1 << 26)) return false;
+    out.tiles.assign((size_t)ntab, WTile{});
+    out.cw.assign((size_t)indptr[n] + 32, 0);
+    out.waves = W; out.plane = (int)Z; out.rows_per_tile = R; out.chunks = chunks; out.most_pages = 0;
+    std::atomic<bool> ok{true};
+    auto sweep = [&](int s_begin, int s_end, int* most) {
+        int64_t held[6];
+        for (int s = s_begin; s < s_end && ok; ++s) {
+            if (s >= C * chunks) continue;                                // padding slot: empty tiles only
+            const int chunk = s / C, j = s % C;
+            const int64_t p_first = P * chunk / chunks, p_end = P * (chunk + 1) / chunks;     // this wave's planes
+            for (int p = 0; p < 6; ++p) held[p] = INT64_MIN;              // page start each LDS slot of this wave holds
+            for (int64_t k = 0; k < K; ++k) {
+                WTile& t = out.tiles[(size_t)(k * W + s)];
+                const int64_t plane = p_first + k;
+                if (plane >= p_end) continue;                             // a run one plane shorter: empty tile
+                const int64_t rb = plane * Z + (int64_t)j * R, re = std::min(rb + R, (plane + 1) * Z);
+                t.rb = (int)rb; t.re = (int)re; t.lo = indptr[rb]; t.hi = indptr[re];
+                // logical pages: the clusters this tile has nonzeros in, ascending
+                bool has[8] = {false, false, false, false, false, false, false, false};
+                int maxlen = 0;
+                for (int64_t r = rb; r < re; ++r) {
+                    maxlen = std::max(maxlen, indptr[r + 1] - indptr[r]);
+                    for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+                        const int64_t o = (int64_t)indices[q] - r;
+                        int g = 0;
+                        while (g < ng && !(o >= gmin[g] && o <= gmax[g])) ++g;
+                        if (g == ng) { ok = false; return; }
+                        has[g] = true;
+                    }
+                }
+                has[own] = true;                                          // the fused epilogues read the row's own entry from the window
+                int np = 0, lp_of[8];
+                int64_t start[6];
+                bool natural = true;
+                for (int g = 0; g < ng; ++g) {
+                    lp_of[g] = -1;
+                    if (!has[g]) continue;
+                    const int64_t st = rb + centre[g] + gmin[own];
+                    if (st < 0) { natural = false; break; }               // at the very start of the vector: pages by the greedy cover, below
+                    if (st + 64 > n_cols + 63) { ok = false; return; }
+                    if (np > 0 && st < start[np - 1] + 64) { ok = false; return; }
+                    lp_of[g] = np; start[np++] = st;
+                }
+                if (!natural) {
+                    // the first tiles of the vector (a cluster's page would begin before column 0): the greedy cover of the row-order
+                    // tilings, pages in their own order (no slot table, nothing carried in or out)
+                    std::vector<WTile> one(1, t);
+                    const int got = window_pages(one, 0, 1, n, n_cols, indptr, indices, max_pages, out.cw.data());
+                    if (got < 0) { ok = false; return; }
+                    t = one[0];
+                    int perm = 0;
+                    for (int p = 0; p < got; ++p) { perm |= p << (3 * p); held[p] = t.page_col[p]; }
+                    t.vd_first = perm | (1 << 25);
+                    t.vd_count = 0;
+                    *most = std::max(*most, got);
+                    continue;
+                }
+                const bool through_perm = true;
+                for (int64_t r = rb; r < re; ++r)
+                    for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+                        const int64_t o = (int64_t)indices[q] - r;
+                        int g = 0;
+                        while (!(o >= gmin[g] && o <= gmax[g])) ++g;
+                        const int64_t w = (int64_t)indices[q] - start[lp_of[g]];
+                        if (w < 0 || w > 63) { ok = false; return; }
+                        out.cw[q] = (uint16_t)(lp_of[g] * 64 + w);
+                    }
+                // LDS slots: a page the wave's previous tile left behind stays where it is
+                int slot[6], used = 0, carry = 0;
+                for (int p = 0; p < np; ++p) {
+                    slot[p] = -1;
+                    if (!through_perm) continue;
+                    for (int sl = 0; sl < 6; ++sl)
+                        if (held[sl] == start[p] && !(used & (1 << sl))) { slot[p] = sl; used |= 1 << sl; carry |= 1 << p; break; }
+                }
+                if (!through_perm) { for (int p = 0; p < np; ++p) slot[p] = p; used = (1 << np) - 1; carry = 0; }
+                for (int p = 0; p < np; ++p) {
+                    if (slot[p] >= 0) continue;
+                    int sl = 0;
+                    while (used & (1 << sl)) ++sl;
+                    slot[p] = sl; used |= 1 << sl;
+                }
+                for (int p = 0; p < np; ++p) held[slot[p]] = start[p];
+                int perm = 0;
+                for (int p = 0; p < np; ++p) perm |= slot[p] << (3 * p);
+                t.vd_first = perm | (carry << 18) | (through_perm ? (1 << 24) : 0) | (1 << 25);
+                t.vd_count = 0;
+                t.geo = np | ((slot[lp_of[own]] * 64 + (int)(rb - start[lp_of[own]])) << 8);
+                t.maxlen = maxlen;
+                for (int p = 0; p < kWinMaxPages; ++p) t.page_col[p] = p < np ? (int)start[p] : 0;
+                *most = std::max(*most, np);
+            }
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+    std::vector<int> most(nt, 0);
+    std::vector<std::thread> th;
+    const int per = (W + (int)nt - 1) / (int)nt;
+    for (unsigned i = 0; i < nt; ++i) {
+        const int a = std::min(W, (int)i * per), b = std::min(W, a + per);
+        if (a < b) th.emplace_back([&, a, b, i] { sweep(a, b, &most[i]); });
+    }
+    for (auto& t : th) t.join();
+    if (!ok) { out = SweepPlan{}; return false; }
+    for (int m : most) out.most_pages = std::max(out.most_pages, m);
     return true;
 }
 

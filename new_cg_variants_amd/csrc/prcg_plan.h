@@ -97,6 +97,29 @@ static_assert(sizeof(PatRec) == 72, "the kernels read a pattern record with scal
 bool plan_window_patterns(std::vector<WTile>& tiles, const int32_t* indptr, const uint16_t* cw, const double* data,
                           std::vector<PatRec>& patterns, std::vector<uint16_t>& masks);
 
+// ---- sweep order for stencils on a regular grid (pattern tiles only) ----------------------------------------
+// A 3-D (2-D) stencil reaches one grid plane (line) up and down: rows r - Z and r + Z.  In row order a wave's consecutive
+// tiles are far apart and every tile stages its z-, own and z+ pages anew (S2: 6 pages of (r,s) pairs per 64 rows against
+// a band's 2 -- what bounds it, profiles/r03_sweeps.md K).  Here the tile TABLE is ordered so that the tiles one wave takes
+// one after the other (slot, slot + waves, slot + 2 waves, ...) are the same block of rows in CONSECUTIVE planes, and the
+// pages are cut so that the own page of plane k IS the z- page of plane k+1 and its z+ page the own page: a page that the
+// wave's previous tile left in LDS is not loaded again (`carry`), only its place in the window changes (`perm`: logical
+// page -> LDS slot).  Requirements: no ghost columns, n a multiple of Z, every row's offsets from the operator's <= 16
+// distinct ones, offset clusters (z-, y-, own, y+, z+, ...) at most kWinPatPages, tiles of 64 - (width of the widest
+// cluster) rows inside one plane.  The launch must run exactly `waves` waves (the kernel checks and otherwise ignores the
+// carry bits: every page is loaded, which is always correct).
+//   tile.vd_first = perm (3 bits per logical page) | carry << 18 | (1 << 24 if slots are addressed through perm) | 1 << 25;
+//   tile.geo's own-row index is PHYSICAL (slot * 64 + offset); cw[q] = logical page * 64 + offset inside it.
+// Empty tiles (rb == re) pad the table where a plane's blocks do not fill the last workgroup.
+struct SweepPlan {
+    std::vector<WTile> tiles;      // table order
+    std::vector<uint16_t> cw;      // per nonzero (CSR order)
+    int waves = 0;                 // waves of the launch the carry bits assume
+    int plane = 0, rows_per_tile = 0, chunks = 0, most_pages = 0;
+};
+bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const int32_t* indices, int max_pages, int max_waves,
+                      SweepPlan& out);
+
 // ---- sliced rows (prcg_sell.hip) ---------------------------------------------------------------
 // Slices of up to 64 consecutive rows of one class (interior slices first).  Within a slice of width w (its longest
 // row), nonzero u of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4]

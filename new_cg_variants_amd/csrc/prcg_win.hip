@@ -169,6 +169,8 @@ __device__ __forceinline__ void load_pattern(const PatRec* __restrict__ pat, int
         ps.val[k] = __hiloint2double((int)hi, (int)lo);
     }
 }
+// sweep tables (prcg_plan.h: plan_sweep_tiles): d.vdf = perm (3 bits per logical page: its LDS slot) | carry << 18 | through-perm << 24
+__device__ __forceinline__ int pat_slot(int vdf, int p) { return (vdf >> (3 * p)) & 7; }
 __device__ __forceinline__ int pat_offset(const PatState& ps, int u) {          // u: compile-time after unrolling
     const unsigned w = ps.cb[u >> 1];
     return (u & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
@@ -190,7 +192,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                                             const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
                                             WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false,
                                             const typename VecT<NV>::type* G = nullptr, int n_own = 0,
-                                            const FusedPrev::Lag* lg = nullptr) {
+                                            const FusedPrev::Lag* lg = nullptr, bool carry_ok = false) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -239,7 +241,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
 #ifdef PRCG_DEBUG_SKIP_PAGES
         if (p < d.np - PRCG_DEBUG_SKIP_PAGES) {                             // TIMING EXPERIMENT ONLY (wrong products): the last pages are not loaded
 #else
-        if (p < d.np) {                                                     // wave-uniform branch
+        if (p < d.np && !(CW == 32 && carry_ok && ((d.vdf >> (18 + p)) & 1))) {   // wave-uniform (sweep tables: a page the wave's previous tile left in LDS)
 #endif
             if constexpr (EPI == kEpiHS) { R.w[p].x = X[d.pc[p] + lane]; R.w[p].y = X2[d.pc[p] + lane]; }
             else if constexpr (epi_pr_one(EPI)) {
@@ -345,6 +347,7 @@ struct WCtx {
     // need go to THEIR ghost areas of the iteration written (offset gout, in doubles, into every exchange buffer)
     const typename VecT<NV>::type* G; int n_own; const PeerDev* px; long long gout;
     const FusedPrev::Lag* lg; bool lagged;      // one-launch Chronopoulos-Gear / Ghysels-Vanroose: vectors; a deferred p, s (u) update is pending
+    bool carry_ok;                              // sweep tables: this launch runs the waves the carry bits assume (else every page is loaded)
 };
 
 // One tile: park its image (R, requested DEPTH tiles ago) in LDS, request tile `dnext` into the
@@ -419,11 +422,12 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     }
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
-        if (p < dcur.np) {
+        if (p < dcur.np && !(CW == 32 && c.carry_ok && ((dcur.vdf >> (18 + p)) & 1))) {
+            const int sp = CW == 32 ? pat_slot(dcur.vdf, p) : p;            // (sweep tables: the page's LDS slot; else its own index)
             // Hestenes-Stiefel: the direction is formed here, p = z + b p_old (hs_cg.py:60), never gathered
-            if constexpr (EPI == kEpiHS) c.sw[p * 64 + lane] = R.w[p].x + cf.bt * R.w[p].y;
+            if constexpr (EPI == kEpiHS) c.sw[sp * 64 + lane] = R.w[p].x + cf.bt * R.w[p].y;
             // predict-and-recompute: r~ -= a s~, then p = r~ + b p_old (pr_cg.py:148,151), formed here
-            else if constexpr (epi_pr_one(EPI)) c.sw[p * 64 + lane] = (R.w[p].x - cf.al * R.w[p].y) + cf.bt * R.w[p].z;
+            else if constexpr (epi_pr_one(EPI)) c.sw[sp * 64 + lane] = (R.w[p].x - cf.al * R.w[p].y) + cf.bt * R.w[p].z;
             // Chronopoulos-Gear: r -= a s, r~ = M^-1 r (cg_cg.py:60, cg_pcg :117-118), formed here
             // (Ghysels-Vanroose: w -= a u, w~ = M^-1 w, gv_cg.py:67 / :155,161 -- the same form)
             // one launch per Chronopoulos-Gear / Ghysels-Vanroose iteration: the deferred s = w + b s_old (u = t + b u_old) and
@@ -431,11 +435,11 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
             else if constexpr (epi_lag(EPI)) {
                 const double z2n = c.lagged ? R.w[p].y + cf.bt * R.w[p].z : R.w[p].z;
                 const double v = R.w[p].x - cf.al * z2n;
-                if constexpr (EPI == kEpiCGOneJ) c.sw[p * 64 + lane] = R.w[p].w * v; else c.sw[p * 64 + lane] = v;
+                if constexpr (EPI == kEpiCGOneJ) c.sw[sp * 64 + lane] = R.w[p].w * v; else c.sw[sp * 64 + lane] = v;
             }
-            else if constexpr (EPI == kEpiCGW || EPI == kEpiGVW) c.sw[p * 64 + lane] = R.w[p].x - cf.al * R.w[p].y;
-            else if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) c.sw[p * 64 + lane] = R.w[p].z * (R.w[p].x - cf.al * R.w[p].y);
-            else reinterpret_cast<RV*>(c.sw)[p * 64 + lane] = R.w[p];
+            else if constexpr (EPI == kEpiCGW || EPI == kEpiGVW) c.sw[sp * 64 + lane] = R.w[p].x - cf.al * R.w[p].y;
+            else if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) c.sw[sp * 64 + lane] = R.w[p].z * (R.w[p].x - cf.al * R.w[p].y);
+            else reinterpret_cast<RV*>(c.sw)[sp * 64 + lane] = R.w[p];
         }
     }
     int rs_[M], re_[M];
@@ -480,7 +484,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first && !c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         next_same = same_image<PG>(rc, dnext);
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own, c.lg);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own, c.lg, c.carry_ok);
     }
 
     const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
@@ -598,6 +602,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
             // pattern tile: slot u of every row that has it is val[u] * window[lane + cb[u]] -- scalar value, scalar offset, no
             // index byte; rows at a grid edge skip the slots their mask lacks (same left-to-right sum over what the row has)
             const bool full = dcur.img != 0;                                // wave-uniform
+            const bool via_perm = ((dcur.vdf >> 24) & 1) != 0;
             const unsigned mk = full ? 0xffffu : (unsigned)rs_[j];
             const int cb0 = pat_offset(ps, 0);
 #pragma unroll
@@ -606,7 +611,8 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                     V g[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int cb = u0 + k < ps.nslots ? pat_offset(ps, u0 + k) : cb0;
+                        int cb = u0 + k < ps.nslots ? pat_offset(ps, u0 + k) : cb0;
+                        if (via_perm) cb = pat_slot(dcur.vdf, cb >> 6) * 64 + (cb & 63);      // wave-uniform: logical page -> LDS slot
                         int idx = cb + lane;
                         if (!full) idx = idx < 0 ? 0 : (idx > PG * 64 - 1 ? PG * 64 - 1 : idx);     // lanes without the slot: any valid entry
                         g[k] = c.sw[idx];
@@ -816,7 +822,8 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
                      yout_, write_mask, ep_r, ep_d, ep_st,
                      FusedRowPtrs{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st),
                                   reinterpret_cast<double2*>(fz.rs), ep_d, fz.w, fz.wt, (write_mask & 8) != 0},
-                     fz.pr, lane, nullptr, 0, nullptr, 0, &fz.lag, fz.nprev > 0};
+                     fz.pr, lane, nullptr, 0, nullptr, 0, &fz.lag, fz.nprev > 0,
+                     CW == 32 && DEF == 0 && A.sweep_waves > 0 && A.sweep_waves == (int)gridDim.x * WPB && A.order == 0};
     WCtx<NV>& cm = c;
     if constexpr (DEF > 0) {
         if (fz.px) {
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         same[i] = false;
         if (t + i * W < tend) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg, c.carry_ok);
             else pend[i] = true;
         }
     }
@@ -1051,7 +1058,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         if (pend[0]) {
             if (!acquired) { if (!fz.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); acquired = true; }
             same[0] = same_image<PG>(rc, d[0]);
-            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own, c.lg);
+            issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own, c.lg, c.carry_ok);
             pend[0] = false;
         }
         // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
@@ -1256,7 +1263,9 @@ int launch_win_g(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
 {
     if constexpr (epi_fused(EPI) && !DEFER) {
         // the one-launch pipelined iteration of a SHORT launch: big workgroups (see waves_per_block_big)
-        if (A.big_ok && win_big_workgroups(ntiles, A.vidx8 != nullptr)) {
+        // (a sweep table keeps the workgroup size that divides its waves: the carry bits are worth more than the prologue)
+        constexpr int kBigW = waves_per_block_big(win_nw(NV, EPI), PG, CW, true);
+        if (A.big_ok && win_big_workgroups(ntiles, A.vidx8 != nullptr) && !(CW == 32 && A.sweep_waves > 0 && A.sweep_waves % kBigW != 0)) {
             if (A.vidx8 != nullptr || CW == 32)
                 return launch_win_v<NV, EPI, M, PG, CW, true, DEFER, true>(st, A, tiles, ntiles, x, y, write_mask, ep_r, ep_d, ep_st, partials,
                                                                            aux, fz, per_cu, done);
@@ -1301,6 +1310,10 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
         const int waves = grid * WPB, rounds = (ntiles + waves - 1) / waves;
         grid = ((ntiles + rounds - 1) / rounds + WPB - 1) / WPB;
     }
+    if (!DEFER && per_cu < 1 && CW == 32 && A.sweep_waves > 0 && A.sweep_waves % WPB == 0 && ntiles == A.sweep_tiles && A.order == 0) {
+        // a sweep table: the carry bits assume exactly these waves (slot s takes tiles s, s + waves, ...)
+        grid = A.sweep_waves / WPB;
+    }
     if (!DEFER && per_cu < 1 && A.period > 1) {
         // the stream images repeat every `period` tiles: with a wave count that is a multiple of the period (and of the
         // workgroup size) every wave meets the SAME image tile after tile and keeps its rows decoded in registers
@@ -1336,7 +1349,7 @@ int launch_win(int geom, hipStream_t st, const WinDev& A, const WTile* tiles, in
 
 }  // namespace
 
-int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok) {
+int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntiles, bool big_ok, int sweep_waves) {
     if (deferred) {
         switch (geom) {
         case 0: return wpb_defer(1, 2, 2, 8, value_dict);
@@ -1353,7 +1366,8 @@ int win_fused_waves_per_block(int geom, bool value_dict, bool deferred, int ntil
     case 2: return big ? waves_per_block_big(2, 8, 16, value_dict) : waves_per_block(2, 8, 16, value_dict);
     case 3: return big ? waves_per_block_big(2, 12, 16, value_dict) : waves_per_block(2, 12, 16, value_dict);
     case 4: return big ? waves_per_block_big(2, 8, 16, value_dict) : waves_per_block(2, 8, 16, value_dict);
-    case 5: return big ? waves_per_block_big(2, kWinPatPages, 32, true) : waves_per_block(2, kWinPatPages, 32, true);
+    case 5: return (big && !(sweep_waves > 0 && sweep_waves % waves_per_block_big(2, kWinPatPages, 32, true) != 0))
+                       ? waves_per_block_big(2, kWinPatPages, 32, true) : waves_per_block(2, kWinPatPages, 32, true);
     default: return 0;
     }
 }

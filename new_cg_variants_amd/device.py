@@ -239,7 +239,7 @@ class DeviceCSR:
         if got < 8:
             raise RuntimeError('prcg_debug_layout failed')
         return {'window': bool(out[0]), 'geometry': int(out[1]), 'rows_per_tile': int(out[2]), 'tiles': out[8:got].reshape(-1, 2).copy(),
-                'grid': int(out[4]), 'waves_per_block': int(out[5]), 'interior_tiles': int(out[6]), 'xcd_chunked': bool(out[7])}
+                'grid': int(out[4]), 'waves_per_block': int(out[5]), 'interior_tiles': int(out[6]), 'xcd_chunked': bool(int(out[7]) & 1), 'sweep_waves': int(out[7]) >> 8}
 
     def operator_bytes(self):
         """Bytes of the operator as the device streams it (prcg.h: prcg_operator_bytes)."""

@@ -566,3 +566,61 @@ def test_pattern_tiles_refuse_what_is_no_constant_stencil():
     assert plan_patterns(E) is not None
     F = sp.diags([np.full(3000 - abs(k), 1.0 + k) for k in range(-3, 4)], list(range(-3, 4))).tocsr()         # 7 values: too many
     assert plan_patterns(F) is None
+
+
+def test_sweep_tables_carry_exactly_the_pages_they_claim():
+    """Sweep order of the pattern tiles (csrc/prcg_plan.h: plan_sweep_tiles), checked through prcg_plan_window_patterns' sibling
+    prcg_plan_sweep: (a) the matrix rebuilt from (pages, patterns, masks) equals the CSR row by row, as for any tiling; (b) an
+    LDS model of every wave -- slot s takes tiles s, s + waves, ...; a tile parks its non-carried pages in the slots its `perm`
+    names -- holds, for every tile, exactly the page each logical page claims, carried or not; (c) carried pages are the
+    majority for a 3-D stencil (z-, own of every plane after a sweep's first)."""
+    for dims in ((72, 8, 200), (100, 9, 96), (300, 64)):
+        A = (problems.laplace_3d(*dims) if len(dims) == 3 else problems.laplace_2d(*dims)).tocsr()
+        n = A.shape[0]
+        indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        data = np.ascontiguousarray(A.data, dtype=np.float64)
+        counts = np.zeros(8, dtype=np.int64)
+        got = L.lib().prcg_plan_sweep(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), 320, None, 0, None, 0, None, 0, L.ptr(counts))
+        assert got < 0, (dims, got)
+        tiles = np.zeros((counts[0], 24), dtype=np.int32)
+        pats = np.zeros(counts[1] * 72, dtype=np.uint8)
+        masks = np.zeros(counts[2], dtype=np.uint16)
+        got = L.lib().prcg_plan_sweep(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), 320, L.ptr(tiles), len(tiles), L.ptr(pats), int(counts[1]),
+                                      L.ptr(masks), len(masks), L.ptr(counts))
+        assert got == 1
+        waves, plane, rows_per_tile = int(counts[3]), int(counts[4]), int(counts[5])
+        assert plane == (dims[0] * dims[1] if len(dims) == 3 else dims[0]) and waves % 4 == 0 and len(tiles) % waves == 0
+        rec = np.dtype([('nslots', '<i4'), ('vsel', '<u4'), ('cb', '<i2', 16), ('val', '<f8', 4)])
+        pats = pats.view(rec)
+        real = tiles[tiles[:, 1] > tiles[:, 0]]
+        ip2, ix2, dt2 = matrix_from_patterns(A.shape, real, pats, masks)
+        assert np.array_equal(ip2, A.indptr) and np.array_equal(ix2, A.indices) and np.array_equal(dt2.view(np.uint64), A.data.view(np.uint64))
+        carried = loaded = 0
+        for s in range(waves):
+            held = [None] * 8
+            for t in tiles[s::waves]:
+                if t[1] <= t[0]:
+                    continue
+                npages, vdf = int(t[4]) & 255, int(t[6])
+                perm = [(vdf >> (3 * p)) & 7 for p in range(npages)]
+                carry = (vdf >> 18) & 63
+                assert len(set(perm)) == npages and max(perm) < 6
+                for p in range(npages):
+                    if (carry >> p) & 1:
+                        assert (vdf >> 24) & 1 and held[perm[p]] == int(t[8 + p]), (s, t[:8], p)
+                        carried += 1
+                    else:
+                        held[perm[p]] = int(t[8 + p])
+                        loaded += 1
+                # the row's own entry: PHYSICAL window index of row rb
+                own = (int(t[4]) >> 8) & 0xffff
+                lp = perm.index(own // 64)
+                assert int(t[8 + lp]) + own % 64 == int(t[0])
+        print(dims, 'waves', waves, 'rows per tile', rows_per_tile, 'pages carried', carried, 'loaded', loaded)
+        assert carried > 0.3 * (carried + loaded)
+    # no sweep for what is no stencil on full planes
+    B = problems.banded_ex2b(8192, 7).tocsr()
+    counts = np.zeros(8, dtype=np.int64)
+    assert L.lib().prcg_plan_sweep(B.shape[0], L.ptr(np.ascontiguousarray(B.indptr, dtype=np.int32)), L.ptr(np.ascontiguousarray(B.indices, dtype=np.int32)),
+                                   L.ptr(np.ascontiguousarray(B.data)), 4096, None, 0, None, 0, None, 0, L.ptr(counts)) == 0

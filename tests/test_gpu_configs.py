@@ -255,12 +255,13 @@ def test_s2_full_size(amd):
     assert (n, A.nnz) == (216 ** 3, 70_263_936)
     x = np.random.default_rng(32).standard_normal(n)
     ones = np.ones(n)
-    for knobs, geom in (({}, 5), ({'PRCG_VALDICT': '0'}, 4), ({'PRCG_WIN_PAT': '0'}, 4), ({'PRCG_WIN_PAT': '0', 'PRCG_WIN_ROWS': '128'}, 3),
+    for knobs, geom in (({}, 5), ({'PRCG_WIN_SWEEP': '0'}, 5), ({'PRCG_VALDICT': '0'}, 4), ({'PRCG_WIN_PAT': '0'}, 4), ({'PRCG_WIN_PAT': '0', 'PRCG_WIN_ROWS': '128'}, 3),
                         ({'PRCG_WIN': '0'}, -1)):
         op = amd['device'].DeviceCSR(A, knobs=knobs)
         s = op.schedule()
         assert s['window'] == ('PRCG_WIN' not in knobs), s
         assert op.layout()['geometry'] == geom, (knobs, op.layout()['geometry'])
+        assert (op.layout()['sweep_waves'] > 0) == (knobs == {}), knobs          # 1e7 rows on full grid planes: sweep table by default
         y1, _ = op.matvec(ones)
         assert np.array_equal(y1, A @ ones)
         products_bitexact(op, A, x, f's2 {knobs}')
@@ -635,3 +636,37 @@ def test_pattern_tiles_for_constant_coefficient_stencils(amd):
         y = op.matvec_ext(np.concatenate([x[lo:hi], x[ghosts]]))
         assert np.array_equal(y, ref[lo:hi]), r
         op.close()
+
+
+@pytest.mark.gpu
+def test_sweep_tables_keep_shared_pages_in_lds(amd):
+    """Stencils on full grid planes (no ghost columns) get a SWEEP table (csrc/prcg_plan.h: plan_sweep_tiles): a wave's consecutive
+    tiles are the same rows of consecutive planes and the pages they share are not loaded again.  Products bit-exact vs SciPy
+    whether the launch runs the waves the carry bits assume (small and big workgroups) or not (another grid: every page is
+    loaded), solves identical to the row-order pattern tiles (PRCG_WIN_SWEEP=0) to rounding; every solver family runs on it."""
+    L, P = amd['L'], amd['problems']
+    rng = np.random.default_rng(9)
+    for name, A in (('lap3d 70^3', P.laplace_3d(70, 70, 70)), ('lap3d 128x64x64', P.laplace_3d(128, 64, 64)), ('lap2d 2048x512', P.laplace_2d(2048, 512))):
+        n = A.shape[0]
+        x = rng.standard_normal(n)
+        b, x0, _ = P.reference_rhs(A, n)
+        hist = {}
+        force = {'PRCG_WIN_SWEEP': '2', 'PRCG_SWEEP_WAVES': '2048'}          # (by default only operators of 5e6 rows and more: S2 in test_s2_full_size)
+        for tag, knobs in (('sweep', force), ('sweep, small workgroups', dict(force, PRCG_WIN_BIG='0')),
+                           ('sweep table, other grid', dict(force, PRCG_WIN_GRID_PER_CU='3')), ('row order', {})):
+            op = amd['device'].DeviceCSR(A, knobs=knobs)
+            s, lay = op.schedule(), op.layout()
+            assert s['pattern'], (name, tag, s)
+            assert (lay['sweep_waves'] > 0) == bool(knobs), (name, tag, lay['sweep_waves'])
+            products_bitexact(op, A, x, f'{name} {tag}')
+            for variant in ('PIPE_PR', 'HS', 'PR', 'CG_CG'):
+                op.begin(getattr(L, variant), b, x0, 22, hist_mask=1)
+                op.iterate(21)
+                op.sync()
+                hist[(tag, variant)] = op.history()['updated_residual_2_norm']
+                if tag == 'sweep' and variant == 'PIPE_PR':
+                    lay2 = op.layout()
+                    assert lay2['grid'] * lay2['waves_per_block'] == lay2['sweep_waves'], lay2['grid']       # the carry bits are live
+            op.close()
+        for (tag, variant), h in hist.items():
+            np.testing.assert_allclose(h, hist[('row order', variant)], rtol=1e-9, err_msg=f'{name} {tag} {variant}')
