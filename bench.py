@@ -428,6 +428,7 @@ def main():
                     raise RuntimeError(er)
                 rec = dict(summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz)), config=cfg, workload=w2['desc'],
                            n=w2['n'], nnz=int(A2.nnz))
+                rec['traffic'] = measured_traffic(f"{name}:{args.variant}:fused:1:" + ('dict' if d2.schedule()['value_dict'] else 'plain'))
                 has_dict = d2.schedule()['value_dict']
                 d2.close()
                 if has_dict:

@@ -774,6 +774,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
 #ifndef PRCG_WIN_DEPTH_DICT
 #define PRCG_WIN_DEPTH_DICT 1
 #endif
+#ifndef PRCG_WIN_DEPTH_PAT
+#define PRCG_WIN_DEPTH_PAT 1        // pattern tiles (A/B builds: 2)
+#endif
 #ifndef PRCG_WIN_DEPTH_PLAIN
 #define PRCG_WIN_DEPTH_PLAIN 1
 #endif
@@ -1290,7 +1293,7 @@ int launch_win_v(hipStream_t st, const WinDev& A, const WTile* tiles, int ntiles
 {
     constexpr int DEF = DEFER ? (M == 1 ? kDeferTiles : 2) : 0;     // (128-row tiles: two stashed tiles = 16 KB of LDS per workgroup)
     constexpr int WPB = DEFER ? wpb_defer(M, win_nw(NV, EPI), PG, CW, vd) : (BIG ? waves_per_block_big(win_nw(NV, EPI), PG, CW, vd) : waves_per_block(win_nw(NV, EPI), PG, CW, vd));
-    auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN), DEF>;
+    auto k = k_win_tiles<NV, EPI, M, PG, CW, vd, WPB, ((CW == 32 && !DEFER) ? PRCG_WIN_DEPTH_PAT : (vd ? PRCG_WIN_DEPTH_DICT : PRCG_WIN_DEPTH_PLAIN)), DEF>;
     // (residency is a property of the kernel, not of the call: cached per instantiation and device)
     static int cached_ntiles_cap[2][2][16] = {};
     int dev = 0;

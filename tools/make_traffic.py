@@ -26,5 +26,13 @@ if len(sys.argv) > 3:      # config 5's stand-in: the sliced-row kernels
         entries['s4b:pipe_pr_cg:fused:1:plain'] = {
             'bytes_per_launch': v['read_bytes_corrected'] + v['write_bytes'], 'read_bytes': v['read_bytes_corrected'],
             'write_bytes': v['write_bytes'], 'kernel': k, 'duration_us_under_pmc': v['duration_us_under_pmc']}
+if len(sys.argv) > 4:      # config 4 at N = 1: S2
+    d = json.load(open(sys.argv[4]))
+    fused = [(k, v) for k, v in d.items() if 'k_win_tiles<2, 3' in k]
+    if fused:
+        k, v = max(fused, key=lambda kv: kv[1].get('dispatches', 0))
+        entries['s2:pipe_pr_cg:fused:1:dict'] = {
+            'bytes_per_launch': v['read_bytes_corrected'] + v['write_bytes'], 'read_bytes': v['read_bytes_corrected'],
+            'write_bytes': v['write_bytes'], 'kernel': k, 'duration_us_under_pmc': v['duration_us_under_pmc']}
 json.dump({'kernel_sha': bench.kernel_source_sha(), 'entries': entries}, sys.stdout, indent=1)
 print()

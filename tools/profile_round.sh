@@ -7,6 +7,7 @@
 #   pmc_dict.json / pmc_plain.json   per-kernel counter means (tools/pmc.sh: one pass per counter group), value
 #                              dictionary on (the default) and off (PRCG_VALDICT=0)
 #   s4b_kernel_stats.csv / pmc_s4b.json   the same for --workload s4b (FEM-like stand-in for Queen_4147)
+#   s2_kernel_stats.csv / pmc_s2.json     the same for --workload s2 (BASELINE config 4 at N = 1)
 #   traffic.json               HBM bytes per launch of the dominant kernel from those counters, stamped with the
 #                              kernel-source hash bench.py checks before quoting it
 tag=${1:-x}
@@ -35,5 +36,14 @@ cd $root
 ./tools/pmc.sh ${tag}_s4b --workload s4b --steps 30 --warmup 5 > $out/pmc_s4b.log 2>&1
 cp gpurun_out/pmc_${tag}_s4b.json $out/pmc_s4b.json
 rm -rf gpurun_out/pmc_${tag}_s4b
-python3 tools/make_traffic.py $out/pmc_dict.json $out/pmc_plain.json $out/pmc_s4b.json > $out/traffic.json
+# config 4 at N = 1 (S2, pattern tiles in sweep order): per-kernel statistics and counters
+cd /tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_s2 -- python3 $root/bench.py --workload s2 --no-cpu-baseline --no-multi-rank-leg --no-workloads --no-plain-values > $out/bench_s2_under_rocprof.json 2> $out/trace_s2.err
+cp $(find $out/trace_s2 -name "*kernel_stats.csv" | head -1) $out/s2_kernel_stats.csv
+rm -rf $out/trace_s2
+cd $root
+./tools/pmc.sh ${tag}_s2 --workload s2 --steps 30 --warmup 5 > $out/pmc_s2.log 2>&1
+cp gpurun_out/pmc_${tag}_s2.json $out/pmc_s2.json
+rm -rf gpurun_out/pmc_${tag}_s2
+python3 tools/make_traffic.py $out/pmc_dict.json $out/pmc_plain.json $out/pmc_s4b.json $out/pmc_s2.json > $out/traffic.json
 head -c 1200 $out/bench.json; echo; head -5 $out/kernel_stats.csv; cat $out/traffic.json
