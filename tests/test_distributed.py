@@ -719,3 +719,41 @@ def test_row_block_operator_self_check_and_drop_in_call_in_threads():
     #  workgroup shapes, rank order -- and the iterates drift apart like the paper's curves do: 0.3-0.7 % seen)
     assert np.linalg.norm(x - ref) <= 2e-2 * np.linalg.norm(ref)
     assert abs(np.linalg.norm(x - x_true) / np.linalg.norm(ref - x_true) - 1.0) <= 0.2
+
+
+@pytest.mark.gpu
+def test_sweep_table_operator_in_a_communicator_session():
+    """A sweep-table operator (pattern tiles in plane-sweep order, csrc/prcg_plan.h: plan_sweep_tiles) run by the DEFERRED
+    multi-rank kernel: its waves are not the ones the carry bits assume (one wave is the communication wave), so every page is
+    loaded -- through the tiles' slot tables all the same.  Teacher-forced steps against the plain schedule on the same
+    table: vectors bit for bit."""
+    from new_cg_variants_amd import _lib as L
+    from new_cg_variants_amd import partition, problems
+    from new_cg_variants_amd.device import DeviceCSR
+    A = problems.laplace_3d(128, 64, 64)
+    n = A.shape[0]
+    b, x0, _ = problems.reference_rhs(A, n)
+    knobs = {'PRCG_WIN_SWEEP': '2', 'PRCG_SWEEP_WAVES': '2048'}
+    uid, path = rccl_ids(1)
+    plain = DeviceCSR(A, knobs=knobs)
+    solo = DeviceCSR(A, comm_init=(0, 1, uid, path), knobs=knobs)
+    assert partition.connect_peer_exchange(solo, 0, lambda obj: [obj])
+    assert plain.layout()['sweep_waves'] > 0 and solo.layout()['sweep_waves'] > 0
+    plain.begin(L.PIPE_PR, b, x0, 40)
+    solo.begin(L.PIPE_PR, b, x0, 40)
+    s = solo.schedule()
+    assert s['pattern'] and s['peer'] and s['fused_comm'], s
+    plain.iterate(5)
+    for k in (5, 6, 7, 8):
+        for v in ('x', 'r', 'p', 's'):
+            solo.set_vector(v, plain.get_vector(v))
+        solo.set_scalars(k, plain.get_scalars(k))
+        solo.set_iteration(k)
+        plain.iterate(1)
+        solo.iterate(1)
+        solo.sync()
+        for v in ('x', 'r', 'p', 's'):
+            assert np.array_equal(solo.get_vector(v), plain.get_vector(v)), (k, v)
+        a, c = solo.get_scalars(k + 1)[:5], plain.get_scalars(k + 1)[:5]
+        assert np.max(np.abs(a - c) / np.abs(c)) <= 1e-12
+    plain.close(); solo.close()
