@@ -600,30 +600,48 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         }
         if constexpr (CW == 32) {
             // pattern tile: slot u of every row that has it is val[u] * window[lane + cb[u]] -- scalar value, scalar offset, no
-            // index byte; rows at a grid edge skip the slots their mask lacks (same left-to-right sum over what the row has)
+            // index byte; rows at a grid edge skip the slots their mask lacks (same left-to-right sum over what the row has).
+            // The per-tile decisions are taken ONCE (straight-line scalar code per slot: a 15-diagonal band lost 40 % to a
+            // branch per decision and slot): the slots' window offsets as the tile's LDS slots have them (sweep tables), whether
+            // every row is complete, whether the pattern has two values at most (a select) or up to four
             const bool full = dcur.img != 0;                                // wave-uniform
-            const bool via_perm = ((dcur.vdf >> 24) & 1) != 0;
             const unsigned mk = full ? 0xffffu : (unsigned)rs_[j];
-            const int cb0 = pat_offset(ps, 0);
+            unsigned pcb[kPatSlots / 2];
+            if ((dcur.vdf >> 24) & 1) {
 #pragma unroll
-            for (int u0 = 0; u0 < kPatSlots; u0 += 4) {
-                if (u0 < ps.nslots) {                                       // wave-uniform
-                    V g[4];
+                for (int w = 0; w < kPatSlots / 2; ++w) {
+                    pcb[w] = 0u;
+                    if (2 * w >= ps.nslots) continue;                       // wave-uniform
+                    const int lo16 = (int)(short)(ps.cb[w] & 0xffffu), hi16 = (int)ps.cb[w] >> 16;
+                    const int plo = pat_slot(dcur.vdf, (lo16 >> 6) & 7) * 64 + (lo16 & 63), phi = pat_slot(dcur.vdf, (hi16 >> 6) & 7) * 64 + (hi16 & 63);
+                    pcb[w] = ((unsigned)plo & 0xffffu) | ((unsigned)phi << 16);
+                }
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int cb = u0 + k < ps.nslots ? pat_offset(ps, u0 + k) : cb0;
-                        if (via_perm) cb = pat_slot(dcur.vdf, cb >> 6) * 64 + (cb & 63);      // wave-uniform: logical page -> LDS slot
-                        int idx = cb + lane;
-                        if (!full) idx = idx < 0 ? 0 : (idx > PG * 64 - 1 ? PG * 64 - 1 : idx);     // lanes without the slot: any valid entry
-                        g[k] = c.sw[idx];
+                for (int w = 0; w < kPatSlots / 2; ++w) pcb[w] = ps.cb[w];
+            }
+            const bool two = (ps.vsel & 0xaaaaaaaau) == 0u;                 // selectors 0 / 1 only
+            auto offset_of = [&](int u) { const unsigned w = pcb[u >> 1]; return (u & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu); };
+            if (full && two) {
+#pragma unroll
+                for (int u = 0; u < kPatSlots; ++u) {
+                    if (u < ps.nslots) {                                    // wave-uniform
+                        const double a = ((ps.vsel >> (2 * u)) & 1u) ? ps.val[1] : ps.val[0];
+                        const V g = c.sw[offset_of(u) + lane];
+                        vacc(sum, vmul(a, g));
                     }
+                }
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (u0 + k < ps.nslots) {                           // wave-uniform
-                            const double a = pat_value(ps, u0 + k);
-                            if (full) vacc(sum, vmul(a, g[k]));
-                            else if ((mk >> (u0 + k)) & 1u) vacc(sum, vmul(a, g[k]));
-                        }
+                for (int u = 0; u < kPatSlots; ++u) {
+                    if (u < ps.nslots) {                                    // wave-uniform
+                        const unsigned sel = (ps.vsel >> (2 * u)) & 3u;
+                        const double a01 = (sel & 1u) ? ps.val[1] : ps.val[0], a23 = (sel & 1u) ? ps.val[3] : ps.val[2];
+                        const double a = (sel & 2u) ? a23 : a01;
+                        int idx = offset_of(u) + lane;
+                        idx = idx < 0 ? 0 : (idx > PG * 64 - 1 ? PG * 64 - 1 : idx);     // lanes without the slot: any valid entry
+                        const V g = c.sw[idx];
+                        if ((mk >> u) & 1u) vacc(sum, vmul(a, g));
                     }
                 }
             }

@@ -1,5 +1,5 @@
 // Sanitizer harness (CPU only): the window planning pipeline of prcg_set_csr -- plan_window_tiles,
-// plan_window_dict, share_window_streams -- behind one C entry point, built with ASan/UBSan by
+// plan_window_dict, share_window_streams, plan_window_patterns, plan_sweep_tiles -- behind one C entry point, built with ASan/UBSan by
 // tools/run_plan_asan.py and driven over every golden matrix and the synthetic operators.
 #include "../new_cg_variants_amd/csrc/prcg_plan.h"
 
@@ -16,6 +16,39 @@ extern "C" int plan_all(long n, long ncols, const int* indptr, const int* indice
                     if (t.voff < 0 || (size_t)t.voff + (size_t)trips * 4 * 128 > sp.val.size() + 0) return -6;
                     if (t.coff < 0 || (size_t)t.coff + (size_t)trips * 2 * 256 > sp.col.size() + 0) return -7;
                 }
+        }
+    }
+    if (rows == 64) {
+        // pattern tiles (plan_window_patterns) on the 64-row / 6-page tiling, and the sweep table (plan_sweep_tiles): every tile's
+        // masks inside the store, every pattern id valid, every slot of a present row inside the tile's pages
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            std::vector<WTile> tl;
+            std::vector<uint16_t> cw;
+            if (sweep) {
+                SweepPlan sw;
+                if (n != ncols || !plan_sweep_tiles(n, ncols, indptr, indices, 6, 512, sw)) continue;
+                tl.swap(sw.tiles); cw.swap(sw.cw);
+            } else {
+                WinPlan wq;
+                plan_window_tiles(n, ncols, indptr, indices, nullptr, 64, 1009, 6, wq);
+                if (!wq.ok0 || !wq.ok1) continue;
+                tl = wq.t0; tl.insert(tl.end(), wq.t1.begin(), wq.t1.end());
+                cw.swap(wq.cw);
+            }
+            std::vector<PatRec> pats;
+            std::vector<uint16_t> masks;
+            if (!plan_window_patterns(tl, indptr, cw.data(), data, pats, masks)) continue;
+            for (const auto& t : tl) {
+                if (t.src_c < 0 || (size_t)t.src_c >= pats.size()) return -8;
+                if (!t.spare && (t.src_r < 0 || (size_t)t.src_r + 64 > masks.size())) return -9;
+                const PatRec& p = pats[(size_t)t.src_c];
+                const int np = t.geo & 255;
+                for (int lane = 0; lane < t.re - t.rb; ++lane) {
+                    const unsigned mk = t.spare ? 0xffffu : masks[(size_t)t.src_r + lane];
+                    for (int u = 0; u < p.nslots; ++u)
+                        if (((mk >> u) & 1u) && (lane + p.cb[u] < 0 || lane + p.cb[u] >= np * 64)) return -10;
+                }
+            }
         }
     }
     WinPlan wp;

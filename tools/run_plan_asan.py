@@ -54,6 +54,9 @@ def main():
     run(problems.laplace_2d(300, 200), 'lap2d')
     run(problems.laplace_3d(40, 40, 40), 'lap3d')
     run(problems.fem_like_3d(12, 3), 'fem')
+    run(problems.laplace_3d(72, 8, 64), 'lap3d sweep')
+    run(problems.laplace_2d(300, 64), 'lap2d sweep')
+    run(problems.banded_ex2b(50000, 7, kappa=1.0), 'band, constant diagonal (pattern operator)')
     print('all clean')
 
 
