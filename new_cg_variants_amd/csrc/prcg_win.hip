@@ -171,15 +171,6 @@ __device__ __forceinline__ void load_pattern(const PatRec* __restrict__ pat, int
 }
 // sweep tables (prcg_plan.h: plan_sweep_tiles): d.vdf = perm (3 bits per logical page: its LDS slot) | carry << 18 | through-perm << 24
 __device__ __forceinline__ int pat_slot(int vdf, int p) { return (vdf >> (3 * p)) & 7; }
-__device__ __forceinline__ int pat_offset(const PatState& ps, int u) {          // u: compile-time after unrolling
-    const unsigned w = ps.cb[u >> 1];
-    return (u & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
-}
-__device__ __forceinline__ double pat_value(const PatState& ps, int u) {
-    const unsigned sel = (ps.vsel >> (2 * u)) & 3u;
-    return sel == 0u ? ps.val[0] : (sel == 1u ? ps.val[1] : (sel == 2u ? ps.val[2] : ps.val[3]));
-}
-
 template <int PG, int M, int RL, int CW>
 __device__ __forceinline__ bool same_image(const RowCache<M, RL, CW>& rc, const WDesc<PG>& d) {
     if constexpr (RL == 0) return false;
@@ -192,7 +183,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                                             const FusedRowPtrs& fr, const FusedPrev::PrOne& pr,
                                             WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R, bool skip_img = false,
                                             const typename VecT<NV>::type* G = nullptr, int n_own = 0,
-                                            const FusedPrev::Lag* lg = nullptr, bool carry_ok = false) {
+                                            const FusedPrev::Lag* lg = nullptr, bool carry_ok = false, bool need_rows = true) {
     constexpr bool FUSED = epi_fused(EPI);
     const int alo = d.lo & ~15;
     // the 1- and 2-byte streams are read from the tile's IMAGE (prcg_plan.h: share_window_streams), which tiles
@@ -296,7 +287,7 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             if constexpr (epi_gv_w(EPI)) { R.rsx[j].x = pr.r[rr]; R.rsx[j].y = pr.s[rr]; }
             if constexpr (EPI == kEpiGVWJ) { R.dd[j] = pr.d[rr]; R.ww[j] = pr.rt[rr]; R.wwt[j] = pr.st[rr]; }
         }
-        if constexpr (FUSED) {
+        if (FUSED && need_rows) {                                           // (a tile whose update is deferred asks for its rows later: phase B)
 #if PRCG_NT_LOADS
             R.xp[j] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(fr.XP) + rr);       // read once per launch
 #else
@@ -390,7 +381,8 @@ template <int NV, int EPI, int M, int PG, int CW, bool VD, int RL, bool STASH = 
 __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRegs<win_nw(NV, EPI), M, PG, CW, VD>& R,
                                          const WDesc<PG>& dcur, bool have_next, const WDesc<PG>& dnext,
                                          double (&acc)[5], const Coefs& cf, RowCache<M, RL, CW>& rc, bool same_cur,
-                                         PatState& ps, double2* stash = nullptr, bool acquire_first = false, int tcur = 0)
+                                         PatState& ps, double2* stash = nullptr, bool acquire_first = false, int tcur = 0,
+                                         bool next_rows = true)
 {
     using V = typename VecT<NV>::type;
     using RV = typename RegV<NV>::type;
@@ -484,7 +476,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         // (deferred form, first tile of this wave that reads ghost rows: consumer side of the hand-off)
         if (acquire_first && !c.px) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         next_same = same_image<PG>(rc, dnext);
-        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own, c.lg, c.carry_ok);
+        issue_loads<NV, EPI, M, PG, CW, VD>(A, dnext, lane, c.X, c.X2, c.fr, c.pr, R, next_same, c.G, c.n_own, c.lg, c.carry_ok, next_rows);
     }
 
     const int last = pad + (dcur.hi - dcur.lo) - 1 > 0 ? pad + (dcur.hi - dcur.lo) - 1 : 0;
@@ -993,7 +985,8 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
         same[i] = false;
         if (t + i * W < tend) {
             d[i] = read_desc<PG>(wt, t + i * W);
-            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg, c.carry_ok);
+            if (t + i * W < safe) issue_loads<NV, EPI, M, PG, CW, VD>(A, d[i], lane, c.X, c.X2, c.fr, c.pr, R[i], false, c.G, c.n_own, c.lg, c.carry_ok,
+                                                                      /* the wave's first DEF tiles are stashed: their rows are asked for in phase B */ DEF == 0);
             else pend[i] = true;
         }
     }
@@ -1014,11 +1007,41 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
             d[0] = dn;
             pend[0] = tnext < tend && !have_next;
             same[0] = win_step<NV, EPI, M, PG, CW, VD, RL, true>(A, c, R[0], dcur, have_next, d[0], acc, cf, rc, same[0], ps,
-                                                                 s_stash[wv] + it * M * 64);
+                                                                 s_stash[wv] + it * M * 64, false, 0, /* next tile fused: */ it + 1 >= DEF);
             if (tnext + W < tend) dn = read_desc<PG>(wt, tnext + W);
             t += W;
             ++n_def;
         }
+        // The deferred rows' operands -- (x,p) and the old input pair of the rows, old vectors all -- are requested for a whole
+        // chunk of tiles at once (one memory round trip per chunk, not per tile), the first chunk BEFORE the wait for the
+        // other ranks' inner products: the round trip and the wait overlap
+        constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : (DEF > 4 ? 4 : DEF);
+        FusedRowIn q[CH][M];
+        double2 io[CH][M];
+        int rbB[CH], reB[CH], sendB[CH];                               // rows of the chunk's tiles (wave-uniform, re-read: scalar loads)
+        auto request_rows = [&](int c0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                rbB[i] = reB[i] = sendB[i] = 0;
+                if (c0 + i < n_def) {
+                    const int ti = t_first + (c0 + i) * W;
+                    const int4 a4 = wt[ti * 6 + 0];
+                    const int geo = wt[ti * 6 + 1].x;
+                    rbB[i] = __builtin_amdgcn_readfirstlane(a4.x); reB[i] = __builtin_amdgcn_readfirstlane(a4.y);
+                    sendB[i] = (__builtin_amdgcn_readfirstlane(geo) >> 30) & 1;
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        const int row = rbB[i] + j * 64 + lane;
+                        const int rr = row < reB[i] ? row : rbB[i];
+                        q[i][j].xp = c.fr.XP[rr];
+                        io[i][j] = c.X[rr];
+                        if constexpr (epi_prec(EPI)) { q[i][j].rs = c.fr.RS[rr]; q[i][j].d = c.fr.D[rr]; }
+                        if constexpr (!epi_recompute(EPI)) { q[i][j].w = c.fr.W[rr]; if constexpr (epi_prec(EPI)) q[i][j].wt = c.fr.WT[rr]; }
+                    }
+                }
+            }
+        };
+        if (n_def > 0) request_rows(0);
         // ---- the communication wave of the peer exchange ----
         if (relay) {
             const PeerDev* px = fz.px;
@@ -1082,34 +1105,10 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_ti
             issue_loads<NV, EPI, M, PG, CW, VD>(A, d[0], lane, c.X, c.X2, c.fr, c.pr, R[0], same[0], c.G, c.n_own, c.lg, c.carry_ok);
             pend[0] = false;
         }
-        // ---- phase B: the deferred updates.  The rows' operands are requested for a whole chunk of tiles
-        //      at once (one memory round trip per chunk, not per tile), then the chunk is updated ----
-        constexpr int CH = (epi_prec(EPI) || !epi_recompute(EPI)) ? (DEF >= 4 ? DEF / 2 : DEF) : (DEF > 4 ? 4 : DEF);
+        // ---- phase B: the deferred updates (the first chunk's operands were requested before the wait) ----
 #pragma unroll 1
         for (int c0 = 0; c0 < n_def; c0 += CH) {
-            FusedRowIn q[CH][M];
-            double2 io[CH][M];
-            int rbB[CH], reB[CH], sendB[CH];                           // rows of the chunk's tiles (wave-uniform, re-read: scalar loads)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                rbB[i] = reB[i] = sendB[i] = 0;
-                if (c0 + i < n_def) {
-                    const int ti = t_first + (c0 + i) * W;
-                    const int4 a4 = wt[ti * 6 + 0];
-                    const int geo = wt[ti * 6 + 1].x;
-                    rbB[i] = __builtin_amdgcn_readfirstlane(a4.x); reB[i] = __builtin_amdgcn_readfirstlane(a4.y);
-                    sendB[i] = (__builtin_amdgcn_readfirstlane(geo) >> 30) & 1;
-#pragma unroll
-                    for (int j = 0; j < M; ++j) {
-                        const int row = rbB[i] + j * 64 + lane;
-                        const int rr = row < reB[i] ? row : rbB[i];
-                        q[i][j].xp = c.fr.XP[rr];
-                        io[i][j] = c.X[rr];
-                        if constexpr (epi_prec(EPI)) { q[i][j].rs = c.fr.RS[rr]; q[i][j].d = c.fr.D[rr]; }
-                        if constexpr (!epi_recompute(EPI)) { q[i][j].w = c.fr.W[rr]; if constexpr (epi_prec(EPI)) q[i][j].wt = c.fr.WT[rr]; }
-                    }
-                }
-            }
+            if (c0 > 0) request_rows(c0);
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 if (c0 + i < n_def) {
