@@ -806,9 +806,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
 // bounded; a timeout sets *err and lets the wave continue (wrong numbers, never a hang).
 // (the deferred dictionary kernels of the 64-row geometries are asked to fit four workgroups per CU -- 128 VGPRs: they
 //  are bound by what one wave can overlap, and a few spilled scalars cost less than a quarter of the resident waves)
-constexpr int win_min_blocks(int m, bool vd, int def) { return (def > 0 && vd && m == 1) ? 4 : 1; }
+constexpr int win_min_blocks(int m, bool vd, int def, int wpb = 4) { return (def > 0 && vd && m == 1 && wpb <= 4) ? 4 : 1; }
 template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH, int DEF = 0>
-__global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF)) void k_win_tiles(
+__global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF, WPB)) void k_win_tiles(
     WinDev A, const int4* __restrict__ wt, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,
@@ -1206,7 +1206,11 @@ inline bool win_big_workgroups(int ntiles, bool vd) {
 // be alone on its CU
 // (64-row geometries whose four-wave workgroup would be alone on its CU -- plain values with eight 2-byte-index pages:
 //  22 KB per wave with the stash -- take two-wave workgroups too: three of them share a CU)
+#ifndef PRCG_DEFER_WPB
+#define PRCG_DEFER_WPB 4
+#endif
 constexpr int wpb_defer(int m, int nv = 2, int pg = 2, int cw = 8, bool vd = true) {
+    if (PRCG_DEFER_WPB > 4 && m == 1 && vd && PRCG_DEFER_WPB * (lds_bytes_per_wave(nv, pg, cw, vd) + 3 * 64 * 16) <= 159 * 1024) return PRCG_DEFER_WPB;
     return (m == 1 && 4 * (lds_bytes_per_wave(nv, pg, cw, vd) + 3 * 64 * 16) <= 80 * 1024) ? 4 : 2;
 }
 
