@@ -251,11 +251,15 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                     // peer exchange: a page of ghost columns lies in this rank's exchange buffer (pages never straddle n_own),
                     // written by OTHER GPUs' stores: system-scope loads, which no cache of this GPU serves -- no acquire
                     // fence (and no invalidation of anybody's cached lines) needed
-                    const double* gp = reinterpret_cast<const double*>(G + d.pc[p] + lane);
+                    // (ONE 16-byte request per lane, sc0 sc1: two 8-byte system-scope atomic loads per lane made the boundary tile the
+                    //  slowest step of the launch)
                     if constexpr (NV == 2) {
-                        R.w[p].x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        R.w[p].y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(G)), 0, 0x7ffffff0, 0x00020000);
+                        const u4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (d.pc[p] + lane) * 16, 0, 17);
+                        R.w[p].x = __hiloint2double((int)raw.y, (int)raw.x);
+                        R.w[p].y = __hiloint2double((int)raw.w, (int)raw.z);
                     } else {
+                        const double* gp = reinterpret_cast<const double*>(G + d.pc[p] + lane);
                         R.w[p] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 } else {

@@ -8,6 +8,7 @@ from new_cg_variants_amd import problems as P, _lib as L, partition
 from new_cg_variants_amd.device import DeviceCSR
 
 knobs = dict(kv.split('=') for kv in sys.argv[1:])
+only = knobs.pop('only', None)        # only=plain | nohalo | halo: just that configuration (for a kernel trace)
 A = P.banded_ex2b(1_250_000, 7); n = A.shape[0]
 b, x0, xt = P.reference_rhs(A, n)
 A_loop, halo, moved = partition.loopback_problem(A, 7)
@@ -28,12 +29,17 @@ def run(name, op, iters=1200):
     op.close()
 
 
-run('plain (no communicator)', DeviceCSR(A, knobs=knobs))
-op = DeviceCSR(A, comm_init=(0, 1, uid(), L.default_rccl_path()), knobs=knobs)
-partition.connect_peer_exchange(op, 0, lambda o: [o])
-run('no halo, peer exchange', op)
-op = DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=knobs)
-partition.connect_peer_exchange(op, 0, lambda o: [o])
-run('loopback halo, peer exchange', op)
-run('loopback halo, RCCL one-launch', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='1')))
-run('loopback halo, RCCL two-kernel', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='0')))
+if only in (None, 'plain'):
+    run('plain (no communicator)', DeviceCSR(A, knobs=knobs))
+if only in (None, 'nohalo'):
+    op = DeviceCSR(A, comm_init=(0, 1, uid(), L.default_rccl_path()), knobs=knobs)
+    partition.connect_peer_exchange(op, 0, lambda o: [o])
+    run('no halo, peer exchange', op)
+if only in (None, 'halo'):
+    op = DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=knobs)
+    partition.connect_peer_exchange(op, 0, lambda o: [o])
+    run('loopback halo, peer exchange', op)
+if only is None:
+    run('loopback halo, RCCL one-launch', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='1')))
+if only is None:
+    run('loopback halo, RCCL two-kernel', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='0')))
