@@ -247,7 +247,11 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
                 if constexpr (EPI == kEpiCGWJ || EPI == kEpiGVWJ) R.w[p].z = pr.d[d.pc[p] + lane];
             }
             else {
+#ifdef PRCG_DEBUG_PLAIN_GHOST
+                if (false) {
+#else
                 if (G != nullptr && d.pc[p] >= n_own) {
+#endif
                     // peer exchange: a page of ghost columns lies in this rank's exchange buffer (pages never straddle n_own),
                     // written by OTHER GPUs' stores: system-scope loads, which no cache of this GPU serves -- no acquire
                     // fence (and no invalidation of anybody's cached lines) needed
@@ -774,7 +778,9 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         }
     }
     if constexpr (FUSED && !STASH) {
+#ifndef PRCG_DEBUG_NO_SEND
         if (c.px && dcur.send) peer_send_rows<M>(c.px, tcur, dcur.rb, newp, c.gout, lane);
+#endif
     }
     wave_lds_sync();     // the next tile's image must not land before every lane has finished reading
     return next_same;
