@@ -9,9 +9,11 @@ OUT := new_cg_variants_amd/libprcg.so
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
 # TEST INFRASTRUCTURE: a stand-in for librccl.so that connects ranks living in threads of one process on one GPU
 TRANSPORT := tests/transport/libthreads_ccl.so
+# ... and one that connects ranks living in separate PROCESSES that share one GPU (the driver's launch shape, rehearsed on one GPU)
+TRANSPORT_P := tests/transport/libprocs_ccl.so
 OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_sell.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
 
-all: $(OUT) $(TRANSPORT)
+all: $(OUT) $(TRANSPORT) $(TRANSPORT_P)
 
 $(CSRC)/prcg_kernels.o: $(CSRC)/prcg_kernels.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
@@ -37,7 +39,10 @@ $(OUT): $(OBJS)
 $(TRANSPORT): tests/transport/threads_ccl.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared $< -o $@
 
+$(TRANSPORT_P): tests/transport/procs_ccl.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -shared $< -o $@ -lrt
+
 clean:
-	rm -f $(OBJS) $(OUT) $(TRANSPORT)
+	rm -f $(OBJS) $(OUT) $(TRANSPORT) $(TRANSPORT_P)
 
 .PHONY: all clean

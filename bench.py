@@ -144,6 +144,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('PRCG_BENCH_DEVICE'):
+        # rehearsal of an N > 1 launch on a box with fewer GPUs than ranks (tests/test_distributed.py, together with
+        # PRCG_RCCL_LIB = a collectives stand-in that accepts ranks sharing a device): every rank on the named device
+        local_rank = int(os.environ['PRCG_BENCH_DEVICE'])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')

@@ -127,6 +127,9 @@ def default_rccl_path():
     brings a second runtime into the process; streams of one handed to the RCCL of the other fail with "unhandled
     cuda error")."""
     lib()
+    if os.environ.get('PRCG_RCCL_LIB'):
+        # a named collectives library instead of RCCL (the tests' stand-ins: tests/transport/lib{threads,procs}_ccl.so)
+        return os.environ['PRCG_RCCL_LIB']
     if _torch_runtime and 'torch' in sys.modules:
         cand = os.path.join(os.path.dirname(sys.modules['torch'].__file__), 'lib', 'librccl.so')
         if os.path.exists(cand):

@@ -757,3 +757,34 @@ def test_sweep_table_operator_in_a_communicator_session():
         a, c = solo.get_scalars(k + 1)[:5], plain.get_scalars(k + 1)[:5]
         assert np.max(np.abs(a - c) / np.abs(c)) <= 1e-12
     plain.close(); solo.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,workload', [(2, 's3_8th'), (3, 's2_8th'), (4, 's3')])
+def test_bench_launched_as_the_driver_does_with_processes_sharing_the_gpu(world, workload):
+    """The driver's N > 1 launch, rehearsed on ONE GPU: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`,
+    one PROCESS per rank, gloo control plane, every rank on device 0 (PRCG_BENCH_DEVICE) and the collectives of the set-up
+    through tests/transport/libprocs_ccl.so (PRCG_RCCL_LIB; RCCL refuses ranks that share a device).  What runs is the
+    product's N > 1 path end to end: row blocks, halo plan over gloo, exchange buffers mapped ACROSS PROCESSES with hipIpc,
+    the self-check of the one-launch schedule against the two-kernel schedule, the timed loop in which every rank's
+    launches wait in-kernel for the other processes' launches, max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    env = dict(os.environ)
+    env.update({'MASTER_ADDR': '127.0.0.1', 'OMP_NUM_THREADS': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'PRCG_BENCH_DEVICE': '0',
+                'PRCG_RCCL_LIB': os.path.join(ROOT, 'tests', 'transport', 'libprocs_ccl.so'),
+                # ranks that SHARE a GPU: one workgroup per CU each, or a rank's persistent launch keeps the others' out
+                'PRCG_DEFER_GRID_PER_CU': '1'})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '60', '--warmup', '10',
+           '--workload', workload, '--no-cpu-baseline']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    s = d['config']['schedule']
+    print(f"{world} processes on one GPU, {workload}: {d['value']:.0f} it/s, schedule {s}, fallback {d['config']['schedule_fallback']}")
+    assert d['n_gpus'] == world and d['steps'] == 60 and d['scaling'] == 'strong'
+    assert d['config']['schedule_fallback'] is None, d['config']['schedule_fallback']
+    assert s['peer'] and s['fused_comm'] and s['window'] and d['config']['residual_finite'], s
+    assert d['value'] > 1        # (processes time-share the GPU while their launches wait for each other: no performance figure)
