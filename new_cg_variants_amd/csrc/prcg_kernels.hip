@@ -469,19 +469,36 @@ __global__ __launch_bounds__(kBlock) void k_hs_update_xr(HsArgs a, int trips, co
     double acc[2] = {0.0, 0.0};   // nu, rr
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
     for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t ie = i + e;
-            if (ie >= a.n) break;
-            double rn = a.r[ie];
+        if (i + 1 < a.n) {
+            // the thread's two elements as 16-byte loads and stores (same expressions, same order of the sums: element i, then i + 1)
+            double2 rn = *reinterpret_cast<const double2*>(a.r + i);
             if constexpr (!DOTS_ONLY) {
-                a.x[ie] = a.x[ie] + al * a.p[ie];
-                rn = rn - al * a.s[ie];
-                a.r[ie] = rn;
+                const double2 x2 = *reinterpret_cast<const double2*>(a.x + i), p2 = *reinterpret_cast<const double2*>(a.p + i);
+                const double2 s2 = *reinterpret_cast<const double2*>(a.s + i);
+                *reinterpret_cast<double2*>(a.x + i) = make_double2(x2.x + al * p2.x, x2.y + al * p2.y);
+                rn = make_double2(rn.x - al * s2.x, rn.y - al * s2.y);
+                *reinterpret_cast<double2*>(a.r + i) = rn;
             }
             if constexpr (PREC) {
-                const double z = a.d[ie] * rn;                  // r~ = M^-1 r
-                a.rt[ie] = z;
+                const double2 d2 = *reinterpret_cast<const double2*>(a.d + i);
+                const double2 z = make_double2(d2.x * rn.x, d2.y * rn.y);      // r~ = M^-1 r
+                *reinterpret_cast<double2*>(a.rt + i) = z;
+                acc[0] += rn.x * z.x; acc[1] += rn.x * rn.x;
+                acc[0] += rn.y * z.y; acc[1] += rn.y * rn.y;
+            } else {
+                acc[0] += rn.x * rn.x;
+                acc[0] += rn.y * rn.y;
+            }
+        } else if (i < a.n) {
+            double rn = a.r[i];
+            if constexpr (!DOTS_ONLY) {
+                a.x[i] = a.x[i] + al * a.p[i];
+                rn = rn - al * a.s[i];
+                a.r[i] = rn;
+            }
+            if constexpr (PREC) {
+                const double z = a.d[i] * rn;
+                a.rt[i] = z;
                 acc[0] += rn * z; acc[1] += rn * rn;
             } else {
                 acc[0] += rn * rn;
