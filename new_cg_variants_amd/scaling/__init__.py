@@ -92,7 +92,8 @@ class RowBlockOperator:
         lo, hi = int(self.offsets[rank]), int(self.offsets[rank + 1])
         self.n_local, self.n = n_local, n
         if device is None:
-            device = int(os.environ.get('LOCAL_RANK', '0'))
+            # (PRCG_BENCH_DEVICE: every rank on one named device -- rehearsals of an N > 1 launch on fewer GPUs, see bench.py)
+            device = int(os.environ.get('PRCG_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
         self.device = device
         comm_init = None
         halo = None

@@ -788,3 +788,32 @@ def test_bench_launched_as_the_driver_does_with_processes_sharing_the_gpu(world,
     assert d['config']['schedule_fallback'] is None, d['config']['schedule_fallback']
     assert s['peer'] and s['fused_comm'] and s['window'] and d['config']['residual_finite'], s
     assert d['value'] > 1        # (processes time-share the GPU while their launches wait for each other: no performance figure)
+
+
+@pytest.mark.gpu
+def test_scaling_tests_driver_with_processes_sharing_the_gpu(tmp_path):
+    """The mpi4py experiment's drop-in driver (experiments/scaling_tests.py; scaling_experiments_mpi4py/scaling_tests.py) launched
+    with one PROCESS per rank, two ranks on one GPU through the process stand-in for RCCL: the five variants print their error
+    lines and save the reference's result files; the errors agree with a single-process run of the same iteration count to the
+    reordering of the inner products."""
+    env = dict(os.environ)
+    env.update({'MASTER_ADDR': '127.0.0.1', 'OMP_NUM_THREADS': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'PRCG_BENCH_DEVICE': '0',
+                'PRCG_RCCL_LIB': os.path.join(ROOT, 'tests', 'transport', 'libprocs_ccl.so'), 'PRCG_DEFER_GRID_PER_CU': '1',
+                'PYTHONPATH': ROOT + os.pathsep + env.get('PYTHONPATH', '')})
+    out = {}
+    for world in (1, 2):
+        cwd = tmp_path / f'w{world}'
+        cwd.mkdir()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), '-m', 'new_cg_variants_amd.experiments.scaling_tests', '12288', '400', f'procs{world}']
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=str(cwd))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        errs = {ln.split(' error: ')[0]: float(ln.split(' error: ')[1]) for ln in p.stdout.splitlines() if ' error: ' in ln}
+        assert set(errs) == {'hs_cg', 'cg_cg', 'gv_cg', 'pr_cg', 'pipe_pr_cg'}, p.stdout[-1500:]
+        for v in errs:
+            res = np.load(cwd / 'data' / '12288' / f'{v}_procs{world}.npy', allow_pickle=True).item()
+            assert res['error'] == errs[v] and res['timings']['tot'] > 0
+        out[world] = errs
+    print(out)
+    for v in out[1]:
+        assert np.isfinite(out[2][v]) and 0.2 <= out[2][v] / out[1][v] <= 5.0, (v, out[1][v], out[2][v])
