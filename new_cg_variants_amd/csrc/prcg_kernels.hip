@@ -525,11 +525,11 @@ __global__ __launch_bounds__(kBlock) void k_hs_update_p(HsArgs a, int trips, con
     const double* __restrict__ z = a.rt ? a.rt : a.r;
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
     for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t ie = i + e;
-            if (ie >= a.n) break;
-            a.p[ie] = z[ie] + bt * a.p[ie];                     // p = r~ + b p
+        if (i + 1 < a.n) {                                      // the thread's two elements as 16-byte loads and stores
+            const double2 z2 = *reinterpret_cast<const double2*>(z + i), p2 = *reinterpret_cast<const double2*>(a.p + i);
+            *reinterpret_cast<double2*>(a.p + i) = make_double2(z2.x + bt * p2.x, z2.y + bt * p2.y);     // p = r~ + b p
+        } else if (i < a.n) {
+            a.p[i] = z[i] + bt * a.p[i];
         }
     }
 }
@@ -547,23 +547,42 @@ __global__ __launch_bounds__(kBlock) void k_pr_update(PrArgs a, int trips) {
     double acc[2] = {0.0, 0.0};   // nu = r~.r, rr
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
     for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t ie = i + e;
-            if (ie >= a.n) break;
-            double rn = a.r[ie];
-            double rtn = PREC ? a.rt[ie] : rn;
+        if (i + 1 < a.n) {
+            // the thread's two elements as 16-byte loads and stores (same expressions, sums in the order element i, then i + 1)
+            double2 rn = *reinterpret_cast<const double2*>(a.r + i);
+            double2 rtn = rn;
+            if constexpr (PREC) rtn = *reinterpret_cast<const double2*>(a.rt + i);
             if constexpr (!DOTS_ONLY) {
-                a.x[ie] = a.x[ie] + c.al * a.p[ie];
-                rn = rn - c.al * a.s[ie];
-                a.r[ie] = rn;
+                const double2 x2 = *reinterpret_cast<const double2*>(a.x + i), p2 = *reinterpret_cast<const double2*>(a.p + i);
+                const double2 s2 = *reinterpret_cast<const double2*>(a.s + i);
+                *reinterpret_cast<double2*>(a.x + i) = make_double2(x2.x + c.al * p2.x, x2.y + c.al * p2.y);
+                rn = make_double2(rn.x - c.al * s2.x, rn.y - c.al * s2.y);
+                *reinterpret_cast<double2*>(a.r + i) = rn;
                 if constexpr (PREC) {
-                    rtn = rtn - c.al * a.st_[ie];
-                    a.rt[ie] = rtn;
+                    const double2 st2 = *reinterpret_cast<const double2*>(a.st_ + i);
+                    rtn = make_double2(rtn.x - c.al * st2.x, rtn.y - c.al * st2.y);
+                    *reinterpret_cast<double2*>(a.rt + i) = rtn;
                 } else {
                     rtn = rn;
                 }
-                a.p[ie] = rtn + c.bt * a.p[ie];
+                *reinterpret_cast<double2*>(a.p + i) = make_double2(rtn.x + c.bt * p2.x, rtn.y + c.bt * p2.y);
+            }
+            acc[0] += rtn.x * rn.x; acc[1] += rn.x * rn.x;
+            acc[0] += rtn.y * rn.y; acc[1] += rn.y * rn.y;
+        } else if (i < a.n) {
+            double rn = a.r[i];
+            double rtn = PREC ? a.rt[i] : rn;
+            if constexpr (!DOTS_ONLY) {
+                a.x[i] = a.x[i] + c.al * a.p[i];
+                rn = rn - c.al * a.s[i];
+                a.r[i] = rn;
+                if constexpr (PREC) {
+                    rtn = rtn - c.al * a.st_[i];
+                    a.rt[i] = rtn;
+                } else {
+                    rtn = rn;
+                }
+                a.p[i] = rtn + c.bt * a.p[i];
             }
             acc[0] += rtn * rn; acc[1] += rn * rn;
         }
@@ -593,15 +612,21 @@ __global__ __launch_bounds__(kBlock) void k_cg_update_ps(CgArgs a, int trips, co
     }
     const double* __restrict__ z = a.z;
     int64_t i = ((int64_t)blockIdx.x * trips) * kElemsPerTrip + threadIdx.x * 2;
+    auto axpby2 = [bt](double* __restrict__ y, const double* __restrict__ x, int64_t at) {      // y = x + b y on two elements, 16 bytes each way
+        const double2 x2 = *reinterpret_cast<const double2*>(x + at), y2 = *reinterpret_cast<const double2*>(y + at);
+        *reinterpret_cast<double2*>(y + at) = make_double2(x2.x + bt * y2.x, x2.y + bt * y2.y);
+    };
     for (int j = 0; j < trips; ++j, i += kElemsPerTrip) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t ie = i + e;
-            if (ie >= a.n) break;
-            a.p[ie] = z[ie] + bt * a.p[ie];                     // p = r~ + b p
-            a.s[ie] = a.w[ie] + bt * a.s[ie];                   // s = w + b s
-            if (a.st_) a.st_[ie] = a.wt[ie] + bt * a.st_[ie];   // s~ = w~ + b s~   (gv_pcg)
-            if (a.u) a.u[ie] = a.t[ie] + bt * a.u[ie];          // u = t + b u      (gv)
+        if (i + 1 < a.n) {
+            axpby2(a.p, z, i);                                  // p = r~ + b p
+            axpby2(a.s, a.w, i);                                // s = w + b s
+            if (a.st_) axpby2(a.st_, a.wt, i);                  // s~ = w~ + b s~   (gv_pcg)
+            if (a.u) axpby2(a.u, a.t, i);                       // u = t + b u      (gv)
+        } else if (i < a.n) {
+            a.p[i] = z[i] + bt * a.p[i];
+            a.s[i] = a.w[i] + bt * a.s[i];
+            if (a.st_) a.st_[i] = a.wt[i] + bt * a.st_[i];
+            if (a.u) a.u[i] = a.t[i] + bt * a.u[i];
         }
     }
 }
