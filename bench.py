@@ -169,6 +169,10 @@ def main():
         comm = scaling.SelfComm()
 
     K, W = args.steps, args.warmup
+    K_MAIN = K
+    # the extra legs (short launches: one eighth of S3 / S2, S1, the multi-rank schedule) are timed over at least 200 steps:
+    # 20 steps of a 25 us launch are 0.5 ms, of which the barriers and the event records around them are several per cent
+    K_LEG = max(K, 200)
     VAR = {'pipe_pr_cg': L.PIPE_PR, 'hs_cg': L.HS, 'pr_cg': L.PR, 'pipe_pr_pcg': L.PIPE_PR, 'pipe_p_cg': L.PIPE_P,
            'cg_cg': L.CG_CG, 'gv_cg': L.GV}
 
@@ -182,10 +186,11 @@ def main():
             partition.connect_peer_exchange(d, 0, lambda obj: [obj])
         return d
 
-    def timed_run(dev, variant, b, x0, inv_diag=None):
+    def timed_run(dev, variant, b, x0, inv_diag=None, K=None):
         """(elapsed, host enqueue time, kernel timings, residual finite, error).  A library error (a one-launch
         iteration of a communicator session that waited longer than its bound for the reduction) is RETURNED, not
         raised: every rank must reach the barriers below, and the decision what to do next is taken collectively."""
+        K = K_MAIN if K is None else K
         err = None
         try:
             dev.begin(variant, b, x0, PREWARM + W + K + 1, inv_diag=inv_diag)
@@ -256,8 +261,9 @@ def main():
                                                          ' iteration, deferred p, s update (k_win_tiles<1,' + ('CGOne' if vname == 'cg_cg' else 'GVOne') + '>)')
         return spmv_bytes(n, nnz), 'SpMV launch (' + ('k_win_tiles<1>' if sched['window'] else 'k_spmv_tiles<1>') + ')'
 
-    def summarize(vname, dev, elapsed, tim, finite, n, nnz):
+    def summarize(vname, dev, elapsed, tim, finite, n, nnz, K=None):
         """value + launch time + must-move bytes + fractions of one timed run on one GPU"""
+        K = K_LEG if K is None else K
         sched = dev.schedule()
         kb, kname = launch_bytes(vname, sched, n, nnz)
         opb = dev.operator_bytes()
@@ -341,20 +347,20 @@ def main():
     if world == 1 and not args.force_comm and not args.no_multi_rank_leg and args.variant.startswith('pipe_'):
         def comm_leg(A, halo, bb, xx0, dd, knobs=None):
             d3 = one_rank_comm_device(A, halo, knobs)
-            e3, q3, tim3, fin3, err3 = timed_run(d3, variant, bb, xx0, dd)
+            e3, q3, tim3, fin3, err3 = timed_run(d3, variant, bb, xx0, dd, K_LEG)
             if err3:
                 d3.close()
                 raise RuntimeError(err3)
             s3 = d3.schedule()
             out = {'one_launch': s3['fused_comm'], 'merged_exchange': s3['gather'], 'peer_stores': s3.get('peer', False),
-                   'value': K / e3, 'unit': 'iters/s', 'us_per_iteration': e3 / K * 1e6,
+                   'value': K_LEG / e3, 'unit': 'iters/s', 'us_per_iteration': e3 / K_LEG * 1e6, 'steps': K_LEG,
                    'launch_us': tim3['spmv_ms'] * 1e3, 'update_us': tim3['update_ms'] * 1e3, 'residual_finite': fin3,
-                   'host_enqueue_us_per_step': q3 / K * 1e6}
+                   'host_enqueue_us_per_step': q3 / K_LEG * 1e6}
             d3.close()
             return out
         try:
             multi = {'what': 'the schedule every rank of an N>1 run executes, timed on this one GPU with a 1-rank communicator '
-                             '(same steps and warm-up as the headline)'}
+                             '(at least 200 timed steps)'}
             multi['s3'] = comm_leg(A_rows.tocsr(), None, b, x0, inv_diag)
             # compatibility with earlier rounds' records
             multi.update({k: multi['s3'][k] for k in ('one_launch', 'value', 'unit', 'host_enqueue_us_per_step')})
@@ -366,7 +372,7 @@ def main():
                 d8 = (1.0 / A8.diagonal()) if inv_diag is not None else None
                 A8_loop, halo8, _ = partition.loopback_problem(A8, 7)       # 14 ghost rows: what a rank of the band receives
                 dp = DeviceCSR(A8, device=local_rank)
-                ep, qp, timp, finp, _ = timed_run(dp, variant, b8, x8, d8)
+                ep, qp, timp, finp, _ = timed_run(dp, variant, b8, x8, d8, K_LEG)
                 dp.close()
                 leg = comm_leg(A8_loop, halo8, b8, x8, d8)
                 try:       # the RCCL schedule of the same slice, for comparison (update kernel + SpMM, all-gather on the communication stream)
@@ -377,7 +383,7 @@ def main():
                                            'multi-rank schedule with a loopback halo (7 ghost rows per side, boundary tiles, the whole '
                                            'exchange: rows and partial sums stored into the exchange buffer by the launch itself, '
                                            'next launch waits in-kernel); a real 8-rank exchange adds xGMI latency to the second',
-                                   'plain_us_per_iteration': ep / K * 1e6, 'plain_host_enqueue_us_per_step': qp / K * 1e6,
+                                   'plain_us_per_iteration': ep / K_LEG * 1e6, 'plain_host_enqueue_us_per_step': qp / K_LEG * 1e6,
                                    'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg, 'rccl_schedule': rccl_leg,
                                    'single_gpu_us_per_iteration': elapsed / K * 1e6,
                                    'speedup_ceiling_at_8_ranks': (elapsed / K * 1e6) / leg['us_per_iteration'] if leg['us_per_iteration'] > 0 else None}
@@ -402,10 +408,10 @@ def main():
                     if key == 'plain_values' and plain is None:
                         continue
                     dp = DeviceCSR(A2, device=local_rank, knobs=kn)
-                    ep, _, _, _, _ = timed_run(dp, variant, b2, x2, d2)
+                    ep, _, _, _, _ = timed_run(dp, variant, b2, x2, d2, K_LEG)
                     dp.close()
                     leg2 = comm_leg(A2_loop, halo2, b2, x2, d2, kn)
-                    r2 = {'plain_us_per_iteration': ep / K * 1e6, 'comm_us_per_iteration': leg2['us_per_iteration'], 'comm': leg2}
+                    r2 = {'plain_us_per_iteration': ep / K_LEG * 1e6, 'comm_us_per_iteration': leg2['us_per_iteration'], 'comm': leg2}
                     if key == 'dict':
                         rec2.update(r2)
                     else:
@@ -427,7 +433,7 @@ def main():
                 A2 = w2['make']()
                 b2, x2, _ = problems.reference_rhs(A2, w2['n'])
                 d2 = DeviceCSR(A2, device=local_rank)
-                e, _, tm, fin, er = timed_run(d2, variant, b2, x2)
+                e, _, tm, fin, er = timed_run(d2, variant, b2, x2, None, K_LEG)
                 if er:
                     raise RuntimeError(er)
                 rec = dict(summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz)), config=cfg, workload=w2['desc'],
@@ -437,7 +443,7 @@ def main():
                 d2.close()
                 if has_dict:
                     d2 = DeviceCSR(A2, device=local_rank, knobs={'PRCG_VALDICT': '0'})
-                    e, _, tm, fin, er = timed_run(d2, variant, b2, x2)
+                    e, _, tm, fin, er = timed_run(d2, variant, b2, x2, None, K_LEG)
                     if not er:
                         rec['plain_values'] = summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz))
                     d2.close()
