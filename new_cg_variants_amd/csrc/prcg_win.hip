@@ -108,6 +108,13 @@ constexpr int win_nw(int nv, int epi) {
     return (epi == kEpiHS || epi == kEpiCGW || epi == kEpiGVW) ? 2
          : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ || epi == kEpiCGOne || epi == kEpiGVOne) ? 3 : (epi == kEpiCGOneJ ? 4 : nv));
 }
+// The one-launch pr / cg / gv kernels need the RAW window triple of the lane's own row beside the formed window entry; the
+// row lies inside the tile's pages, which the wave holds raw in registers when it parks them: a cross-lane read instead of
+// three more 8-byte loads per row (these kernels are bound by the number of vector-memory instructions)
+#ifndef PRCG_ROW_FROM_PAGES
+#define PRCG_ROW_FROM_PAGES 1
+#endif
+constexpr bool row_from_pages(int epi, int m, int pg) { return PRCG_ROW_FROM_PAGES && (epi_pr_one(epi) || epi_lag(epi)) && m == 1 && pg <= 4; }
 template <int NV, int M, int PG, int CW, bool VD>
 struct WRegs {
     d2_t v[VD ? 1 : kWinSlots / 128];   // plain values: nonzeros alo + st*128 + lane*2 .. +2
@@ -282,13 +289,13 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             R.e[j] = A.rel[d.srcr + jj + 1];
         }
         if constexpr (epi_lag(EPI)) {
-            R.zrow[j].x = lg->z0[rr]; R.zrow[j].y = lg->z1[rr]; R.zrow[j].z = lg->z2[rr];
+            if constexpr (!row_from_pages(EPI, M, PG)) { R.zrow[j].x = lg->z0[rr]; R.zrow[j].y = lg->z1[rr]; R.zrow[j].z = lg->z2[rr]; }
             R.xp[j].x = lg->x[rr]; R.xp[j].y = lg->p[rr];
             if constexpr (EPI == kEpiCGOneJ) R.dd[j] = lg->d[rr];
             if constexpr (EPI == kEpiGVOne) { R.rsx[j].x = lg->r[rr]; R.rsx[j].y = lg->s[rr]; }
         }
         if constexpr (epi_rowset(EPI)) {
-            R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr];
+            if constexpr (!row_from_pages(EPI, M, PG)) { R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr]; }
             R.xp[j].x = pr.x[rr];
             if constexpr (EPI == kEpiPROneJ) { R.rsx[j].x = pr.r[rr]; R.rsx[j].y = pr.s[rr]; R.dd[j] = pr.d[rr]; }
             if constexpr (EPI == kEpiCGWJ) R.dd[j] = pr.d[rr];
@@ -445,17 +452,31 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     int rs_[M], re_[M];
     FusedRowIn fin[M];
     d3_t zr[M];
+    if constexpr (row_from_pages(EPI, M, PG)) {
+        // row rb + lane sits at window index own + lane: lane (own + lane) % 64 of page (own + lane) / 64 holds its raw triple
+        const int p0 = dcur.own >> 6, src = (dcur.own + lane) & 63;
+        const bool second = ((dcur.own & 63) + lane) >= 64;
+        d3_t a = {0.0, 0.0, 0.0}, b = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < PG; ++p) {
+            if (p == p0) { a.x = R.w[p].x; a.y = R.w[p].y; a.z = R.w[p].z; }          // wave-uniform
+            if (p == p0 + 1) { b.x = R.w[p].x; b.y = R.w[p].y; b.z = R.w[p].z; }
+        }
+        const double ax = __shfl(a.x, src, 64), ay = __shfl(a.y, src, 64), az = __shfl(a.z, src, 64);
+        const double bx = __shfl(b.x, src, 64), by = __shfl(b.y, src, 64), bz = __shfl(b.z, src, 64);
+        zr[0].x = second ? bx : ax; zr[0].y = second ? by : ay; zr[0].z = second ? bz : az;
+    }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         rs_[j] = R.s[j]; re_[j] = R.e[j];
         if constexpr (epi_lag(EPI)) {
-            zr[j] = R.zrow[j];
+            if constexpr (!row_from_pages(EPI, M, PG)) zr[j] = R.zrow[j];
             fin[j].xp = make_double2(R.xp[j].x, R.xp[j].y);
             if constexpr (EPI == kEpiCGOneJ) fin[j].d = R.dd[j];
             if constexpr (EPI == kEpiGVOne) fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y);
         }
         if constexpr (epi_rowset(EPI)) {
-            zr[j] = R.zrow[j];
+            if constexpr (!row_from_pages(EPI, M, PG)) zr[j] = R.zrow[j];
             fin[j].xp.x = R.xp[j].x;
             if constexpr (EPI == kEpiPROneJ) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
             if constexpr (EPI == kEpiCGWJ) fin[j].d = R.dd[j];
