@@ -24,7 +24,7 @@ $(CSRC)/prcg_win.o: $(CSRC)/prcg_win.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_dev
 $(CSRC)/prcg_sell.o: $(CSRC)/prcg_sell.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
-$(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h
+$(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h include/prcg_test.h
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_plan.o: $(CSRC)/prcg_plan.cpp $(CSRC)/prcg_plan.h

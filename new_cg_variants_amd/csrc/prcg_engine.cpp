@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/prcg.h"
+#include "../../include/prcg_test.h"
 #include "prcg_kernels.h"
 #include "prcg_plan.h"
 #include "prcg_rccl.h"
@@ -139,7 +140,12 @@ struct prcg_handle {
     bool sell = false;
     int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
-    DevBuf sval, scol, sslices;
+    DevBuf sval, scol, sslices, srows;
+    int sell_sigma_opt = 0;              // PRCG_SELL_SIGMA: sorting window of the sliced layout in rows (0: chosen by the planner)
+    int sell_planes_opt = 8;             // PRCG_SELL_PLANES: grid planes interleaved in the slice table (<= 1: row order)
+    int sell_nt = 0;                     // PRCG_SELL_NT=1: the value / column streams are read with nontemporal loads
+    int sell_sigma = 0, sell_planes = 0; // what the planner chose (prcg_schedule_info)
+    int64_t sell_stride = 0;
     bool want_big = true;                // PRCG_WIN_BIG=0: short launches keep the small workgroups too
     int win_order = 0;                   // 1: XCD-chunked tile order of the window launches (opt-in: PRCG_WIN_ORDER=1)
     int win_order_override = -1;
@@ -260,7 +266,7 @@ struct prcg_handle {
                       win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
-    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p)}; }
+    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt}; }
     const double* val_sell() const { return static_cast<const double*>(sval.p); }
     const void* sslice_ptr(int first = 0) const { return static_cast<const char*>(sslices.p) + (size_t)first * 32; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -1254,6 +1260,9 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_WIN_SWEEP") h->want_sweep = (v >= 0 && v <= 2) ? (int)v : 1;
     else if (k == "PRCG_SWEEP_WAVES") h->sweep_max_waves = (v >= 64 && v <= 16384) ? (int)v : 6144;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
+    else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
+    else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 8;
+    else if (k == "PRCG_SELL_NT") h->sell_nt = v != 0;
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
@@ -1267,7 +1276,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1594,8 +1603,12 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     SellPlan sp;
     // (rows of 24 nonzeros and more: shorter rows that are no window operator keep the CSR-adaptive kernels with their
     //  narrow column / value encodings -- a lane per row pays once a row is a sizeable share of a tile)
-    if (!h->win && h->want_sell && n_rows >= 64 && nnz >= 24 * n_rows)
-        h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, 1.25, sp);
+    if (!h->win && h->want_sell && n_rows >= 64 && nnz >= 24 * n_rows) {
+        SellOptions so;
+        so.sigma = h->sell_sigma_opt;
+        so.planes = h->sell_planes_opt;
+        h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, so, sp);
+    }
     const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels
 
     // --- 16-bit tile-relative column encoding (host, once) ---
@@ -1733,7 +1746,10 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         HIPCHK(h, hipMemcpy(h->scol.p, sp.col.data(), sp.col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIPCHK(h, h->sslices.alloc((sall.size() + 1) * sizeof(SellSlice)));
         if (!sall.empty()) HIPCHK(h, hipMemcpy(h->sslices.p, sall.data(), sall.size() * sizeof(SellSlice), hipMemcpyHostToDevice));
-        h->sell_bytes = sp.padded_nnz * 10 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1);
+        HIPCHK(h, h->srows.alloc((sp.rows.size() + 64) * sizeof(int32_t)));
+        if (!sp.rows.empty()) HIPCHK(h, hipMemcpy(h->srows.p, sp.rows.data(), sp.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->sell_bytes = sp.padded_nnz * 10 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4;
+        h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows;
         sp = SellPlan{};
     }
     h->peer_ok = false;
@@ -2726,19 +2742,26 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
 }
 
 int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-                       double max_overhead, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
-                       int64_t array_capacity, int64_t* stats) {
+                       double max_overhead, int sigma, int planes, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
+                       int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity, int64_t* stats) {
     if (n < 0 || !indptr || (indptr[n] > 0 && (!indices || !data)) || (!slices_out && capacity > 0)) return -1;
     SellPlan sp;
-    if (!plan_sell(n, indptr, indices, data, row_class, max_overhead, sp)) return 0;
+    SellOptions so;
+    so.max_overhead = max_overhead; so.sigma = sigma; so.planes = planes;
+    if (!plan_sell(n, indptr, indices, data, row_class, so, sp)) return 0;
     const int64_t total = (int64_t)sp.s0.size() + (int64_t)sp.s1.size();
-    if (stats) { stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz; }
-    if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity)) return -total;
+    if (stats) {
+        stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz;
+        stats[4] = sp.sigma; stats[5] = sp.stride_rows; stats[6] = sp.planes; stats[7] = (int64_t)sp.rows.size();
+    }
+    if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity) ||
+        (rows_out && (int64_t)sp.rows.size() > rows_capacity)) return -total;
     int64_t o = 0;
     for (const auto* v : {&sp.s0, &sp.s1})
         for (const auto& t : *v) { memcpy(slices_out + 8 * o, &t, 8 * sizeof(int32_t)); ++o; }
     if (val_out) memcpy(val_out, sp.val.data(), sp.val.size() * sizeof(double));
     if (col_out) memcpy(col_out, sp.col.data(), sp.col.size() * sizeof(uint16_t));
+    if (rows_out && !sp.rows.empty()) memcpy(rows_out, sp.rows.data(), sp.rows.size() * sizeof(int32_t));
     return total;
 }
 

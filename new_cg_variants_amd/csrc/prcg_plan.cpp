@@ -635,35 +635,140 @@ template StreamStats share_window_streams<uint8_t>(std::vector<WTile>&, const in
 template StreamStats share_window_streams<uint16_t>(std::vector<WTile>&, const int32_t*, const uint16_t*, const uint8_t*, bool,
                                                     std::vector<uint16_t>&, std::vector<uint8_t>&, std::vector<uint16_t>&);
 
+namespace {
+
+// rows of one class run [a, b) in slice order for a sorting window of `sigma` rows: windows of sigma consecutive rows,
+// inside a window the rows by descending length (stable: rows of equal length keep their order, so an operator whose
+// rows all have the window's length keeps consecutive rows); sigma <= 64: no sorting
+void sell_run_order(const int32_t* indptr, int64_t a, int64_t b, int sigma, std::vector<int32_t>& perm) {
+    const size_t first = perm.size();
+    for (int64_t r = a; r < b; ++r) perm.push_back((int32_t)r);
+    if (sigma <= 64) return;
+    for (int64_t w = a; w < b; w += sigma) {
+        int32_t* lo = perm.data() + first + (w - a);
+        int32_t* hi = perm.data() + first + (std::min<int64_t>(w + sigma, b) - a);
+        std::stable_sort(lo, hi, [&](int32_t x, int32_t y) { return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y]; });
+    }
+}
+
+// padded nonzeros of the sliced layout for a sorting window of sigma rows
+int64_t sell_padded(int64_t n, const int32_t* indptr, const uint8_t* row_class, int sigma) {
+    int64_t tot = 0, r = 0;
+    std::vector<int32_t> perm;
+    while (r < n) {
+        int64_t e = r + 1;
+        if (row_class) { while (e < n && (row_class[e] != 0) == (row_class[r] != 0)) ++e; } else e = n;
+        perm.clear();
+        sell_run_order(indptr, r, e, sigma, perm);
+        for (size_t i = 0; i < perm.size(); i += 64) {
+            int w = 0;
+            for (size_t j = i; j < std::min(perm.size(), i + 64); ++j) w = std::max(w, indptr[perm[j] + 1] - indptr[perm[j]]);
+            tot += (int64_t)((w + 1) & ~1) * 64;
+        }
+        r = e;
+    }
+    return tot;
+}
+
+// The dominant FAR column offset of the operator, in rows: a 3-D discretisation in natural ordering couples row r to rows
+// r +- (one grid plane); 0 if no offset beyond 1024 rows carries a sizeable share of the nonzeros.  (Sampled.)
+int64_t sell_far_stride(int64_t n, const int32_t* indptr, const int32_t* indices) {
+    if (n < 16384) return 0;
+    const int64_t bins = (n + 63) / 64 + 1;
+    std::vector<int64_t> cnt((size_t)bins, 0);
+    int64_t sampled = 0;
+    const int64_t step = std::max<int64_t>(1, n / 20000);
+    for (int64_t r = 0; r < n; r += step)
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int64_t c = indices[q];
+            if (c >= n) continue;                                  // ghost columns: numbered behind the owned ones
+            const int64_t d = c > r ? c - r : r - c;
+            ++cnt[(size_t)(d >> 6)];
+            ++sampled;
+        }
+    if (sampled == 0) return 0;
+    // smoothed over +-6 bins (the plane's own line neighbours spread the peak), offsets of 1024 rows and more
+    int64_t best = 0, best_bin = -1;
+    for (int64_t k = 16; k < bins; ++k) {
+        int64_t s = 0;
+        for (int64_t j = std::max<int64_t>(16, k - 6); j <= std::min(bins - 1, k + 6); ++j) s += cnt[(size_t)j];
+        if (s > best) { best = s; best_bin = k; }
+    }
+    if (best_bin < 0 || best * 100 < sampled * 15) return 0;
+    // centre of mass of the peak, from the sampled offsets themselves
+    double num = 0.0, den = 0.0;
+    for (int64_t r = 0; r < n; r += step)
+        for (int32_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int64_t c = indices[q];
+            if (c >= n) continue;
+            const int64_t d = c > r ? c - r : r - c;
+            const int64_t k = d >> 6;
+            if (k >= best_bin - 6 && k <= best_bin + 6) { num += (double)d; den += 1.0; }
+        }
+    return den > 0.0 ? (int64_t)(num / den + 0.5) : 0;
+}
+
+}  // namespace
+
 bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-               double max_overhead, SellPlan& out) {
-    out.s0.clear(); out.s1.clear(); out.val.clear(); out.col.clear(); out.padded_nnz = 0;
+               const SellOptions& opt, SellPlan& out) {
+    out = SellPlan{};
     const int64_t nnz = indptr[n];
+    // --- the sorting window (SELL-C-sigma): 64 (rows stay consecutive: coalesced row operands, the smallest gather footprint)
+    // while that pads by at most opt.target64; else the smallest of 256, 1024, 4096 whose padding is within opt.target of
+    // the nonzeros, else the one that pads least
+    int sigma = opt.sigma;
+    if (sigma <= 0) {
+        int64_t best_pad = -1;
+        for (int cand : {64, 256, 1024, 4096}) {
+            const int64_t pd = sell_padded(n, indptr, row_class, cand);
+            if (best_pad < 0 || pd < best_pad) { best_pad = pd; sigma = cand; }
+            if ((double)pd <= (cand == 64 ? opt.target64 : opt.target) * (double)std::max<int64_t>(nnz, 1)) { sigma = cand; break; }
+        }
+    }
+    if (sigma < 64) sigma = 64;
+    out.sigma = sigma;
     // pass 1: slices, widths, offsets
     std::vector<SellSlice> all;
     std::vector<uint8_t> cls_of;
+    std::vector<int32_t>& perm = out.rows;        // every slice's (row, length) pairs in lane order (sigma > 64), 64 pairs per slice
+    std::vector<int32_t> run;
     int64_t voff = 0, coff = 0, r = 0;
     while (r < n) {
         const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
-        int64_t e = r;
-        int width = 0;
-        int32_t cmin = INT32_MAX, cmax = -1;
-        while (e < n && e - r < 64 && (!row_class || (row_class[e] != 0) == cls)) {
-            width = std::max(width, indptr[e + 1] - indptr[e]);
-            for (int32_t q = indptr[e]; q < indptr[e + 1]; ++q) { cmin = std::min(cmin, indices[q]); cmax = std::max(cmax, indices[q]); }
-            ++e;
+        int64_t e = r + 1;
+        if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
+        run.clear();
+        sell_run_order(indptr, r, e, sigma, run);
+        for (size_t i = 0; i < run.size(); i += 64) {
+            const size_t je = std::min(run.size(), i + 64);
+            int width = 0;
+            int32_t cmin = INT32_MAX, cmax = -1, rmin = INT32_MAX;
+            for (size_t j = i; j < je; ++j) {
+                const int32_t row = run[j];
+                rmin = std::min(rmin, row);
+                width = std::max(width, indptr[row + 1] - indptr[row]);
+                for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q) { cmin = std::min(cmin, indices[q]); cmax = std::max(cmax, indices[q]); }
+            }
+            if (cmax < 0) cmin = 0;
+            if (cmax >= 0 && cmax - cmin >= 65536) return false;
+            const int w2 = (width + 1) & ~1, w4 = (width + 3) & ~3;
+            if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w4 * 64 >= (int64_t)INT32_MAX - 4096) return false;
+            int rows_off = -1;
+            if (sigma > 64) {
+                rows_off = (int)(perm.size() / 2);
+                for (size_t j = i; j < je; ++j) { perm.push_back(run[j]); perm.push_back(indptr[run[j] + 1] - indptr[run[j]]); }
+                for (size_t j = je; j < i + 64; ++j) { perm.push_back(-1); perm.push_back(0); }
+            }
+            // (sigma == 64: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
+            all.push_back(SellSlice{sigma > 64 ? rmin : run[i], (sigma > 64 ? rmin : run[i]) + (int)(je - i), (int)voff, (int)coff, width, cmin, rows_off, 0});
+            cls_of.push_back(cls);
+            voff += (int64_t)w2 * 64;
+            coff += (int64_t)w4 * 64;
         }
-        if (cmax < 0) cmin = 0;
-        if (cmax >= 0 && cmax - cmin >= 65536) return false;
-        const int w2 = (width + 1) & ~1, w4 = (width + 3) & ~3;
-        if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w4 * 64 >= (int64_t)INT32_MAX - 4096) return false;
-        all.push_back(SellSlice{(int)r, (int)e, (int)voff, (int)coff, width, cmin, 0, 0});
-        cls_of.push_back(cls);
-        voff += (int64_t)w2 * 64;
-        coff += (int64_t)w4 * 64;
         r = e;
     }
-    if ((double)voff > max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
+    if ((double)voff > opt.max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
     out.padded_nnz = voff;
     // pass 2: fill (padding: value 0, column 0)
     out.val.assign((size_t)voff + 1024, 0.0);
@@ -675,8 +780,8 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     auto fill = [&](size_t a, size_t b) {
         for (size_t i = a; i < b; ++i) {
             const SellSlice& sl = all[i];
-            for (int row = sl.rb; row < sl.re; ++row) {
-                const int l = row - sl.rb;
+            for (int l = 0; l < sl.re - sl.rb; ++l) {
+                const int row = sl.rows_off < 0 ? sl.rb + l : perm[2 * ((size_t)sl.rows_off + l)];
                 const int32_t lo = indptr[row];
                 const int len = indptr[row + 1] - lo;
                 for (int u = 0; u < len; ++u) {
@@ -697,6 +802,29 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < all.size(); ++i) (cls_of[i] ? out.s1 : out.s0).push_back(all[i]);
+    // --- processing order of the class-0 slices (any order is correct; the table IS the order: the waves of a launch
+    // take consecutive entries).  A 3-D discretisation couples row r to r +- one grid plane: in row order the slices that
+    // read a row as their plane neighbour are a plane apart -- processed in another XCD (each has its own L2) or long after
+    // the row has left the L2, so every vector entry crosses the fabric ~7 times (s4b, r03: 1.14 x the bytes that must
+    // move).  Here groups of opt.planes consecutive planes are INTERLEAVED: the slices at the same place of planes
+    // z, z+1, ... are neighbours in the table, hence processed at the same time by neighbouring workgroups of one XCD.
+    out.stride_rows = opt.planes > 1 ? sell_far_stride(n, indptr, indices) : 0;
+    if (out.stride_rows > 0 && out.s0.size() >= 4096) {
+        const int64_t beta = out.stride_rows;
+        const int G = opt.planes;
+        const int64_t bin = sigma;                         // rows per place: one slice (or one sorting window of slices)
+        std::vector<std::array<int64_t, 4>> key(out.s0.size());
+        for (size_t i = 0; i < out.s0.size(); ++i) {
+            const int64_t rb = out.s0[i].rb;
+            const int64_t z = rb / beta, y = rb - z * beta;
+            key[i] = {z / G, y / bin, z, (int64_t)i};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<SellSlice> ord(out.s0.size());
+        for (size_t i = 0; i < key.size(); ++i) ord[i] = out.s0[(size_t)key[i][3]];
+        out.s0.swap(ord);
+        out.planes = G;
+    }
     return true;
 }
 

@@ -121,21 +121,39 @@ bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const in
                       SweepPlan& out);
 
 // ---- sliced rows (prcg_sell.hip) ---------------------------------------------------------------
-// Slices of up to 64 consecutive rows of one class (interior slices first).  Within a slice of width w (its longest
-// row), nonzero u of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4]
-// (column minus the slice's smallest column); shorter rows are padded with value 0 / column 0 (never multiplied: the
-// kernels mask by the row length).  The arrays end with a whole trip of padding.  Returns false (nothing built) if
-// the operator does not qualify: a slice's columns span 65536 or more, or padding would exceed `max_overhead` x nnz.
-struct SellSlice { int rb, re, voff, coff, width, cbase, pad0, pad1; };
+// Slices of up to 64 rows of one class (interior slices first).  Within a slice of width w (its longest row), nonzero u
+// of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus the
+// slice's smallest column); shorter rows are padded with value 0 / column 0 (never multiplied: the kernels mask by the
+// row length).  The arrays end with a whole trip of padding.
+// Which rows: with a sorting window of 64 (SellPlan::sigma) the slice holds the consecutive rows [rb, re) and
+// rows_off = -1; with a larger window (SELL-C-sigma: every window of sigma consecutive rows of one class is sorted by
+// descending row length -- stable -- before it is cut into slices, so that rows of similar length share a slice and
+// the padding stays small for operators whose row lengths vary) lane l holds row rows[2 * (rows_off + l)], whose length
+// is rows[2 * (rows_off + l) + 1] (64 pairs per slice; row -1, length 0 behind the last), and rb is the smallest of them.  Every row is still summed left to right
+// by ONE lane: the products are scipy's bit for bit whatever the order.
+// Returns false (nothing built) if the operator does not qualify: a slice's columns span 65536 or more, or padding
+// would exceed `max_overhead` x nnz.
+struct SellSlice { int rb, re, voff, coff, width, cbase, rows_off, flags; };
 static_assert(sizeof(SellSlice) == 32, "the kernels read a slice descriptor as two int4");
+struct SellOptions {
+    double max_overhead = 1.25;      // most padded nonzeros per nonzero
+    int sigma = 0;                   // sorting window in rows (64: none); 0: 64 if that pads <= target64, else the smallest of
+    double target64 = 1.06;          //    256, 1024, 4096 that pads <= target (else the one that pads least)
+    double target = 1.04;
+    int planes = 8;                  // class-0 slices of this many consecutive grid planes are interleaved in the table (<= 1: row order)
+};
 struct SellPlan {
-    std::vector<SellSlice> s0, s1;       // interior slices, slices touching ghost columns
+    std::vector<SellSlice> s0, s1;       // interior slices (in PROCESSING order), slices touching ghost columns
     std::vector<double> val;
     std::vector<uint16_t> col;
+    std::vector<int32_t> rows;           // sigma > 64: the slices' (row, length) pairs in lane order
     int64_t padded_nnz = 0;
+    int sigma = 64;
+    int64_t stride_rows = 0;             // the operator's dominant far column offset (a grid plane), 0: none found
+    int planes = 0;                      // > 0: the class-0 table interleaves groups of this many planes
 };
 bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-               double max_overhead, SellPlan& out);
+               const SellOptions& opt, SellPlan& out);
 
 // Merged exchange (small halos ride on the one all-gather per iteration):
 // every rank contributes a slot of `slot` doubles = 8 (partial sums) + 2 x its packed send rows;

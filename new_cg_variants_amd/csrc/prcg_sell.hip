@@ -26,7 +26,7 @@ namespace {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-struct SDesc { int rb, re, voff, coff, width, cbase; };
+struct SDesc { int rb, re, voff, coff, width, cbase, rows_off; };
 
 __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) {
     const int4 a = st[2 * t], b = st[2 * t + 1];
@@ -34,12 +34,14 @@ __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) 
     d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
     d.voff = __builtin_amdgcn_readfirstlane(a.z); d.coff = __builtin_amdgcn_readfirstlane(a.w);
     d.width = __builtin_amdgcn_readfirstlane(b.x); d.cbase = __builtin_amdgcn_readfirstlane(b.y);
+    d.rows_off = __builtin_amdgcn_readfirstlane(b.z);
     return d;
 }
 
 // 8 nonzeros of every row of the slice: four value chunks (2 doubles per lane each), two column chunks (4 x u16)
 struct Trip { d2_t v[4]; uint2 c[2]; };
 
+template <bool NT>
 __device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip& T) {
     // chunk index of nonzero u: values u / 2, columns u / 4.  The last trip of a slice may reach past its width: those
     // chunks belong to the following slice (or to the whole trip of padding the arrays end with, see plan_sell) and are
@@ -47,12 +49,32 @@ __device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int 
     const int64_t vb = (int64_t)d.voff + ((int64_t)(u0 >> 1) * 64 + lane) * 2;
     const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 2) * 64 + lane) * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) T.v[k] = *reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)k * 128);
+    for (int k = 0; k < 4; ++k) {
+        const d2_t* q = reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)k * 128);
+        T.v[k] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) T.c[k] = *reinterpret_cast<const uint2*>(A.col16 + cb + (int64_t)k * 256);
+    for (int k = 0; k < 2; ++k) {
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+        const u2_t* q = reinterpret_cast<const u2_t*>(A.col16 + cb + (int64_t)k * 256);
+        const u2_t c = NT ? __builtin_nontemporal_load(q) : *q;
+        T.c[k] = make_uint2(c.x, c.y);
+    }
 }
 
-template <int NV, int EPI>
+// the row lane `lane` of slice d holds and its length: consecutive rows (lengths from the row pointers), or -- sorting
+// window wider than a slice -- the slice's (row, length) pairs in lane order (row -1 behind the last: length 0)
+__device__ __forceinline__ int2 slice_row(const SellDev& A, const SDesc& d, int lane) {
+    if (d.rows_off < 0) {                                                   // wave-uniform
+        const int row = d.rb + lane;
+        const int r0 = row < d.re ? row : d.rb;
+        const int a = A.indptr[r0], b = A.indptr[r0 + 1];
+        return make_int2(row < d.re ? row : -1, row < d.re ? b - a : 0);
+    }
+    return reinterpret_cast<const int2*>(A.rows)[d.rows_off + lane];
+}
+
+template <int NV, int EPI, bool NT>
 __global__ __launch_bounds__(kBlock) void k_sell_tiles(
     SellDev A, const int4* __restrict__ slices, int nslices,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -87,26 +109,22 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
     int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
 
     Trip cur, nxt;
-    SDesc d = {0, 0, 0, 0, 0, 0}, dn = {0, 0, 0, 0, 0, 0};
-    int ip0 = 0, ip1 = 0;                  // row pointers of the lane's row in the CURRENT slice (requested a slice ahead)
+    SDesc d = {0, 0, 0, 0, 0, 0, -1}, dn = {0, 0, 0, 0, 0, 0, -1};
+    int2 rl = make_int2(-1, 0);            // row and length of the lane's row in the CURRENT slice (requested a slice ahead)
     if (t < nslices) {
         d = read_sdesc(slices, t);
-        load_trip(A, d, 0, lane, cur);
-        const int r0 = d.rb + lane < d.re ? d.rb + lane : d.rb;
-        ip0 = A.indptr[r0]; ip1 = A.indptr[r0 + 1];
+        load_trip<NT>(A, d, 0, lane, cur);
+        rl = slice_row(A, d, lane);
         if (t + W < nslices) dn = read_sdesc(slices, t + W);
     }
     while (t < nslices) {
-        const int row = d.rb + lane;
-        const bool active = row < d.re;
+        const int row = rl.x;
+        const bool active = row >= 0;
         const int rr = active ? row : d.rb;
-        const int len = active ? ip1 - ip0 : 0;
-        // requested now, used at the end of the slice: the next slice's row pointers and, for the fused iteration, the
+        const int len = rl.y;
+        // requested now, used at the end of the slice: the next slice's rows and lengths and, for the fused iteration, the
         // row's own operands (the row walk covers their latency)
-        if (t + W < nslices) {
-            const int rn = dn.rb + lane < dn.re ? dn.rb + lane : dn.rb;
-            ip0 = A.indptr[rn]; ip1 = A.indptr[rn + 1];
-        }
+        if (t + W < nslices) rl = slice_row(A, dn, lane);
         FusedRowIn q;
         V own; vzero(own);
         if constexpr (epi_fused(EPI)) {
@@ -119,14 +137,18 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
         for (int u0 = 0; u0 < d.width; u0 += 8) {                            // wave-uniform trip count
             // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
             const bool more = u0 + 8 < d.width;
-            if (more) load_trip(A, d, u0 + 8, lane, nxt);
-            else if (t + W < nslices) load_trip(A, dn, 0, lane, nxt);
+            if (more) load_trip<NT>(A, d, u0 + 8, lane, nxt);
+            else if (t + W < nslices) load_trip<NT>(A, dn, 0, lane, nxt);
             int col[8];
             col[0] = cur.c[0].x & 0xffffu; col[1] = cur.c[0].x >> 16; col[2] = cur.c[0].y & 0xffffu; col[3] = cur.c[0].y >> 16;
             col[4] = cur.c[1].x & 0xffffu; col[5] = cur.c[1].x >> 16; col[6] = cur.c[1].y & 0xffffu; col[7] = cur.c[1].y >> 16;
             V g[8];
 #pragma unroll
+#ifdef PRCG_SELL_DIAG_NOGATHER      // TIMING ONLY (wrong products): every gather hits the same 64 entries -- what the kernel costs without gather misses
+            for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + (col[k] & 63)];
+#else
             for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + col[k]];         // (padding columns are 0: a valid entry, never used)
+#endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const double a = (k & 1) ? cur.v[k >> 1].y : cur.v[k >> 1].x;
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
             }
             cur = nxt;
         }
-        if (d.width == 0 && t + W < nslices) load_trip(A, dn, 0, lane, cur);
+        if (d.width == 0 && t + W < nslices) load_trip<NT>(A, dn, 0, lane, cur);
         if constexpr (epi_fused(EPI)) {
             if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
         } else {
@@ -180,8 +202,8 @@ template <int NV, int EPI>
 int launch_sell(hipStream_t st, const SellDev& A, const void* slices, int nslices, const void* x, void* y, int write_mask,
                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz, int per_cu)
 {
-    auto k = k_sell_tiles<NV, EPI>;
-    const int grid = sell_grid(k, nslices, per_cu);
+    auto k = A.nt ? k_sell_tiles<NV, EPI, true> : k_sell_tiles<NV, EPI, false>;
+    const int grid = sell_grid(k_sell_tiles<NV, EPI, false>, nslices, per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r, ep_d,
                        ep_st, partials, aux, fz);
     return hipGetLastError() == hipSuccess ? grid : -1;

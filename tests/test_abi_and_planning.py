@@ -13,10 +13,14 @@ from new_cg_variants_amd import problems
 from new_cg_variants_amd.device import plan_tiles
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'prcg.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(prcg_[a-z0-9_]+)\s*\(', text)))
+def declared_symbols(headers=('prcg.h', 'prcg_test.h')):
+    """include/prcg.h: the boundary a maintainer binds; include/prcg_test.h: planner / diagnostic / test hooks"""
+    names = set()
+    for hname in headers:
+        text = open(os.path.join(ROOT, 'include', hname)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        names |= set(re.findall(r'\b(prcg_[a-z0-9_]+)\s*\(', text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,8 +29,10 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for name in names:
         assert hasattr(lib, name), f'{name} declared in include/prcg.h but not exported'
-    # and the binding covers exactly the header
+    # and the binding covers exactly the two headers
     assert sorted(L._SIGNATURES) == names
+    # the product header carries no planner / debug / test hook
+    assert not [n for n in declared_symbols(('prcg.h',)) if n.startswith(('prcg_plan_', 'prcg_debug_')) or n in ('prcg_peer_selftest', 'prcg_world_init', 'prcg_tile_caps')]
     assert lib.prcg_version() == 1
 
 
@@ -366,35 +372,52 @@ def test_missing_x_true_is_refused_for_large_systems():
         cg_variants.pipe_pr_cg(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), 5, callbacks=[error_A_norm])
 
 
-def plan_sell(A, row_class=None, max_overhead=1.25):
+def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8):
     A = A.tocsr()
     n = A.shape[0]
     indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
     indices = np.ascontiguousarray(A.indices, dtype=np.int32)
     data = np.ascontiguousarray(A.data, dtype=np.float64)
     rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
-    stats = np.zeros(4, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64)
     cap = n // 64 + 8 + (0 if rc is None else int(np.count_nonzero(np.diff(rc.astype(np.int8)))) + 2)
     slices = np.zeros((cap, 8), dtype=np.int32)
     arr_cap = int(max_overhead * A.nnz * 1.3) + 64 * 130 * 4 + 4096
     val = np.zeros(arr_cap)
     col = np.zeros(arr_cap, dtype=np.uint16)
-    got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), L.ptr(slices), cap,
-                                 L.ptr(val), L.ptr(col), arr_cap, L.ptr(stats))
-    return got, slices[:max(got, 0)], val, col, stats
+    rows = np.zeros((cap * 64, 2), dtype=np.int32)
+    got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), int(sigma), int(planes),
+                                 L.ptr(slices), cap, L.ptr(val), L.ptr(col), arr_cap, L.ptr(rows), rows.size, L.ptr(stats))
+    return got, slices[:max(got, 0)], val, col, stats, rows
 
 
-@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts'])
+def slice_rows(sl, rows):
+    """(row, length) of every lane of a slice descriptor: consecutive rows, or the slice's entries of the row stream"""
+    rb, re, _, _, _, _, rows_off, _ = sl
+    if rows_off < 0:
+        return [(r, None) for r in range(rb, re)]
+    ent = rows[rows_off:rows_off + 64]
+    k = re - rb
+    assert np.all(ent[k:, 0] == -1) and np.all(ent[k:, 1] == 0)
+    assert ent[:k, 0].min() == rb
+    return [(int(r), int(ln)) for r, ln in ent[:k]]
+
+
+@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256'])
 def test_sliced_row_layout_holds_exactly_the_matrix(name):
     """Host planner of the lane-per-row kernels (prcg_plan.cpp: plan_sell): every row in exactly one slice (classes apart,
     class 0 first), and reading the re-laid arrays back with the kernel's index formula gives the caller's CSR rows,
-    values bit for bit and columns exactly, in order; padding is zero."""
+    values bit for bit and columns exactly, in order; padding is zero.  With a sorting window wider than a slice
+    (SELL-C-sigma: operators whose row lengths vary) the slices name their rows and lengths, rows of one window only,
+    longest first."""
     import scipy.sparse as sp
     from new_cg_variants_amd import partition
     rng = np.random.default_rng(9)
     row_class = None
+    sigma = 0
     if name == 'fem':
         A = problems.fem_like_3d(9, 3)
+        sigma = 64
     elif name == 'ragged':
         n = 5000
         lens = rng.integers(40, 51, size=n)
@@ -403,24 +426,40 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
         r = np.repeat(np.arange(n), lens)
         A = sp.csr_matrix((rng.standard_normal(r.size), (r + rng.integers(-900, 901, size=r.size)).clip(0, n - 1).astype(np.int32), indptr),
                           shape=(n, n))
+    elif name.startswith('irregular'):
+        A = problems.fem_irregular_3d(11)
+        sigma = 256 if name.endswith('256') else 0
     else:
         full = problems.fem_like_3d(10, 3)
         A, ghost_ids = partition.localize(full[900:2100], 900, 2100)
         row_class = np.array([(A.indices[A.indptr[i]:A.indptr[i + 1]] >= 1200).any() for i in range(1200)])
-    got, slices, val, col, stats = plan_sell(A, row_class)
+    got, slices, val, col, stats, rows = plan_sell(A, row_class, sigma=sigma)
     assert got > 0, got
     n = A.shape[0]
+    sig = int(stats[4])
+    assert sig == (sigma or sig) and sig in (64, 256, 1024, 4096)
+    if name == 'irregular':
+        assert sig > 64                                  # consecutive rows would pad by ~30 %
+        assert stats[3] <= 1.10 * A.nnz
+    lens_all = np.diff(A.indptr)
     seen = np.zeros(n, dtype=int)
     used_v = np.zeros(int(stats[1]), dtype=bool)
-    for si, (rb, re, voff, coff, width, cbase, _, _) in enumerate(slices):
+    for si, sl in enumerate(slices):
+        rb, re, voff, coff, width, cbase, rows_off, _ = sl
         assert 0 < re - rb <= 64
-        seen[rb:re] += 1
+        lanes = slice_rows(sl, rows)
+        assert (rows_off < 0) == (sig == 64)
+        rws = np.array([r for r, _ in lanes])
+        seen[rws] += 1
         if row_class is not None:
-            assert np.all(row_class[rb:re] == (si >= stats[0]))
-        assert width == np.diff(A.indptr[rb:re + 1]).max()
-        for row in range(rb, re):
-            lane = row - rb
+            assert np.all(row_class[rws] == (si >= stats[0]))
+        assert width == lens_all[rws].max()
+        if sig > 64:
+            assert rws.max() // sig == rws.min() // sig or row_class is not None      # rows of ONE sorting window
+            assert np.all(np.diff(lens_all[rws]) <= 0)                                # longest first
+        for lane, (row, ln) in enumerate(lanes):
             lo, hi = A.indptr[row], A.indptr[row + 1]
+            assert ln is None or ln == hi - lo
             u = np.arange(hi - lo)
             vi = voff + ((u >> 1) * 64 + lane) * 2 + (u & 1)
             ci = coff + ((u >> 2) * 64 + lane) * 4 + (u & 3)
@@ -430,8 +469,41 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
     assert np.all(seen == 1)
     assert np.all(val[:int(stats[1])][~used_v] == 0.0)
     assert stats[3] <= 1.25 * max(A.nnz, 1)
-    for part in (slices[:stats[0]], slices[stats[0]:]):
-        assert np.all(np.diff(part[:, 0]) > 0)
+    if stats[6] == 0:
+        for part in (slices[:stats[0]], slices[stats[0]:]):
+            assert np.all(np.diff(part[:, 0]) > 0) or sig > 64
+
+
+def test_sliced_row_table_interleaves_grid_planes():
+    """Processing order of the slice table (any order is correct; this one is fast): for an operator with a dominant far
+    column offset -- a 3-D discretisation in natural ordering: one grid plane -- the slices at the same place of 8
+    consecutive planes are neighbours in the table, so the launch's concurrent waves (consecutive table entries) read each
+    plane-neighbour row while another of them owns it.  The stride is found from the matrix alone."""
+    m = 48                                                # (5184 slices: tables of fewer than 4096 stay in row order -- two rounds of a launch)
+    A = problems.fem_like_3d(m, 3)
+    got, slices, _, _, stats, _ = plan_sell(A, sigma=64)
+    plane = 3 * m * m
+    assert abs(int(stats[5]) - plane) <= 0.01 * plane, stats
+    assert stats[6] == 8 and stats[4] == 64
+    rb = slices[:, 0].astype(np.int64)
+    assert sorted(rb.tolist()) == list(range(0, A.shape[0], 64))          # a permutation of the row-order table
+    beta = int(stats[5])
+    z = rb // beta
+    # any 64 consecutive table entries inside a plane group hold all of its 8 planes ...
+    for start in range(0, 8 * plane // 64 - 64, 17):
+        assert len(set(z[start:start + 64].tolist())) == 8, start
+    # ... and the plane neighbours (rows +- one plane) of an entry's rows are owned by an entry at most a few places away
+    pos = {int(r): i for i, r in enumerate(rb)}
+    far = []
+    for i in range(0, len(rb), 7):
+        for nb in (rb[i] - beta, rb[i] + beta):
+            nb64 = int(nb // 64 * 64)
+            if nb64 in pos and z[pos[nb64]] // 8 == z[i] // 8:
+                far.append(abs(pos[nb64] - i))
+    assert np.percentile(far, 95) <= 24, np.percentile(far, 95)
+    # without a far stride (a band) or with planes <= 1 the table stays in row order
+    got, slices, _, _, stats, _ = plan_sell(A, sigma=64, planes=1)
+    assert stats[6] == 0 and np.all(np.diff(slices[:, 0]) > 0)
 
 
 def test_sliced_rows_refuse_wide_and_ragged_operators():
@@ -446,7 +518,9 @@ def test_sliced_rows_refuse_wide_and_ragged_operators():
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     r = np.repeat(np.arange(4000), lens)
     ragged = sp.csr_matrix((np.ones(r.size), (r // 2).astype(np.int32), indptr), shape=(4000, 4000))
-    assert plan_sell(ragged)[0] == 0                     # padding to each slice's longest row would double the stream
+    assert plan_sell(ragged, sigma=64)[0] == 0           # consecutive rows: padding to each slice's longest row would double the stream
+    got, _, _, _, stats, _ = plan_sell(ragged)           # a sorting window of 4096 rows brings it under 25 %
+    assert got > 0 and stats[4] > 64 and stats[3] <= 1.25 * ragged.nnz
 
 
 def plan_patterns(A_local, row_class=None):
