@@ -109,6 +109,7 @@ def cpu_baseline(A, b, x0, family, seconds=15.0):
 
 
 PREWARM = 300      # untimed iterations before any clock starts: the chip's clocks are up, whatever --warmup says
+SAMPLE_AFTER = 200  # launches AFTER the timed region with HIP events around every second one: a larger sample of the launch duration
 VARIANTS = ['pipe_pr_cg', 'hs_cg', 'pr_cg', 'pipe_pr_pcg', 'pipe_p_cg', 'cg_cg', 'gv_cg']
 FAMILY = {'pipe_pr_cg': 'pipe', 'hs_cg': 'hs', 'pr_cg': 'pr', 'pipe_pr_pcg': 'pipe', 'pipe_p_cg': 'pipe', 'cg_cg': 'cg_cg', 'gv_cg': 'gv'}
 
@@ -130,6 +131,8 @@ def main():
                     help='skip the second timed run with the value dictionary off')
     ap.add_argument('--no-multi-rank-leg', action='store_true',
                     help='skip the extra N=1 runs of the multi-rank schedule (1-rank communicator, S3/8 slice)')
+    ap.add_argument('--no-rccl-leg', action='store_true',
+                    help='N>1 only: skip the second, short timed leg on the RCCL side-stream schedule')
     ap.add_argument('--no-workloads', action='store_true',
                     help="skip the extra N=1 runs of BASELINE.json's other configurations (S1, S2, s4b, s4)")
     args = ap.parse_args()
@@ -186,15 +189,23 @@ def main():
             partition.connect_peer_exchange(d, 0, lambda obj: [obj])
         return d
 
-    def timed_run(dev, variant, b, x0, inv_diag=None, K=None):
+    def timed_run(dev, variant, b, x0, inv_diag=None, K=None, sample_after=0):
         """(elapsed, host enqueue time, kernel timings, residual finite, error).  A library error (a one-launch
         iteration of a communicator session that waited longer than its bound for the reduction) is RETURNED, not
-        raised: every rank must reach the barriers below, and the decision what to do next is taken collectively."""
+        raised: every rank must reach the barriers below, and the decision what to do next is taken collectively.
+        The PREWARM iterations bring the chip's clocks up; then the session is begun AFRESH (x0 again), so that the W
+        warm-up and the K timed iterations run on the first W + K iterates of the solve -- a finite state whatever the
+        operator's conditioning (round 3 timed one stand-in 500 iterations in, after CG had converged to an exact zero).
+        sample_after > 0: that many further launches after the timed region with HIP events around every second one
+        (timings()['sampled_after_ms']): a larger sample of the launch duration than the timed region allows itself."""
         K = K_MAIN if K is None else K
         err = None
         try:
-            dev.begin(variant, b, x0, PREWARM + W + K + 1, inv_diag=inv_diag)
-            dev.iterate(PREWARM + W)
+            dev.begin(variant, b, x0, PREWARM + 1, inv_diag=inv_diag)
+            dev.iterate(PREWARM)
+            dev.sync()
+            dev.begin(variant, b, x0, W + K + sample_after + 1, inv_diag=inv_diag)
+            dev.iterate(W)
             dev.sync()
         except L.PrcgError as exc:
             err = str(exc)
@@ -222,8 +233,18 @@ def main():
             err = next((e for e in comm.allgather_obj(err) if e), None)
         if err is not None:
             return elapsed, t_enq, None, False, err
-        finite = bool(np.isfinite(dev.get_scalars(PREWARM + W + K)[L.S_NU]))
-        return elapsed, t_enq, dev.timings(), finite, None
+        finite = bool(np.isfinite(dev.get_scalars(W + K)[L.S_NU]))
+        tim = dev.timings()
+        if sample_after > 0:
+            try:
+                dev.set_profiling(2)
+                dev.iterate(sample_after)
+                dev.sync()
+                t2 = dev.timings()
+                tim = dict(tim, sampled_after_ms=t2['spmv_ms'], sampled_after=t2['spmv_samples'])
+            except L.PrcgError:
+                pass
+        return elapsed, t_enq, tim, finite, None
 
     def product_rates(dev, sched, n, nnz):
         """Standalone SpMV / two-vector SpMM of the resident operator (north_star: effective SpMV HBM GB/s)."""
@@ -271,12 +292,14 @@ def main():
         ms = tim['spmv_ms']
         return {'value': K / elapsed, 'unit': 'iters/s', 'ms_per_step': elapsed / K * 1e3, 'kernel': kname, 'avg_launch_ms': ms,
                 'launches_sampled': tim['spmv_samples'], 'update_kernel_ms': tim['update_ms'],
+                'avg_launch_ms_sampled_after': tim.get('sampled_after_ms'), 'launches_sampled_after': tim.get('sampled_after'),
                 'bytes_must_move': mv, 'moved_GBps': mv / ms * 1e-6 if ms > 0 else 0.0,
                 'frac': mv / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0,
                 'bytes_algorithmic': kb, 'algorithmic_frac': kb / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0,
                 'operator_bytes': opb, 'operator_bytes_per_nonzero': opb / max(nnz, 1),
                 'window_kernels': sched['window'], 'value_dictionary': sched['value_dict'], 'col_bytes': sched['col_bytes'],
                 'pattern_tiles': sched.get('pattern', False), 'sliced_rows': sched.get('sliced_rows', False),
+                'sorted_windows': sched.get('sorted_windows', False), 'nt_loads': sched.get('nt_loads', False), 'stream_stores': sched.get('stream_stores', False),
                 'one_launch': sched['fused'], 'residual_finite': finite}
 
     # ---- the rank's row block of the synthetic operator, right-hand side as the reference --
@@ -312,7 +335,7 @@ def main():
         # is timed (scaling.one_launch_self_check): on disagreement every rank runs the timed region on the RCCL schedule
         run_err = scaling.one_launch_self_check(op, variant, b, x0, inv_diag)
     if run_err is None:
-        elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag)
+        elapsed, t_enq, tim, finite, run_err = timed_run(dev, variant, b, x0, inv_diag, sample_after=SAMPLE_AFTER if world == 1 else 0)
     if run_err is not None:
         # the one-launch schedule of a multi-rank session could not be kept fed on this node (its waits are
         # bounded and reported): every rank rebuilds its operator with the RCCL two-kernel schedule and the run is repeated
@@ -329,13 +352,31 @@ def main():
     sched = dev.schedule()
     spmv = product_rates(dev, sched, n, nnz_total) if world == 1 else None
 
+    # N > 1: the paper's contrast in one run -- after the default schedule (one launch per iteration, direct peer exchange) the same
+    # loop on the RCCL schedule (update kernel + two-vector SpMM, halo and the single all-reduce on side streams: the GPU form of
+    # scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173), a short second leg
+    rccl_leg = None
+    if world > 1 and args.variant.startswith('pipe_') and fallback is None and sched.get('peer') and not args.no_rccl_leg:
+        try:
+            op2 = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
+            e2, q2, tim2, fin2, err2 = timed_run(op2.dev, variant, b, x0, inv_diag, K=min(K, 100))
+            s2 = op2.dev.schedule()
+            rccl_leg = {'what': 'the same loop on the RCCL side-stream schedule (PRCG_PEER=0): update kernel + SpMM, halo send/recv or merged '
+                                'all-gather and ONE all-reduce per iteration on communication streams',
+                        'rccl_ranks': world, 'value': min(K, 100) / e2 if not err2 else None, 'unit': 'iters/s', 'steps': min(K, 100),
+                        'ms_per_step': e2 / min(K, 100) * 1e3, 'residual_finite': fin2, 'error': err2,
+                        'merged_exchange': s2.get('gather'), 'one_launch': s2.get('fused_comm'), 'host_enqueue_us_per_step': q2 / min(K, 100) * 1e6}
+            op2.dev.close()
+        except Exception as exc:
+            rccl_leg = {'rccl_ranks': world, 'error': str(exc)[:300]}
+
     # An operator whose values do not repeat (an assembled FEM matrix) streams the doubles themselves: time
     # that path too, same matrix, value dictionary off.  This leg IS what SURVEY.md 8d's algorithmic bytes
     # (12 B per nonzero) describe up to the narrower column stream.
     plain = None
     if world == 1 and not args.force_comm and sched['value_dict'] and not args.no_plain_values:
         dev2 = DeviceCSR(A_rows.tocsr(), device=local_rank, knobs={'PRCG_VALDICT': '0'})
-        e2, _, tim2, fin2, _err2 = timed_run(dev2, variant, b, x0, inv_diag)
+        e2, _, tim2, fin2, _err2 = timed_run(dev2, variant, b, x0, inv_diag, sample_after=SAMPLE_AFTER)
         sched2 = dev2.schedule()
         plain = (e2, tim2, fin2, sched2, product_rates(dev2, sched2, n, nnz_total), dev2.operator_bytes())
         dev2.close()
@@ -366,58 +407,51 @@ def main():
             multi.update({k: multi['s3'][k] for k in ('one_launch', 'value', 'unit', 'host_enqueue_us_per_step')})
             multi['ms_per_step'] = multi['s3']['us_per_iteration'] * 1e-3
             if args.workload == 's3':
-                wl8 = problems.WORKLOADS['s3_8th']
-                A8 = wl8['make']()
-                b8, x8, _ = problems.reference_rhs(A8, wl8['n'])
-                d8 = (1.0 / A8.diagonal()) if inv_diag is not None else None
-                A8_loop, halo8, _ = partition.loopback_problem(A8, 7)       # 14 ghost rows: what a rank of the band receives
-                dp = DeviceCSR(A8, device=local_rank)
-                ep, qp, timp, finp, _ = timed_run(dp, variant, b8, x8, d8, K_LEG)
-                dp.close()
-                leg = comm_leg(A8_loop, halo8, b8, x8, d8)
-                try:       # the RCCL schedule of the same slice, for comparison (update kernel + SpMM, all-gather on the communication stream)
-                    rccl_leg = comm_leg(A8_loop, halo8, b8, x8, d8, {'PRCG_PEER': '0'})
-                except Exception as exc:
-                    rccl_leg = {'error': str(exc)[:200]}
-                multi['s3_8th'] = {'what': 'one rank\'s share of S3 on 8 GPUs (n = 1.25e6) on this GPU: the plain one-launch schedule, and the '
-                                           'multi-rank schedule with a loopback halo (7 ghost rows per side, boundary tiles, the whole '
-                                           'exchange: rows and partial sums stored into the exchange buffer by the launch itself, '
-                                           'next launch waits in-kernel); a real 8-rank exchange adds xGMI latency to the second',
-                                   'plain_us_per_iteration': ep / K_LEG * 1e6, 'plain_host_enqueue_us_per_step': qp / K_LEG * 1e6,
-                                   'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg, 'rccl_schedule': rccl_leg,
-                                   'single_gpu_us_per_iteration': elapsed / K * 1e6,
-                                   'speedup_ceiling_at_8_ranks': (elapsed / K * 1e6) / leg['us_per_iteration'] if leg['us_per_iteration'] > 0 else None}
+                def share_leg(name, halo_rows, cut, single_us, single_plain_us, with_rccl):
+                    """one rank's share of an N-GPU run on this GPU: plain one-launch schedule, multi-rank schedule with a loopback halo"""
+                    wls = problems.WORKLOADS[name]
+                    As = wls['make']()
+                    bs, xs, _ = problems.reference_rhs(As, wls['n'])
+                    ds = (1.0 / As.diagonal()) if inv_diag is not None else None
+                    A_loop, halo_s, _ = partition.loopback_problem(As, halo_rows, cut=cut)
+                    rec = {'workload': wls['desc'], 'halo_rows_per_side': halo_rows}
+                    for key, kn in (('dict', None), ('plain_values', {'PRCG_VALDICT': '0'})):
+                        if key == 'plain_values' and plain is None:
+                            continue
+                        dp = DeviceCSR(As, device=local_rank, knobs=kn)
+                        ep, qp, _, _, _ = timed_run(dp, variant, bs, xs, ds, K_LEG)
+                        dp.close()
+                        leg = comm_leg(A_loop, halo_s, bs, xs, ds, kn)
+                        single = single_us if key == 'dict' else single_plain_us
+                        r = {'plain_us_per_iteration': ep / K_LEG * 1e6, 'plain_host_enqueue_us_per_step': qp / K_LEG * 1e6,
+                             'comm_us_per_iteration': leg['us_per_iteration'], 'comm': leg, 'single_gpu_us_per_iteration': single,
+                             'speedup_ceiling': single / leg['us_per_iteration'] if single and leg['us_per_iteration'] > 0 else None}
+                        if key == 'dict':
+                            rec.update(r)
+                            if with_rccl:
+                                try:       # the RCCL schedule of the same slice, for comparison
+                                    rec['rccl_schedule'] = comm_leg(A_loop, halo_s, bs, xs, ds, {'PRCG_PEER': '0'})
+                                except Exception as exc:
+                                    rec['rccl_schedule'] = {'error': str(exc)[:200]}
+                        else:
+                            rec['plain_values'] = r
+                    return rec
+                s3_us, s3_plain_us = elapsed / K * 1e6, (plain[0] / K * 1e6 if plain is not None else None)
+                multi['what_shares'] = ("s3_half / s3_quarter / s3_8th (and s2_*): ONE rank's share of S3 (S2) on 2 / 4 / 8 GPUs, run on this GPU: "
+                                        'the plain one-launch schedule, and the multi-rank schedule with a loopback halo (boundary tiles, ghost rows, '
+                                        'the whole exchange: rows and partial sums stored into the exchange buffer by the launch itself, next launch '
+                                        'waits in-kernel); speedup_ceiling = single-GPU time / that -- a real exchange adds xGMI latency to it')
+                multi['s3_half'] = share_leg('s3_half', 7, None, s3_us, s3_plain_us, False)
+                multi['s3_quarter'] = share_leg('s3_quarter', 7, None, s3_us, s3_plain_us, False)
+                multi['s3_8th'] = share_leg('s3_8th', 7, None, s3_us, s3_plain_us, True)
+                multi['s3_8th']['speedup_ceiling_at_8_ranks'] = multi['s3_8th'].get('speedup_ceiling')     # (earlier rounds' key)
+                multi['forecast_s3'] = {str(N): multi[k].get('speedup_ceiling') for N, k in ((2, 's3_half'), (4, 's3_quarter'), (8, 's3_8th'))}
                 if plain is not None:
-                    # the same for an operator whose values do not repeat (value dictionary off): more bytes per rank and iteration
-                    # against the same fixed costs
-                    legp = comm_leg(A8_loop, halo8, b8, x8, d8, {'PRCG_VALDICT': '0'})
-                    multi['s3_8th']['plain_values'] = {
-                        'comm_us_per_iteration': legp['us_per_iteration'], 'comm': legp,
-                        'single_gpu_us_per_iteration': plain[0] / K * 1e6,
-                        'speedup_ceiling_at_8_ranks': (plain[0] / K * 1e6) / legp['us_per_iteration'] if legp['us_per_iteration'] > 0 else None}
-                # one rank's share of S2 (BASELINE config 4) on 8 GPUs: 27 grid planes, a halo of one 216 x 216 plane per side
-                # (746 KB of pairs each way) -- the same two schedules, dictionary and plain values
-                wl2 = problems.WORKLOADS['s2_8th']
-                A2 = wl2['make']()
-                b2, x2, _ = problems.reference_rhs(A2, wl2['n'])
-                d2 = (1.0 / A2.diagonal()) if inv_diag is not None else None
-                A2_loop, halo2, _ = partition.loopback_problem(A2, 216 * 216, cut=13 * 216 * 216)
-                rec2 = {'what': "one rank's share of S2 on 8 GPUs (216 x 216 x 27, n = 1,259,712) on this GPU: plain one-launch schedule, "
-                                'and the multi-rank schedule with a loopback halo of one grid plane per side'}
-                for key, kn in (('dict', None), ('plain_values', {'PRCG_VALDICT': '0'})):
-                    if key == 'plain_values' and plain is None:
-                        continue
-                    dp = DeviceCSR(A2, device=local_rank, knobs=kn)
-                    ep, _, _, _, _ = timed_run(dp, variant, b2, x2, d2, K_LEG)
-                    dp.close()
-                    leg2 = comm_leg(A2_loop, halo2, b2, x2, d2, kn)
-                    r2 = {'plain_us_per_iteration': ep / K_LEG * 1e6, 'comm_us_per_iteration': leg2['us_per_iteration'], 'comm': leg2}
-                    if key == 'dict':
-                        rec2.update(r2)
-                    else:
-                        rec2['plain_values'] = r2
-                multi['s2_8th'] = rec2
-                del A2, A2_loop
+                    multi['forecast_s3_plain_values'] = {str(N): (multi[k].get('plain_values') or {}).get('speedup_ceiling')
+                                                         for N, k in ((2, 's3_half'), (4, 's3_quarter'), (8, 's3_8th'))}
+                # BASELINE config 4: S2's shares (whole grid planes, a halo of one 216 x 216 plane = 746 KB of pairs per side);
+                # its single-GPU time comes from the workloads leg below (multi['s2_single_us'] is filled there)
+                multi['_s2_pending'] = True
         except Exception as exc:       # RCCL missing on a box: the bench line itself does not depend on it
             multi = dict(multi or {}, error=str(exc)[:300])
 
@@ -426,7 +460,9 @@ def main():
     if world == 1 and not args.force_comm and not args.no_workloads and args.workload == 's3' and args.variant == 'pipe_pr_cg':
         others = {}
         for name, cfg in (('s1', 'BASELINE config 3'), ('s2', 'BASELINE config 4 at N=1'),
-                          ('s4b', 'BASELINE config 5, FEM-like stand-in for Queen_4147'),
+                          ('s4b', "BASELINE config 5, FEM-like stand-in at Queen_4147's size (uniform 3 dof x 27-point coupling)"),
+                          ('s4c', "BASELINE config 5, IRREGULAR FEM-like stand-in at Queen_4147's size (nodes of 1 / 3 / 6 unknowns, thinned couplings: "
+                                  'rows of 7..121 nonzeros with FEM locality -- the load-balance stress)'),
                           ('s4', 'BASELINE config 5, random-offset irregular stand-in (SURVEY 8d)')):
             try:
                 w2 = problems.WORKLOADS[name]
@@ -439,6 +475,9 @@ def main():
                 rec = dict(summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz)), config=cfg, workload=w2['desc'],
                            n=w2['n'], nnz=int(A2.nnz))
                 rec['traffic'] = measured_traffic(f"{name}:{args.variant}:fused:1:" + ('dict' if d2.schedule()['value_dict'] else 'plain'))
+                if rec['traffic']:
+                    rec['traffic_over_must_move'] = rec['traffic'] / rec['bytes_must_move']
+                    rec['frac_physical'] = rec['traffic'] / (rec['avg_launch_ms'] * 1e-3) * 1e-9 / HBM_PEAK_GBS
                 has_dict = d2.schedule()['value_dict']
                 d2.close()
                 if has_dict:
@@ -446,11 +485,28 @@ def main():
                     e, _, tm, fin, er = timed_run(d2, variant, b2, x2, None, K_LEG)
                     if not er:
                         rec['plain_values'] = summarize(args.variant, d2, e, tm, fin, w2['n'], int(A2.nnz))
+                        rec['plain_values']['traffic'] = measured_traffic(f"{name}:{args.variant}:fused:1:plain")
                     d2.close()
                 others[name] = rec
                 del A2
             except Exception as exc:
                 others[name] = {'error': str(exc)[:300]}
+        # S2's shares on 2 / 4 / 8 GPUs (see multi_rank_schedule above), now that its single-GPU time is known
+        if multi and multi.pop('_s2_pending', False) and 'value' in others.get('s2', {}):
+            try:
+                s2_us = others['s2']['ms_per_step'] * 1e3
+                s2_plain_us = (others['s2'].get('plain_values') or {}).get('ms_per_step')
+                s2_plain_us = s2_plain_us * 1e3 if s2_plain_us else None
+                for key, nz in (('s2_half', 108), ('s2_quarter', 54), ('s2_8th', 27)):
+                    multi[key] = share_leg(key, 216 * 216, (nz // 2) * 216 * 216, s2_us, s2_plain_us, False)
+                multi['forecast_s2'] = {str(N): multi[k].get('speedup_ceiling') for N, k in ((2, 's2_half'), (4, 's2_quarter'), (8, 's2_8th'))}
+                if plain is not None:
+                    multi['forecast_s2_plain_values'] = {str(N): (multi[k].get('plain_values') or {}).get('speedup_ceiling')
+                                                         for N, k in ((2, 's2_half'), (4, 's2_quarter'), (8, 's2_8th'))}
+            except Exception as exc:
+                multi['s2_shares_error'] = str(exc)[:300]
+    if multi:
+        multi.pop('_s2_pending', None)
 
     # BASELINE configs 1 and 2: the paper's small matrices (committed fixtures, data only) at the iteration counts of
     # figure_gen.py:263,289 -- launch-bound systems: the whole pipelined solve of nos7 is ONE launch of ONE workgroup
@@ -492,14 +548,24 @@ def main():
         moved = moved_bytes(kbytes, n_local, nnz_local, opb)
         achieved = moved / ms * 1e-6 if ms > 0 else 0.0
         tkey = f"{args.workload}:{args.variant}{':fused' if fused else ''}:{world}"
+        traffic = measured_traffic(tkey + (':dict' if sched['value_dict'] else ':plain'))
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic(tkey + (':dict' if sched['value_dict'] else ':plain')),
+                'traffic': traffic,
+                'frac_physical': (traffic / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS) if traffic and ms > 0 else None,
+                'frac_8d': kbytes / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else None,
                 'kernel': kname, 'bytes_per_launch': moved, 'avg_launch_ms': ms, 'launches_sampled': tim['spmv_samples'],
+                'avg_launch_ms_sampled_after': tim.get('sampled_after_ms'), 'launches_sampled_after': tim.get('sampled_after'),
                 'update_kernel_ms': tim['update_ms'],
-                'basis': ('achieved = bytes the launch must move / mean launch time by HIP events on the compute stream: the operator '
-                          'as the device streams it (prcg_operator_bytes: ' f"{sched['col_bytes']} B window / column index + "
+                'basis': ('achieved / frac = bytes the launch MUST MOVE / mean launch time by HIP events on the compute stream inside the timed region: '
+                          'the operator as the device streams it (prcg_operator_bytes: ' f"{sched['col_bytes']} B window / column index + "
                           + ('1 B value-dictionary index' if sched['value_dict'] else '8 B value') + ' per nonzero, relative row '
-                          'pointers, tile descriptors; stream images shared by many tiles counted once) + the vector traffic of SURVEY 8d per row'),
+                          'pointers, tile descriptors; stream images shared by many tiles counted once) + the vector traffic of SURVEY 8d per row.  '
+                          'frac_8d = SURVEY.md 8d\'s algorithmic bytes (12 B per nonzero + vectors) / the same time / peak: it EXCEEDS 1 for this '
+                          'workload because the operator is compressed (S3 is a two-value band at n = 1e7: 15 MB of descriptors and shared images '
+                          'instead of 1.8 GB of CSR) -- it is no roofline fraction.  The 8d ratio that IS one is frac_8d_general_csr: the same matrix '
+                          'and loop with every 8-byte value actually streamed (plain_values), with frac_physical_general_csr = PMC traffic / time / '
+                          'peak beside it.  frac_physical = PMC traffic of this launch / its time / peak.  stream_ceiling_GBps: what this GPU '
+                          'delivered in this run for the launch\'s own byte mix with no arithmetic.'),
                 'operator_stream': {'col_bytes': sched['col_bytes'], 'value_dictionary': sched['value_dict'],
                                     'window_kernels': sched['window'], 'bytes': opb, 'bytes_per_nonzero': opb / max(nnz_local, 1),
                                     'csr_bytes': 12 * nnz_local + 4 * (n_local + 1)},
@@ -507,6 +573,22 @@ def main():
                                       'north_star\'s "effective" bandwidth; exceeds the peak when the stream is compressed',
                               'bytes_per_launch': kbytes, 'GBps': kbytes / ms * 1e-6 if ms > 0 else 0.0,
                               'frac_of_peak': kbytes / ms * 1e-6 / HBM_PEAK_GBS if ms > 0 else 0.0}}
+        if world == 1:
+            # "also report a measured stream ceiling" -- in this run, on this GPU: the one-launch iteration's own vector mix
+            # (per row 2 x 16 B read, 2 x 16 B written: all the dictionary kernel moves besides 15 MB of operator) over this workload's n
+            # rows, with the stores the kernel uses; and a pure 16-byte read over 2 GB (what bounds the plain-value / sliced-row streams)
+            try:
+                mix = dev.stream_ceiling(n_local, 2 if sched.get('stream_stores', True) else 1)
+                mix_plain = dev.stream_ceiling(n_local, 1)
+                rd = dev.stream_ceiling(128_000_000, 0, reps=10)
+                roof['stream_ceiling_GBps'] = mix
+                roof['stream_ceiling'] = {'own_mix_GBps': mix, 'own_mix_plain_stores_GBps': mix_plain, 'pure_read_2GB_GBps': rd,
+                                          'what': f'prcg_stream_ceiling on this GPU in this run: 2 x 16 B read + 2 x 16 B written per row over {n_local} rows '
+                                                  '(nontemporal stores as the kernel / plain stores), and a pure 16-byte-per-lane read of 2 GB'}
+                roof['frac_of_stream_ceiling'] = achieved / mix if mix > 0 else None
+            except Exception as exc:
+                roof['stream_ceiling_GBps'] = None
+                roof['stream_ceiling_error'] = str(exc)[:200]
         assert roof['frac'] <= 1.0, 'a physical fraction cannot exceed 1: the byte count is wrong'
         value_general = None
         if plain is not None:
@@ -514,20 +596,33 @@ def main():
             ms2 = tim2['spmv_ms']
             mv2 = moved_bytes(kbytes, n_local, nnz_local, opb2)
             value_general = K / e2
+            tr2 = measured_traffic(tkey + ':plain')
             roof['plain_values'] = {
                 'what': 'same matrix and loop with the value dictionary off (PRCG_VALDICT=0): the rate of an operator '
                         f"whose values do not repeat; {sched2['col_bytes']} B column stream + 8 B value per nonzero",
                 'value': K / e2, 'unit': 'iters/s', 'ms_per_step': e2 / K * 1e3, 'avg_launch_ms': ms2,
+                'launches_sampled': tim2['spmv_samples'], 'avg_launch_ms_sampled_after': tim2.get('sampled_after_ms'),
+                'launches_sampled_after': tim2.get('sampled_after'),
                 'achieved': kbytes / ms2 * 1e-6, 'frac': kbytes / ms2 * 1e-6 / HBM_PEAK_GBS,
                 'basis': 'SURVEY.md 8d algorithmic bytes (12 B per nonzero + vectors) / mean launch time',
                 'moved_GBps': mv2 / ms2 * 1e-6, 'moved_frac': mv2 / ms2 * 1e-6 / HBM_PEAK_GBS, 'bytes_moved_per_launch': mv2,
                 'operator_bytes': opb2,
-                'traffic': measured_traffic(tkey + ':plain'), 'residual_finite': fin2, 'spmv': spmv2}
+                'traffic': tr2, 'frac_physical': (tr2 / (ms2 * 1e-3) * 1e-9 / HBM_PEAK_GBS) if tr2 else None,
+                'residual_finite': fin2, 'spmv': spmv2}
+            # first-class: SURVEY 8d's ratio on the leg it describes, algorithmic and physical
+            roof['value_general_csr'] = K / e2
+            roof['frac_8d_general_csr'] = roof['plain_values']['frac']
+            roof['frac_moved_general_csr'] = roof['plain_values']['moved_frac']
+            roof['frac_physical_general_csr'] = roof['plain_values']['frac_physical']
+            if roof.get('stream_ceiling'):
+                roof['plain_values']['frac_of_pure_read_ceiling'] = (mv2 / ms2 * 1e-6) / roof['stream_ceiling']['pure_read_2GB_GBps']
             assert roof['plain_values']['frac'] <= 1.0
         if spmv:
             roof['spmv'] = spmv
         if multi:
             roof['multi_rank_schedule'] = multi
+        if rccl_leg:
+            roof['rccl_schedule'] = rccl_leg
         out = {
             'metric': f'{args.variant} iterations/sec (synthetic banded CSR, fp64)',
             'value': K / elapsed, 'unit': 'iters/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -540,9 +635,9 @@ def main():
                                        'that transfers to other matrices') if value_general is not None else None,
             'config': {'workload': wl['desc'], 'n': n, 'nnz': nnz_total, 'variant': args.variant,
                        'partition': f'row blocks x{world}' + (' (nnz-balanced)' if world > 1 and args.workload in ('s4', 'queen') else ''), 'rhs': 'x_true=1/sqrt(n), b=A x_true, x0=0',
-                       'residual_finite': finite, 'host_enqueue_us_per_step': t_enq / K * 1e6,
+                       'residual_finite': finite, 'fresh_session_before_timed_steps': True, 'host_enqueue_us_per_step': t_enq / K * 1e6,
                        'operator_setup_s': t_setup, 'prewarm_steps': PREWARM,
-                       'schedule_fallback': fallback,
+                       'schedule_fallback': fallback, 'rccl_ranks': (world if (rccl_leg and not rccl_leg.get('error')) or fallback else 0),
                        'schedule': {k: v for k, v in sched.items()}},
             'roofline': roof,
         }

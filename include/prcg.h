@@ -212,6 +212,9 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_PEER 16384  /* ... through the direct peer exchange (prcg_peer_setup / prcg_peer_connect): no collective in the loop */
 #define PRCG_SCHED_PATTERN 65536 /* ... window kernels over PATTERN tiles (constant-coefficient stencils): no per-nonzero stream at all --
                                     per tile one pattern record (slot offsets + values) and the rows' 16-bit slot masks */
+#define PRCG_SCHED_STREAM_STORES 131072 /* the one-launch iteration writes its row results with nontemporal stores (vectors far larger than the caches) */
+#define PRCG_SCHED_SELL_SORTED 262144  /* sliced rows with a sorting window wider than a slice (SELL-C-sigma: row lengths vary) */
+#define PRCG_SCHED_NT_LOADS 524288     /* sliced rows: value / column-code streams read with nontemporal loads (operator far larger than the Infinity Cache) */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */
 /* A preconditioner that is not a diagonal scaling: `fn(ctx, n, v, out)` must write M^-1 v to out (host buffers,

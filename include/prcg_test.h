@@ -28,6 +28,15 @@ int prcg_world_init(prcg_t* h, int rank, int nranks);
 int prcg_peer_selftest(prcg_t* h, int k, const double* rows2n, const double* slot5, double* sums5, double* ghost2g);
 
 
+/* ---- measurement (bench.py: roofline.stream_ceiling_GBps; SURVEY.md 8d: "also report a measured stream ceiling") ------
+ * What the memory system of the attached GPU delivers for a byte mix, with no arithmetic to speak of, over n_pairs
+ * 16-byte entries per array (scratch allocated and freed inside the call): mode 0 = pure read (8 loads of 16 B in flight
+ * per thread); 1 = the vector traffic of the one-launch pipelined iteration -- per row one pair read and rewritten in
+ * place, one pair read from one array and written to another (2 x 16 B in, 2 x 16 B out) -- with plain stores;
+ * 2 = the same with nontemporal stores (what the kernels use when the vectors exceed the Infinity Cache).
+ * gbytes_per_s: bytes moved / time between HIP events around `reps` launches on the handle's compute stream. */
+int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* gbytes_per_s);
+
 /* ---- host-only planning helpers (no GPU needed; used by the CPU test-suite) ------ */
 /* CSR-adaptive tiling of rows [0,n): consecutive rows are packed into tiles of at most
  * cap_nnz nonzeros / cap_rows rows; a row longer than cap_nnz gets a tile of its own.
@@ -80,18 +89,20 @@ int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices
                         int64_t mask_capacity, int64_t* counts_out);
 /* Sliced rows (lane-per-row kernels for operators with medium-length rows that are no window operators -- assembled FEM
  * matrices; csrc/prcg_plan.h: plan_sell): rows are cut into slices of up to 64 rows of one class (class-0 slices first, in
- * PROCESSING order); nonzero u of the row in lane l of a slice is val[voff + ((u/2)*64 + l)*2 + u%2] and
- * col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus the slice's smallest column); shorter rows are padded (value 0,
- * column 0; never multiplied).  sigma: sorting window in rows -- 64: a slice holds consecutive rows [first row, end row);
- * larger (SELL-C-sigma): every window of sigma consecutive rows of one class is sorted by descending length (stable)
- * before it is cut, lane l of a slice holds row rows_out[2 * (rows_off + l)] of length rows_out[2 * (rows_off + l) + 1]
- * (row -1, length 0 behind the last); 0: 64 while that pads by at most 6 %, else the
- * smallest of 256, 1024, 4096 whose padding stays within 4 % (else the one that pads least).  planes > 1: the class-0 table interleaves
- * groups of that many grid planes when the operator has a dominant far column offset (any table order is correct).
- * slices_out: 8 int32 per slice {first (smallest) row, that + rows, voff, coff, longest row, smallest column, rows_off
- * or -1, 0}; stats[0..8) = {class-0 slices, elements of val, elements of col16, padded nonzeros, sigma chosen, far
- * stride in rows (0: none), planes interleaved (0: row order), elements of rows}.  Returns the number of slices, 0 if
- * the operator does not qualify (a slice's columns span >= 65536, or padding beyond max_overhead x nnz), -needed if a
+ * PROCESSING order); stored position u of the row in lane l of a slice holds val[voff + ((u/2)*64 + l)*2 + u%2] and the
+ * 16-bit code col16[coff + ((u/8)*64 + l)*8 + u%8]: starting from the slice's `cbase`, every position moves the lane's
+ * running column by code - 16384 and -- unless the code is 0 or 65535 (skips: -16384 / +49151, no nonzero) -- names a
+ * nonzero at the column reached; shorter rows are padded (value 0, code 16384; never multiplied).
+ * sigma: sorting window in rows -- 64: a slice holds consecutive rows [first row, end row); larger (SELL-C-sigma): every
+ * window of sigma consecutive rows of one class is sorted by descending length (stable) before it is cut; slices of such
+ * windows, and slices with a row that needs skips, name their rows: lane l holds row rows_out[2 * (rows_off + l)] of STORED
+ * length rows_out[2 * (rows_off + l) + 1] (row -1, length 0 behind the last); 0: 64 while that pads by at most 6 %, else the
+ * smallest of 256, 1024, 4096 whose padding stays within 4 % (else the one that pads least).  planes > 1: the class-0 table
+ * interleaves groups of that many grid planes when the operator has a dominant far column offset (any table order is correct).
+ * slices_out: 8 int32 per slice {first (smallest) row, that + rows, voff, coff, longest stored row, cbase, rows_off or -1, 0};
+ * stats[0..9) = {class-0 slices, elements of val, elements of col16, padded nonzeros, sigma chosen, far stride in rows
+ * (0: none), planes interleaved (0: row order), elements of rows, column codes in use}.
+ * Returns the number of slices, 0 if the operator does not qualify (padding beyond max_overhead x nnz), -needed if a
  * capacity is too small, -1 on a bad argument.  What prcg_set_csr runs for rows of 24 nonzeros and more. */
 int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
                        double max_overhead, int sigma, int planes, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,

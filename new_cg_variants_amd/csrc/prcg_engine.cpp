@@ -142,8 +142,10 @@ struct prcg_handle {
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
     DevBuf sval, scol, sslices, srows;
     int sell_sigma_opt = 0;              // PRCG_SELL_SIGMA: sorting window of the sliced layout in rows (0: chosen by the planner)
-    int sell_planes_opt = 8;             // PRCG_SELL_PLANES: grid planes interleaved in the slice table (<= 1: row order)
-    int sell_nt = 0;                     // PRCG_SELL_NT=1: the value / column streams are read with nontemporal loads
+    int sell_planes_opt = 0;             // PRCG_SELL_PLANES: grid planes interleaved in the slice table (<= 1: row order, the default:
+                                         // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
+    int sell_nt = 0;                     // the value / code streams are read with nontemporal loads: chosen per operator in prcg_set_csr
+    int sell_nt_opt = -1;                // PRCG_SELL_NT=0|1 overrides
     int sell_sigma = 0, sell_planes = 0; // what the planner chose (prcg_schedule_info)
     int64_t sell_stride = 0;
     bool want_big = true;                // PRCG_WIN_BIG=0: short launches keep the small workgroups too
@@ -1261,8 +1263,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SWEEP_WAVES") h->sweep_max_waves = (v >= 64 && v <= 16384) ? (int)v : 6144;
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
-    else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 8;
-    else if (k == "PRCG_SELL_NT") h->sell_nt = v != 0;
+    else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 0;
+    else if (k == "PRCG_SELL_NT") { h->sell_nt_opt = v != 0; h->sell_nt = v != 0; }
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
     else if (k == "PRCG_DEFER_GRID_PER_CU") h->defer_per_cu = (v >= 1 && v <= 4) ? (int)v : 0;
@@ -1748,7 +1750,9 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         if (!sall.empty()) HIPCHK(h, hipMemcpy(h->sslices.p, sall.data(), sall.size() * sizeof(SellSlice), hipMemcpyHostToDevice));
         HIPCHK(h, h->srows.alloc((sp.rows.size() + 64) * sizeof(int32_t)));
         if (!sp.rows.empty()) HIPCHK(h, hipMemcpy(h->srows.p, sp.rows.data(), sp.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        h->sell_bytes = sp.padded_nnz * 10 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4;
+        // what a product reads of the operator: 8 B per (padded) value, 2 B per (padded) column code, the slice descriptors, and
+        // the row pointers (slices of consecutive rows) or the slices' (row, stored length) pairs
+        h->sell_bytes = sp.padded_nnz * 8 + sp.col_entries * 2 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4;
         h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows;
         sp = SellPlan{};
     }
@@ -1832,6 +1836,13 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
     h->gather_planned = false;
     h->stream_stores = h->stream_override >= 0 ? h->stream_override
                                                : ((int64_t)64 * n_rows + prcg_operator_bytes(h) > (int64_t)256 << 20);
+    // sliced rows with a sorting window: a slice's rows lie anywhere in the window, its 16-byte row results are PARTS of cache
+    // lines that the other slices of the window complete -- plain stores let the L2 merge them (nontemporal ones wrote 1.54 x the
+    // bytes: s4c 706 -> 675 us, profiles/r04_sweeps.md)
+    if (h->sell && h->sell_sigma > 64 && h->stream_override < 0) h->stream_stores = 0;
+    // ... and the value / code streams of an operator far larger than the Infinity Cache are read with nontemporal loads
+    // (s4b at 3.4 GB: 638 -> 610 us, s4c +4.6 %; at 1.3 GB -1 %)
+    if (h->sell && h->sell_nt_opt < 0) h->sell_nt = h->sell_bytes >= (int64_t)2000 << 20;
     return PRCG_OK;
 }
 
@@ -2061,6 +2072,31 @@ static int timed_product(prcg_t* h, int nc, const double* in, double* out, int r
 int prcg_spmv(prcg_t* h, const double* x, double* y, int reps, double* ms_avg) {
     if (!h) return PRCG_EINVAL;
     return timed_product(h, 1, x, y, reps, ms_avg);
+}
+
+int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* gbytes_per_s) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, n_pairs >= 1024 && mode >= 0 && mode <= 2 && reps >= 1 && gbytes_per_s, "prcg_stream_ceiling: bad argument");
+    HIPCHK(h, hipSetDevice(h->dev));
+    DevBuf a, b, c;
+    const size_t bytes = (size_t)n_pairs * 16;
+    HIPCHK(h, a.alloc(bytes));
+    HIPCHK(h, b.alloc(mode ? bytes : 64));
+    HIPCHK(h, c.alloc(mode ? bytes : 64));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_stream_probe(h->sc, mode, a.d(), b.d(), c.d(), (size_t)n_pairs);
+    HIPCHK(h, hipEventRecord(e0, h->sc));
+    for (int i = 0; i < reps; ++i) launch_stream_probe(h->sc, mode, a.d(), b.d(), c.d(), (size_t)n_pairs);
+    HIPCHK(h, hipEventRecord(e1, h->sc));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double moved = (double)bytes * (mode ? 4.0 : 1.0) * reps;
+    *gbytes_per_s = ms > 0.f ? moved / (ms * 1e-3) * 1e-9 : 0.0;
+    return PRCG_OK;
 }
 
 int prcg_spmv_ext(prcg_t* h, const double* x_ext, double* y) {
@@ -2459,6 +2495,8 @@ int prcg_schedule(const prcg_t* h) {
     return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) |
            (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
+           (h->stream_stores ? PRCG_SCHED_STREAM_STORES : 0) | ((h->sell && h->sell_sigma > 64) ? PRCG_SCHED_SELL_SORTED : 0) |
+           ((h->sell && h->sell_nt) ? PRCG_SCHED_NT_LOADS : 0) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_pat ? PRCG_SCHED_PATTERN : (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16)) | PRCG_SCHED_WINDOW
                    : (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0)));
@@ -2753,6 +2791,7 @@ int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices,
     if (stats) {
         stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz;
         stats[4] = sp.sigma; stats[5] = sp.stride_rows; stats[6] = sp.planes; stats[7] = (int64_t)sp.rows.size();
+        stats[8] = sp.col_entries;
     }
     if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity) ||
         (rows_out && (int64_t)sp.rows.size() > rows_capacity)) return -total;

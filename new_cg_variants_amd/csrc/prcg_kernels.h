@@ -311,11 +311,12 @@ int launch_win_cg_one(hipStream_t st, const WinDev& A, const WTile* tiles, int n
                       double* partials, double* coef_out, int per_cu);
 
 // ---- sliced rows: lane-per-row kernels for medium-length rows (prcg_sell.hip) -----------------
-// Planned on the host by plan_sell (prcg_plan.cpp): slices of up to 64 consecutive rows of one class; nonzero u of row
-// rb + lane at position (u, lane) of the slice -- val in chunks of two doubles, col16 (column - the slice's smallest
-// column) in chunks of four -- so that one wave instruction reads "nonzeros u.. of all 64 rows" fully coalesced.
-// Lossless re-layout of the caller's CSR arrays; the row lengths are read from indptr.  Slice descriptor: 8 int32
-// {first row, end row, offset of the slice in val, offset in col16, longest row, smallest column, 0, 0}.
+// Planned on the host by plan_sell (prcg_plan.h): slices of up to 64 rows of one class; stored position u of the row in lane
+// l at (u, l) of the slice -- val in chunks of two doubles, col16 in chunks of eight 16-bit column-DELTA codes (the lane's
+// running column moves by code - 16384 per position; codes 0 / 65535 are skips: no nonzero) -- so that one wave
+// instruction reads "positions u.. of all 64 rows" fully coalesced.  Lossless re-layout of the caller's CSR arrays.
+// Slice descriptor: 8 int32 {first (smallest) row, that + rows, offset of the slice in val, offset in col16, longest stored
+// row, smallest first column, first (row, stored length) pair in rows or -1, 0}.
 struct SellDev {
     const int* indptr;
     const double* val;
@@ -437,6 +438,9 @@ void launch_flag_send_tiles(hipStream_t st, void* wtiles, const void* tile_send,
 constexpr int kPubCopies = 64;
 constexpr int kPubDoubles = 8 * kPubCopies;
 void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value);
+// one launch of the streaming probes (prcg_stream_ceiling): mode 0 reads a[0..n_pairs) pairs; 1 / 2: a read and rewritten,
+// b read, c written (plain / nontemporal stores)
+void launch_stream_probe(hipStream_t st, int mode, double* a, double* b, double* c, size_t n_pairs);
 // one wave on `st` waits (bounded, ~2 ms) for the record to reach `want`; *err = 1 if it does not
 void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigned* err);
 

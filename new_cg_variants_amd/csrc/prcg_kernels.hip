@@ -1316,6 +1316,53 @@ __global__ __launch_bounds__(64) void k_probe_wait(const double* pub, unsigned w
         __builtin_amdgcn_s_sleep(16);
     if (!ok && threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- what the memory system delivers for the iteration's own byte mix (bench.py: roofline.stream_ceiling_GBps) ----
+// mode 0: pure 16-byte-per-lane read (8 loads in flight per thread); mode 1 / 2: per row one pair read and rewritten in
+// place, one pair read from one array and written to another -- 2 x 16 B in, 2 x 16 B out, the vector traffic of the
+// one-launch pipelined iteration with nothing else -- with plain (1) or nontemporal (2) stores.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_stream_read(const double2* __restrict__ a, size_t n2, double* out) {
+    double s = 0.0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + (UNROLL - 1) * stride < n2; i += UNROLL * stride) {
+        double2 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = a[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) s += v[u].x + v[u].y;
+    }
+    for (; i < n2; i += stride) { const double2 v = a[i]; s += v.x + v.y; }
+    if (s == 123.456) out[0] = s;                                           // (keeps the loads alive)
+}
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_stream_pairs(double2* __restrict__ xp, const double2* __restrict__ rs, double2* __restrict__ rsn, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* X = reinterpret_cast<d2*>(xp);
+    const d2* R = reinterpret_cast<const d2*>(rs);
+    d2* Rn = reinterpret_cast<d2*>(rsn);
+    for (; i < n2; i += UNROLL * stride) {
+        d2 x[UNROLL], r[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) if (i + u * stride < n2) { x[u] = X[i + u * stride]; r[u] = R[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) if (i + u * stride < n2) {
+            const d2 xo = x[u], ro = r[u];
+            const d2 xn = {xo.x + 0.5 * xo.y, ro.x + 0.25 * xo.y}, rn = {ro.x - 0.5 * ro.y, xo.y + 0.25 * ro.y};
+            if (NT) { __builtin_nontemporal_store(xn, X + i + u * stride); __builtin_nontemporal_store(rn, Rn + i + u * stride); }
+            else { X[i + u * stride] = xn; Rn[i + u * stride] = rn; }
+        }
+    }
+}
+void launch_stream_probe(hipStream_t st, int mode, double* a, double* b, double* c, size_t n_pairs) {
+    const dim3 grid(kMaxGridBlocks), block(256);
+    if (mode == 0) hipLaunchKernelGGL(k_stream_read<8>, grid, block, 0, st, reinterpret_cast<const double2*>(a), n_pairs, c);
+    else if (mode == 1) hipLaunchKernelGGL((k_stream_pairs<4, false>), grid, block, 0, st, reinterpret_cast<double2*>(a), reinterpret_cast<const double2*>(b), reinterpret_cast<double2*>(c), n_pairs);
+    else hipLaunchKernelGGL((k_stream_pairs<4, true>), grid, block, 0, st, reinterpret_cast<double2*>(a), reinterpret_cast<const double2*>(b), reinterpret_cast<double2*>(c), n_pairs);
+}
+
 void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigned* err) {
     hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, st, pub, want, err);
 }

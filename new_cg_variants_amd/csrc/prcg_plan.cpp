@@ -7,6 +7,8 @@
 #include <array>
 #include <map>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <unordered_map>
@@ -714,6 +716,14 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
                const SellOptions& opt, SellPlan& out) {
     out = SellPlan{};
     const int64_t nnz = indptr[n];
+    // a slice is as wide as its longest row and ONE wave walks it: an operator with a few rows far longer than the rest (the
+    // random-offset stand-in s4: one row of 46,694 nonzeros against a mean of 76) would end its launch on that one wave
+    // (s4: 4.97 ms against 1.05 ms on the CSR-adaptive kernels, which sum a long row with the whole wave) -- refused
+    {
+        int32_t longest = 0;
+        for (int64_t r = 0; r < n; ++r) longest = std::max(longest, indptr[r + 1] - indptr[r]);
+        if (longest > 1024 && (int64_t)longest * n > 16 * std::max<int64_t>(nnz, 1)) return false;
+    }
     // --- the sorting window (SELL-C-sigma): 64 (rows stay consecutive: coalesced row operands, the smallest gather footprint)
     // while that pads by at most opt.target64; else the smallest of 256, 1024, 4096 whose padding is within opt.target of
     // the nonzeros, else the one that pads least
@@ -728,11 +738,23 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     }
     if (sigma < 64) sigma = 64;
     out.sigma = sigma;
-    // pass 1: slices, widths, offsets
+    // pass 1: slices, widths, offsets.  A row's columns are stored as 16-bit DELTAS (prcg_plan.h); a gap too wide for one
+    // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips
     std::vector<SellSlice> all;
     std::vector<uint8_t> cls_of;
-    std::vector<int32_t>& perm = out.rows;        // every slice's (row, length) pairs in lane order (sigma > 64), 64 pairs per slice
+    std::vector<int32_t>& perm = out.rows;        // (row, stored length) pairs in lane order, 64 pairs per slice that has them
     std::vector<int32_t> run;
+    auto skips_of = [&](int32_t row, int32_t base) {
+        int sk = 0;
+        int64_t prev = base;
+        for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q) {
+            int64_t dlt = (int64_t)indices[q] - prev;
+            if (dlt > kSellDeltaMax) sk += (int)((dlt - kSellDeltaMax + kSellSkipFwd - 1) / kSellSkipFwd);
+            else if (dlt < kSellDeltaMin) sk += (int)((kSellDeltaMin - dlt + kSellSkipBack - 1) / kSellSkipBack);
+            prev = indices[q];
+        }
+        return sk;
+    };
     int64_t voff = 0, coff = 0, r = 0;
     while (r < n) {
         const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
@@ -742,37 +764,44 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         sell_run_order(indptr, r, e, sigma, run);
         for (size_t i = 0; i < run.size(); i += 64) {
             const size_t je = std::min(run.size(), i + 64);
-            int width = 0;
-            int32_t cmin = INT32_MAX, cmax = -1, rmin = INT32_MAX;
+            int32_t rmin = INT32_MAX, cbase = INT32_MAX;
             for (size_t j = i; j < je; ++j) {
-                const int32_t row = run[j];
-                rmin = std::min(rmin, row);
-                width = std::max(width, indptr[row + 1] - indptr[row]);
-                for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q) { cmin = std::min(cmin, indices[q]); cmax = std::max(cmax, indices[q]); }
+                rmin = std::min(rmin, run[j]);
+                if (indptr[run[j] + 1] > indptr[run[j]]) cbase = std::min(cbase, indices[indptr[run[j]]]);
             }
-            if (cmax < 0) cmin = 0;
-            if (cmax >= 0 && cmax - cmin >= 65536) return false;
-            const int w2 = (width + 1) & ~1, w4 = (width + 3) & ~3;
-            if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w4 * 64 >= (int64_t)INT32_MAX - 4096) return false;
+            if (cbase == INT32_MAX) cbase = 0;
+            int width = 0;
+            bool any_skip = false;
+            for (size_t j = i; j < je; ++j) {
+                const int sk = skips_of(run[j], cbase);
+                any_skip |= sk > 0;
+                width = std::max(width, indptr[run[j] + 1] - indptr[run[j]] + sk);
+            }
+            const int w2 = (width + 1) & ~1, w8 = (width + 7) & ~7;
+            if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w8 * 64 >= (int64_t)INT32_MAX - 4096) return false;
             int rows_off = -1;
-            if (sigma > 64) {
+            if (sigma > 64 || any_skip) {
                 rows_off = (int)(perm.size() / 2);
-                for (size_t j = i; j < je; ++j) { perm.push_back(run[j]); perm.push_back(indptr[run[j] + 1] - indptr[run[j]]); }
+                for (size_t j = i; j < je; ++j) { perm.push_back(run[j]); perm.push_back(indptr[run[j] + 1] - indptr[run[j]] + skips_of(run[j], cbase)); }
                 for (size_t j = je; j < i + 64; ++j) { perm.push_back(-1); perm.push_back(0); }
             }
-            // (sigma == 64: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
-            all.push_back(SellSlice{sigma > 64 ? rmin : run[i], (sigma > 64 ? rmin : run[i]) + (int)(je - i), (int)voff, (int)coff, width, cmin, rows_off, 0});
+            // (rows_off < 0: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
+            const int first = rows_off < 0 ? run[i] : rmin;
+            all.push_back(SellSlice{first, first + (int)(je - i), (int)voff, (int)coff, width, cbase, rows_off, 0});
             cls_of.push_back(cls);
             voff += (int64_t)w2 * 64;
-            coff += (int64_t)w4 * 64;
+            coff += (int64_t)w8 * 64;
         }
         r = e;
     }
+    if (getenv("PRCG_PLAN_DEBUG"))
+        fprintf(stderr, "plan_sell: sigma %d, %zu slices, padded / nnz = %.4f\n", sigma, all.size(), (double)voff / (double)std::max<int64_t>(nnz, 1));
     if ((double)voff > opt.max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
     out.padded_nnz = voff;
-    // pass 2: fill (padding: value 0, column 0)
+    out.col_entries = coff;
+    // pass 2: fill (padding: value 0, delta 0 -- the column stays where it is)
     out.val.assign((size_t)voff + 1024, 0.0);
-    out.col.assign((size_t)coff + 1024, 0);
+    out.col.assign((size_t)coff + 1024, (uint16_t)kSellDeltaBias);
     unsigned nt = std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > 16) nt = 16;
@@ -784,9 +813,17 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
                 const int row = sl.rows_off < 0 ? sl.rb + l : perm[2 * ((size_t)sl.rows_off + l)];
                 const int32_t lo = indptr[row];
                 const int len = indptr[row + 1] - lo;
-                for (int u = 0; u < len; ++u) {
-                    out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + u];
-                    out.col[(size_t)sl.coff + ((size_t)(u >> 2) * 64 + l) * 4 + (u & 3)] = (uint16_t)(indices[lo + u] - sl.cbase);
+                int64_t prev = sl.cbase;
+                int u = 0;                                  // stored position
+                auto put = [&](uint16_t code) { out.col[(size_t)sl.coff + ((size_t)(u >> 3) * 64 + l) * 8 + (u & 7)] = code; };
+                for (int q = 0; q < len; ++q) {
+                    int64_t dlt = (int64_t)indices[lo + q] - prev;
+                    while (dlt > kSellDeltaMax) { put(kSellCodeSkipFwd); ++u; prev += kSellSkipFwd; dlt -= kSellSkipFwd; }
+                    while (dlt < kSellDeltaMin) { put(kSellCodeSkipBack); ++u; prev -= kSellSkipBack; dlt += kSellSkipBack; }
+                    put((uint16_t)(dlt + kSellDeltaBias));
+                    out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + q];
+                    ++u;
+                    prev = indices[lo + q];
                 }
             }
         }

@@ -121,18 +121,30 @@ bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const in
                       SweepPlan& out);
 
 // ---- sliced rows (prcg_sell.hip) ---------------------------------------------------------------
-// Slices of up to 64 rows of one class (interior slices first).  Within a slice of width w (its longest row), nonzero u
-// of the row in lane l is val[voff + ((u/2)*64 + l)*2 + u%2] and col16[coff + ((u/4)*64 + l)*4 + u%4] (column minus the
-// slice's smallest column); shorter rows are padded with value 0 / column 0 (never multiplied: the kernels mask by the
-// row length).  The arrays end with a whole trip of padding.
-// Which rows: with a sorting window of 64 (SellPlan::sigma) the slice holds the consecutive rows [rb, re) and
-// rows_off = -1; with a larger window (SELL-C-sigma: every window of sigma consecutive rows of one class is sorted by
-// descending row length -- stable -- before it is cut into slices, so that rows of similar length share a slice and
-// the padding stays small for operators whose row lengths vary) lane l holds row rows[2 * (rows_off + l)], whose length
-// is rows[2 * (rows_off + l) + 1] (64 pairs per slice; row -1, length 0 behind the last), and rb is the smallest of them.  Every row is still summed left to right
+// Slices of up to 64 rows of one class (interior slices first).  Within a slice of width w (its longest STORED row),
+// stored position u of the row in lane l holds the value val[voff + ((u/2)*64 + l)*2 + u%2] and the 16-bit code
+// col16[coff + ((u/8)*64 + l)*8 + u%8].  The codes of a row are column DELTAS: starting from the slice's `cbase` (the
+// smallest first column of its rows), every position moves the lane's running column by code - 16384 and -- unless the
+// code is 0 or 65535 -- names a nonzero at the column reached.  Codes 0 / 65535 are SKIPS (move by -16384 / +49151, no
+// nonzero, value slot unused): a gap between consecutive columns of a row (or an unsorted row's step back) wider than
+// one code costs the row extra stored positions, so any operator can be encoded, and one whose rows' sorted columns lie
+// within 49,150 of each other -- an assembled FEM matrix of any size: a grid plane of 111 x 111 nodes x 3 is 37,000 --
+// needs none.  (A fixed 16-bit offset from a per-slice base, round 3's encoding, refused every operator whose slices
+// span 65,536 columns: Queen_4147's size.)  Shorter rows are padded with value 0 / code 16384 (column stays; never
+// multiplied: the kernels mask by the stored length).  A TRIP (positions 8 j .. 8 j + 7) is what the wave reads with four
+// 16-byte value loads and one 16-byte code load per lane.  The arrays end with a whole trip of padding.
+// Which rows: rows_off = -1: the slice holds the consecutive rows [rb, re), their stored lengths are the row pointers'
+// (no skips).  Otherwise lane l holds row rows[2 * (rows_off + l)] with stored length rows[2 * (rows_off + l) + 1]
+// (64 pairs per slice; row -1, length 0 behind the last) and rb is the smallest of them: slices of a sorting window wider
+// than 64 (SELL-C-sigma: every window of sigma consecutive rows of one class is sorted by descending row length --
+// stable -- before it is cut into slices, so that rows of similar length share a slice and the padding stays small for
+// operators whose row lengths vary), and slices with a row that needs skips.  Every row is still summed left to right
 // by ONE lane: the products are scipy's bit for bit whatever the order.
-// Returns false (nothing built) if the operator does not qualify: a slice's columns span 65536 or more, or padding
-// would exceed `max_overhead` x nnz.
+// Returns false (nothing built) if the operator does not qualify: padding would exceed `max_overhead` x nnz.
+constexpr int kSellDeltaBias = 16384;
+constexpr int kSellDeltaMin = -16383, kSellDeltaMax = 49150;       // deltas one code can hold (codes 1 .. 65534)
+constexpr int kSellSkipFwd = 49151, kSellSkipBack = 16384;         // what the skip codes 65535 / 0 move the column by
+constexpr uint16_t kSellCodeSkipFwd = 65535, kSellCodeSkipBack = 0;
 struct SellSlice { int rb, re, voff, coff, width, cbase, rows_off, flags; };
 static_assert(sizeof(SellSlice) == 32, "the kernels read a slice descriptor as two int4");
 struct SellOptions {
@@ -146,7 +158,8 @@ struct SellPlan {
     std::vector<SellSlice> s0, s1;       // interior slices (in PROCESSING order), slices touching ghost columns
     std::vector<double> val;
     std::vector<uint16_t> col;
-    std::vector<int32_t> rows;           // sigma > 64: the slices' (row, length) pairs in lane order
+    std::vector<int32_t> rows;           // (row, stored length) pairs in lane order of the slices that have them
+    int64_t col_entries = 0;             // entries of col in use
     int64_t padded_nnz = 0;
     int sigma = 64;
     int64_t stride_rows = 0;             // the operator's dominant far column offset (a grid plane), 0: none found

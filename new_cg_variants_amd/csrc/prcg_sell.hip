@@ -38,28 +38,26 @@ __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) 
     return d;
 }
 
-// 8 nonzeros of every row of the slice: four value chunks (2 doubles per lane each), two column chunks (4 x u16)
-struct Trip { d2_t v[4]; uint2 c[2]; };
+// 8 stored positions of every row of the slice: four value chunks (2 doubles per lane each), one chunk of eight 16-bit
+// column-delta codes
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+struct Trip { d2_t v[4]; u4_t c; };
 
 template <bool NT>
 __device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip& T) {
-    // chunk index of nonzero u: values u / 2, columns u / 4.  The last trip of a slice may reach past its width: those
-    // chunks belong to the following slice (or to the whole trip of padding the arrays end with, see plan_sell) and are
-    // never used -- the row walk masks by the row's length
+    // chunk index of position u: values u / 2, codes u / 8.  Value chunks past the slice's width (the slice's last trip) belong
+    // to the following slice: the lane reads its first chunk of the trip again instead (no branch around a load -- the
+    // compiler's wait counts at a join assume the worst -- and no bytes from memory that nobody uses: 7 % of the stream)
     const int64_t vb = (int64_t)d.voff + ((int64_t)(u0 >> 1) * 64 + lane) * 2;
-    const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 2) * 64 + lane) * 4;
+    const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 3) * 64 + lane) * 8;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const d2_t* q = reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)k * 128);
+        const int kk = (u0 + 2 * k < d.width) ? k : 0;                      // wave-uniform select
+        const d2_t* q = reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)kk * 128);
         T.v[k] = NT ? __builtin_nontemporal_load(q) : *q;
     }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-        const u2_t* q = reinterpret_cast<const u2_t*>(A.col16 + cb + (int64_t)k * 256);
-        const u2_t c = NT ? __builtin_nontemporal_load(q) : *q;
-        T.c[k] = make_uint2(c.x, c.y);
-    }
+    const u4_t* q = reinterpret_cast<const u4_t*>(A.col16 + cb);
+    T.c = NT ? __builtin_nontemporal_load(q) : *q;
 }
 
 // the row lane `lane` of slice d holds and its length: consecutive rows (lengths from the row pointers), or -- sorting
@@ -134,25 +132,32 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
             if constexpr (!epi_recompute(EPI)) { q.w = fr.W[rr]; if constexpr (epi_prec(EPI)) q.wt = fr.WT[rr]; }
         }
         V sum; vzero(sum);
+        int colacc = d.cbase;
         for (int u0 = 0; u0 < d.width; u0 += 8) {                            // wave-uniform trip count
             // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
             const bool more = u0 + 8 < d.width;
             if (more) load_trip<NT>(A, d, u0 + 8, lane, nxt);
             else if (t + W < nslices) load_trip<NT>(A, dn, 0, lane, nxt);
-            int col[8];
-            col[0] = cur.c[0].x & 0xffffu; col[1] = cur.c[0].x >> 16; col[2] = cur.c[0].y & 0xffffu; col[3] = cur.c[0].y >> 16;
-            col[4] = cur.c[1].x & 0xffffu; col[5] = cur.c[1].x >> 16; col[6] = cur.c[1].y & 0xffffu; col[7] = cur.c[1].y >> 16;
+            // the lane's running column: every position moves it by code - 16384; codes 0 and 65535 only move it (skips)
+            int code[8], col[8];
+            code[0] = cur.c.x & 0xffffu; code[1] = cur.c.x >> 16; code[2] = cur.c.y & 0xffffu; code[3] = cur.c.y >> 16;
+            code[4] = cur.c.z & 0xffffu; code[5] = cur.c.z >> 16; code[6] = cur.c.w & 0xffffu; code[7] = cur.c.w >> 16;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { colacc += code[k] - 16384; col[k] = colacc; }
             V g[8];
 #pragma unroll
-#ifdef PRCG_SELL_DIAG_NOGATHER      // TIMING ONLY (wrong products): every gather hits the same 64 entries -- what the kernel costs without gather misses
+#if defined(PRCG_SELL_DIAG_NOGATHER) && PRCG_SELL_DIAG_NOGATHER == 2   // TIMING ONLY (wrong products): no gather instruction at all
+            for (int k = 0; k < 8; ++k) { g[k] = own; if constexpr (NV == 2) g[k].x += (double)col[k]; else g[k] += (double)col[k]; }
+#elif defined(PRCG_SELL_DIAG_NOGATHER)      // TIMING ONLY (wrong products): every gather hits the same 64 entries -- what the kernel costs without gather misses
             for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + (col[k] & 63)];
 #else
-            for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + col[k]];         // (padding columns are 0: a valid entry, never used)
+            for (int k = 0; k < 8; ++k) g[k] = X[col[k]];                   // (padding positions stay at the row's last column, a skip lands between two
+                                                                            //  of the row's columns: valid entries, never used)
 #endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const double a = (k & 1) ? cur.v[k >> 1].y : cur.v[k >> 1].x;
-                if (u0 + k < len) vacc(sum, vmul(a, g[k]));                  // left to right, product rounded, then added
+                if (u0 + k < len && (unsigned)(code[k] - 1) < 65534u) vacc(sum, vmul(a, g[k]));   // left to right, product rounded, then added
             }
             cur = nxt;
         }
@@ -193,7 +198,13 @@ int sell_grid(K kernel, int nslices, int per_cu) {
     const int cus = cached % 1024;
     if (per_cu >= 1 && per_cu <= 8) occ = per_cu;
     int g = (nslices + kWaves - 1) / kWaves;
-    if (g > occ * cus) g = occ * cus;
+    if (g > occ * cus) {
+        // every wave the same number of slices: the fewest rounds the resident waves need, then the fewest waves for
+        // those rounds (a last round that only a third of the waves take costs the launch 2 % at 30 rounds)
+        const int waves = occ * cus * kWaves;
+        const int rounds = (nslices + waves - 1) / waves;
+        g = ((nslices + rounds - 1) / rounds + kWaves - 1) / kWaves;
+    }
     if (g < 1) g = 1;
     return g;
 }

@@ -228,7 +228,8 @@ class DeviceCSR:
         return {'fused': bool(s & 1), 'small': bool(s & 2), 'comm': bool(s & 4), 'gather': bool(s & 8),
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
                 'col_bytes': 0 if s & 65536 else (1 if s & 64 else (2 if s & 128 else 4)), 'tile_steps': (s >> 8) & 15,
-                'pattern': bool(s & 65536), 'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384), 'sliced_rows': bool(s & 32768)}
+                'pattern': bool(s & 65536), 'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384), 'sliced_rows': bool(s & 32768),
+                'stream_stores': bool(s & 131072), 'sorted_windows': bool(s & 262144), 'nt_loads': bool(s & 524288)}
 
     def layout(self):
         """Diagnostic (prcg.h: prcg_debug_layout): what the summation order of the one-launch iteration's inner
@@ -284,6 +285,14 @@ class DeviceCSR:
 
     def set_profiling(self, stride):
         self._check(self._lib.prcg_set_profiling(self._h, int(stride)))
+
+    def stream_ceiling(self, n_pairs, mode, reps=20):
+        """GB/s the memory system delivers for a byte mix over arrays of n_pairs 16-byte entries (prcg_test.h:
+        prcg_stream_ceiling): mode 0 pure read, 1 = 2 x 16 B in + 2 x 16 B out per row (the one-launch iteration's vector
+        traffic) with plain stores, 2 with nontemporal stores."""
+        g = C.c_double()
+        self._check(self._lib.prcg_stream_ceiling(self._h, int(n_pairs), int(mode), int(reps), C.byref(g)))
+        return float(g.value)
 
     def timings(self):
         t = L.Timings()

@@ -236,6 +236,15 @@ WORKLOADS = {
                    make=lambda rows=None: banded_ex2b(1_250_000, 7, rows=rows)),
     's2_8th': dict(desc='one eighth of S2: 7-pt Laplacian 216 x 216 x 27 (n=1,259,712)', n=216 * 216 * 27,
                    make=lambda rows=None: laplace_3d(216, 216, 27, rows)),
+    # one rank's share of a 2- / 4-GPU run (bench.py: roofline.multi_rank_schedule)
+    's3_half': dict(desc='one half of S3: ex2b banded n=5e6, 15 diagonals', n=5_000_000,
+                    make=lambda rows=None: banded_ex2b(5_000_000, 7, rows=rows)),
+    's3_quarter': dict(desc='one quarter of S3: ex2b banded n=2.5e6, 15 diagonals', n=2_500_000,
+                       make=lambda rows=None: banded_ex2b(2_500_000, 7, rows=rows)),
+    's2_half': dict(desc='one half of S2: 7-pt Laplacian 216 x 216 x 108 (n=5,038,848)', n=216 * 216 * 108,
+                    make=lambda rows=None: laplace_3d(216, 216, 108, rows)),
+    's2_quarter': dict(desc='one quarter of S2: 7-pt Laplacian 216 x 216 x 54 (n=2,519,424)', n=216 * 216 * 54,
+                       make=lambda rows=None: laplace_3d(216, 216, 54, rows)),
     's4': dict(desc='S4 stand-in for Queen_4147: irregular symmetric SPD, n=1e6, log-normal row lengths (mean ~76, max 2000), reach 50000, seed 0',
                n=1_000_000, make=lambda rows=None: _row_slice(irregular_standin(1_000_000), rows)),
     's4b': dict(desc='FEM-like stand-in for Queen_4147 at its size: 3 dof x 27-point coupling on 111^3 nodes (n=4,102,893, nnz=326,382,219, <= 81 nnz/row)',

@@ -379,8 +379,8 @@ def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8):
     indices = np.ascontiguousarray(A.indices, dtype=np.int32)
     data = np.ascontiguousarray(A.data, dtype=np.float64)
     rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
-    stats = np.zeros(8, dtype=np.int64)
-    cap = n // 64 + 8 + (0 if rc is None else int(np.count_nonzero(np.diff(rc.astype(np.int8)))) + 2)
+    stats = np.zeros(10, dtype=np.int64)
+    cap = n // 60 + 64 + (0 if rc is None else int(np.count_nonzero(np.diff(rc.astype(np.int8)))) + 2)
     slices = np.zeros((cap, 8), dtype=np.int32)
     arr_cap = int(max_overhead * A.nnz * 1.3) + 64 * 130 * 4 + 4096
     val = np.zeros(arr_cap)
@@ -403,7 +403,7 @@ def slice_rows(sl, rows):
     return [(int(r), int(ln)) for r, ln in ent[:k]]
 
 
-@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256'])
+@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256', 'wide_gaps'])
 def test_sliced_row_layout_holds_exactly_the_matrix(name):
     """Host planner of the lane-per-row kernels (prcg_plan.cpp: plan_sell): every row in exactly one slice (classes apart,
     class 0 first), and reading the re-laid arrays back with the kernel's index formula gives the caller's CSR rows,
@@ -429,6 +429,19 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
     elif name.startswith('irregular'):
         A = problems.fem_irregular_3d(11)
         sigma = 256 if name.endswith('256') else 0
+    elif name == 'wide_gaps':
+        # rows whose consecutive columns lie up to 200,000 apart, unsorted in places: gaps beyond one 16-bit delta code cost skip positions
+        n, nr = 300_000, 2000
+        rows_c = []
+        for i in range(nr):
+            c0 = int(rng.integers(0, 40_000))
+            c = np.concatenate([c0 + np.sort(rng.choice(3000, size=24, replace=False)) + off for off in (0, 120_000, 255_000)])
+            if i % 97 == 0:
+                c[[5, 40]] = c[[40, 5]]                    # an unsorted row: one step back by ~120,000, one forward
+            rows_c.append(c)
+        indptr = np.arange(nr + 1, dtype=np.int32) * 72
+        A = sp.csr_matrix((rng.standard_normal(72 * nr), np.concatenate(rows_c).astype(np.int32), indptr), shape=(nr, n))
+        A.has_sorted_indices = False
     else:
         full = problems.fem_like_3d(10, 3)
         A, ghost_ids = partition.localize(full[900:2100], 900, 2100)
@@ -448,27 +461,39 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
         rb, re, voff, coff, width, cbase, rows_off, _ = sl
         assert 0 < re - rb <= 64
         lanes = slice_rows(sl, rows)
-        assert (rows_off < 0) == (sig == 64)
+        assert rows_off >= 0 or sig == 64
         rws = np.array([r for r, _ in lanes])
         seen[rws] += 1
         if row_class is not None:
             assert np.all(row_class[rws] == (si >= stats[0]))
-        assert width == lens_all[rws].max()
         if sig > 64:
             assert rws.max() // sig == rws.min() // sig or row_class is not None      # rows of ONE sorting window
             assert np.all(np.diff(lens_all[rws]) <= 0)                                # longest first
+        stored_max = 0
         for lane, (row, ln) in enumerate(lanes):
             lo, hi = A.indptr[row], A.indptr[row + 1]
-            assert ln is None or ln == hi - lo
-            u = np.arange(hi - lo)
+            stored = (hi - lo) if ln is None else ln
+            stored_max = max(stored_max, stored)
+            u = np.arange(stored)
             vi = voff + ((u >> 1) * 64 + lane) * 2 + (u & 1)
-            ci = coff + ((u >> 2) * 64 + lane) * 4 + (u & 3)
-            assert np.array_equal(val[vi].view(np.uint64), A.data[lo:hi].view(np.uint64))
-            assert np.array_equal(col[ci].astype(np.int64) + cbase, A.indices[lo:hi])
-            used_v[vi] = True
+            ci = coff + ((u >> 3) * 64 + lane) * 8 + (u & 7)
+            # decode as the kernel does: a running column moved by code - 16384 per position; codes 0 / 65535 name no nonzero
+            code = col[ci].astype(np.int64)
+            running = cbase + np.cumsum(code - 16384)
+            real = (code != 0) & (code != 65535)
+            assert real.sum() == hi - lo and (ln is not None or real.all())
+            assert np.array_equal(running[real], A.indices[lo:hi])
+            assert np.array_equal(val[vi][real].view(np.uint64), A.data[lo:hi].view(np.uint64))
+            used_v[vi[real]] = True
+            # behind the row: code 16384 (the column stays), up to the slice's width
+            tail = np.arange(stored, (width + 7) // 8 * 8)
+            assert np.all(col[coff + ((tail >> 3) * 64 + lane) * 8 + (tail & 7)] == 16384)
+        assert width == stored_max
     assert np.all(seen == 1)
     assert np.all(val[:int(stats[1])][~used_v] == 0.0)
     assert stats[3] <= 1.25 * max(A.nnz, 1)
+    if name == 'wide_gaps':
+        assert any(sl[6] >= 0 for sl in slices)          # some rows needed skips: their slices name rows and stored lengths
     if stats[6] == 0:
         for part in (slices[:stats[0]], slices[stats[0]:]):
             assert np.all(np.diff(part[:, 0]) > 0) or sig > 64
@@ -513,7 +538,8 @@ def test_sliced_rows_refuse_wide_and_ragged_operators():
     lens = np.full(n, 30)
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     wide = sp.csr_matrix((np.ones(indptr[-1]), rng.integers(0, n, size=indptr[-1]).astype(np.int32), indptr), shape=(n, n))
-    assert plan_sell(wide)[0] == 0                       # a slice's columns span the whole matrix: no 16-bit offsets
+    assert plan_sell(wide)[0] == 0                       # columns all over the matrix: a position of 64 rows spans more than 16 bits, the
+                                                         # slices would get a few rows each -- and pad the other lanes: refused
     lens = rng.integers(0, 100, size=4000)
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     r = np.repeat(np.arange(4000), lens)

@@ -399,7 +399,7 @@ def test_s3_full_size_row_blocks_in_threads():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workload,nranks,variant', [('s2', 4, 'PIPE_PR'), ('s2', 2, 'HS'), ('s4b', 3, 'PIPE_PR')])
+@pytest.mark.parametrize('workload,nranks,variant', [('s2', 4, 'PIPE_PR'), ('s2', 2, 'HS'), ('s4b_80', 3, 'PIPE_PR')])
 def test_full_size_stencil_and_fem_row_blocks_in_threads(workload, nranks, variant):
     """The other two multi-GPU configurations of BASELINE.json at full size, cut into row blocks whose ranks run in
     threads on ONE GPU: S2 (7-point Laplacian 216^3; blocks of whole grid planes, halo = one 216^2 plane per side =

@@ -270,10 +270,10 @@ def test_s2_full_size(amd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workload', ['s4', 's4b'])
+@pytest.mark.parametrize('workload', ['s4', 's4b_80', 's4b', 's4c'])
 def test_irregular_standins_at_bench_size(amd, workload):
-    """BASELINE.json configs[4] (Queen_4147, irregular degrees) cannot be fetched: its two labelled stand-ins
-    at the size bench.py --workload s4 / s4b runs them.  SpMV bit-exact on rows that fit a tile, rows summed
+    """BASELINE.json configs[4] (Queen_4147, irregular degrees) cannot be fetched: its labelled stand-ins at the size
+    bench.py --workload s4 / s4b / s4c runs them (s4b, s4c: Queen_4147's own size, 4.1 M rows; s4b_80: rounds 2-3).  SpMV bit-exact on rows that fit a tile, rows summed
     by a whole wave within 1e-14 * sum|a x|; the nnz-balanced 8-way row-block split (what 8 ranks would own)
     reassembles the global product on the device."""
     P, part = amd['problems'], amd['partition']
