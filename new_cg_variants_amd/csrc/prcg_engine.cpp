@@ -797,7 +797,10 @@ int iterate_pipe_fused_comm(prcg_t* h, int k) {
     f.wt = (!rec && h->prec) ? h->wt.d() : nullptr;
     f.dots_prev = dots_at(h, k - 1); f.coef_out = coef_at(h, k); f.partials = part_out;
     f.meurant = meurant(h->variant); f.recompute_w = rec;
-    f.stream_stores = h->stream_stores;
+    // (the deferred form gains nothing from streaming stores where the plain schedule gains 20 % -- S3 on one rank 143.7 against
+    //  142.7 us -- and loses 13 % where the vectors just exceed the Infinity Cache -- one half of S3: 78.1 against 68.0 us;
+    //  profiles/r04_sweeps.md: plain stores unless PRCG_STREAM_STORES=1 asks)
+    f.stream_stores = h->stream_override > 0 ? 1 : 0;
     f.prev = FusedPrev{};
     f.prev.pub = h->pub.d(); f.prev.want = (unsigned)(k - 1); f.prev.err = static_cast<unsigned*>(h->pub_err.p);
     f.deferred = 1;

@@ -11,13 +11,17 @@ from new_cg_variants_amd.device import DeviceCSR
 
 args = sys.argv[1:]
 wl = P.WORKLOADS[args[0]]
-iters, warm, variant = 100, 30, 'PIPE_PR'
+iters, warm, variant, prof, prewarm = 100, 30, 'PIPE_PR', 0, 0
 cfgs = []
 for a in args[1:]:
     if a.startswith('iters='):
         iters = int(a[6:])
     elif a.startswith('warm='):
         warm = int(a[5:])
+    elif a.startswith('prof='):
+        prof = int(a[5:])
+    elif a.startswith('prewarm='):
+        prewarm = int(a[8:])
     elif a.startswith('variant='):
         variant = a[8:]
     else:
@@ -31,8 +35,12 @@ for knobs in cfgs:
     t0 = time.perf_counter()
     op = DeviceCSR(A, knobs=knobs)
     setup = time.perf_counter() - t0
+    if prewarm:
+        op.begin(getattr(L, variant), b, x0, prewarm + 1); op.iterate(prewarm); op.sync()
     op.begin(getattr(L, variant), b, x0, warm + iters + 2)
     op.iterate(warm); op.sync()
+    if prof:
+        op.set_profiling(prof)
     t0 = time.perf_counter(); op.iterate(iters); op.sync(); dt = time.perf_counter() - t0
     s = op.schedule()
     opb = op.operator_bytes()

@@ -1,5 +1,5 @@
 """One rank's share of S3 on 8 GPUs (n = 1.25e6, loopback halo) on ONE GPU: us per iteration of the plain one-launch
-schedule and of the multi-rank schedules (direct peer exchange; RCCL chains).  usage: slice_comm_time.py [KNOB=val ...]"""
+schedule and of the multi-rank schedules (direct peer exchange; RCCL chains).  usage: slice_comm_time.py [n=rows] [only=plain|nohalo|halo] [KNOB=val ...]"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ from new_cg_variants_amd.device import DeviceCSR
 
 knobs = dict(kv.split('=') for kv in sys.argv[1:])
 only = knobs.pop('only', None)        # only=plain | nohalo | halo: just that configuration (for a kernel trace)
-A = P.banded_ex2b(1_250_000, 7); n = A.shape[0]
+n_rows = int(knobs.pop('n', 1_250_000))   # n=5000000: one half of S3
+A = P.banded_ex2b(n_rows, 7); n = A.shape[0]
 b, x0, xt = P.reference_rhs(A, n)
 A_loop, halo, moved = partition.loopback_problem(A, 7)
 
@@ -20,7 +21,7 @@ def uid():
     return u.tobytes()
 
 
-def run(name, op, iters=1200):
+def run(name, op, iters=600):
     op.begin(L.PIPE_PR, b, x0, iters + 401); s = op.schedule()
     op.iterate(400); op.sync()
     t0 = time.perf_counter(); op.iterate(iters); tq = time.perf_counter() - t0; op.sync(); dt = time.perf_counter() - t0
@@ -39,7 +40,7 @@ if only in (None, 'halo'):
     op = DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=knobs)
     partition.connect_peer_exchange(op, 0, lambda o: [o])
     run('loopback halo, peer exchange', op)
-if only is None:
+if only is None and n_rows <= 1_250_000:
     run('loopback halo, RCCL one-launch', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='1')))
 if only is None:
     run('loopback halo, RCCL two-kernel', DeviceCSR(A_loop, comm_init=(0, 1, uid(), L.default_rccl_path()), halo=halo, knobs=dict(knobs, PRCG_FUSED_COMM='0')))
