@@ -11,7 +11,7 @@ CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iin
 TRANSPORT := tests/transport/libthreads_ccl.so
 # ... and one that connects ranks living in separate PROCESSES that share one GPU (the driver's launch shape, rehearsed on one GPU)
 TRANSPORT_P := tests/transport/libprocs_ccl.so
-OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_sell.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
+OBJS := $(CSRC)/prcg_kernels.o $(CSRC)/prcg_win.o $(CSRC)/prcg_sell.o $(CSRC)/prcg_medium.o $(CSRC)/prcg_engine.o $(CSRC)/prcg_plan.o $(CSRC)/prcg_rccl.o
 
 all: $(OUT) $(TRANSPORT) $(TRANSPORT_P)
 
@@ -22,6 +22,9 @@ $(CSRC)/prcg_win.o: $(CSRC)/prcg_win.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_dev
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_sell.o: $(CSRC)/prcg_sell.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
+	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/prcg_medium.o: $(CSRC)/prcg_medium.hip $(CSRC)/prcg_kernels.h $(CSRC)/prcg_device.hpp
 	$(HIPCC) --offload-arch=$(ARCH) $(CXXFLAGS) -c $< -o $@
 
 $(CSRC)/prcg_engine.o: $(CSRC)/prcg_engine.cpp $(CSRC)/prcg_kernels.h $(CSRC)/prcg_plan.h $(CSRC)/prcg_rccl.h include/prcg.h include/prcg_test.h

@@ -343,6 +343,26 @@ struct SmallArgs {
 bool small_fits(int64_t n, int64_t nnz, int max_row_len, int* mode);
 int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode);
 
+// ---- mid-size systems: the whole pipelined solve in one launch of a few co-operating workgroups (prcg_medium.hip) ----
+constexpr int kMedSlices = 4;                   // 64-row slices per wave at most
+constexpr int kMedMaxGroups = 32;               // workgroups (one per CU, 16 waves each)
+constexpr int kMedMaxWindow = 9728;             // (r,s) pairs of a workgroup's column window that fit its LDS (152 KB)
+struct MediumArgs {
+    int n, G;
+    const int4* slices;                          // the sliced layout of the operator (prcg_plan.h: plan_sell)
+    const double* val; const unsigned short* col16; const int* rows; const int* indptr;
+    const int* wave_first;                       // [16 G + 1]: first slice of every wave
+    const int2* wg_window;                       // [G]: {first column, columns} of the workgroup's window
+    double* xp; double* rs;                      // pairs (x,p), (r,s): read at entry, written at exit
+    double* exch;                                // [2][n] pairs: the exchange buffer
+    double* slots;                               // [G][8] doubles: four partial sums, ..., tag
+    double* dots; double* coef;                  // [max_iter+1][kPartialStride], [max_iter+1][4]
+    int k0, iters, meurant;
+    unsigned long long seq;                      // launch number: the tags of this launch are (seq << 24) + iteration
+    unsigned* err;                               // set if a workgroup waited longer than its bound for the others
+};
+int launch_medium_pipe_pr(hipStream_t st, const MediumArgs& a, int window_pairs);
+
 // ---- fused vector updates + inner products -----------------------------------------
 struct PipeUpdateArgs {
     int64_t n;

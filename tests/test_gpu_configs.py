@@ -306,15 +306,17 @@ def test_irregular_standins_at_bench_size(amd, workload):
         dev.close()
     assert np.array_equal(got[fits], ref[fits])
     assert np.all(np.abs(got - ref) <= 1e-14 * (abs(A) @ np.abs(x)))
-    # a short solve: HS-CG and the pipelined variant against the oracle (diagonally dominant: well conditioned)
+    # a short solve: HS-CG and the pipelined variant against the oracle.  The stand-ins are weakly diagonally dominant
+    # (condition number ~1e4, so that a benchmark run of hundreds of iterations stays finite): a free-running history leaves
+    # 1e-9 of the oracle's after a handful of iterations, like every ill-conditioned system (tests/test_gpu_parity.py) --
+    # the first five entries are held (s4's history then jumps by factors of 100 from step to step: nothing to compare)
     b, x0, x_true = P.reference_rhs(A, n)
     for name in ('hs_cg', 'pipe_pr_cg'):
         want = getattr(orc, name)(A, b, x0, 8, callbacks=['updated_residual_2_norm'], x_true=x_true)
         got_h = getattr(amd['cgv'], name)(A, b, x0, 8, callbacks=[amd['cbs'].updated_residual_2_norm], x_true=x_true)
-        # (strongly diagonally dominant: the residual falls seven decades per step by cancellation, so the
-        #  bar is absolute -- 1e-11 of the initial residual -- like the b - A x histories of test_gpu_parity)
-        np.testing.assert_allclose(got_h['updated_residual_2_norm'], want['updated_residual_2_norm'], rtol=1e-9,
+        np.testing.assert_allclose(got_h['updated_residual_2_norm'][:5], want['updated_residual_2_norm'][:5], rtol=1e-9,
                                    atol=1e-11 * want['updated_residual_2_norm'][0])
+        assert np.all(np.isfinite(got_h['updated_residual_2_norm']))
 
 
 # ---------------------------------------------------------------------------------------
