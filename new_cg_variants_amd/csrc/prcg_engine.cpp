@@ -201,6 +201,13 @@ struct prcg_handle {
     bool red_pending = false;    // the communication chain of the previous iteration is outstanding ...
     hipEvent_t red_event = nullptr;   // ... and this event marks its end
     bool want_fused = true;      // PRCG_FUSED=0 turns it off
+    bool medium = false;         // this session runs the few-workgroup solver (prcg_medium.hip): mid-size systems
+    bool want_medium = false;    // PRCG_MEDIUM=1 turns it on (opt-in: correct, but at ~5 us per grid-wide hand-off -- two per iteration -- it does not
+                                 // yet beat one launch per iteration, 8-12 us: profiles/r04_sweeps.md)
+    bool medium_ok = false;      // the operator has a medium plan (prcg_set_csr)
+    int med_groups = 0, med_window = 0;
+    unsigned long long med_seq = 0;
+    DevBuf m_val, m_col, m_slices, m_rows, m_wave_first, m_window, m_own, m_exch, m_slots, m_err;
     bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
     int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
     int max_row_len = 0;
@@ -1246,6 +1253,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_FUSED") h->want_fused = v != 0;
     else if (k == "PRCG_WIN_SHARE") h->want_share = v != 0;
     else if (k == "PRCG_SMALL") h->want_small = v != 0;
+    else if (k == "PRCG_MEDIUM") h->want_medium = v != 0;
     else if (k == "PRCG_COL16") h->want_c16 = v != 0;
     else if (k == "PRCG_COL8") h->want_c8 = v != 0;
     else if (k == "PRCG_VALDICT") h->want_vdict = v != 0;
@@ -1278,7 +1286,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else return false;
     return true;
 }
-const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_COL16", "PRCG_COL8",
+const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
                                    "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
@@ -1759,6 +1767,33 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows;
         sp = SellPlan{};
     }
+    // mid-size systems (no ghosts, at most 131,072 rows): the plan of the few-workgroup solver, used by pipelined sessions
+    // that record nothing but the recurrence residual (prcg_solve_begin decides)
+    h->medium_ok = false;
+    if (h->want_medium && n_ghost == 0 && n_rows >= 256 && n_rows <= (int64_t)kMedMaxGroups * 16 * kMedSlices * 64 && nnz <= (int64_t)1 << 23) {
+        MediumPlan mp;
+        if (plan_medium(n_rows, ip.data(), indices, data, kMedMaxGroups, kMedSlices, kMedMaxWindow, mp)) {
+            HIPCHK(h, h->m_val.alloc(mp.sell.val.size() * sizeof(double), false));
+            HIPCHK(h, hipMemcpy(h->m_val.p, mp.sell.val.data(), mp.sell.val.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_col.alloc(mp.sell.col.size() * sizeof(uint16_t), false));
+            HIPCHK(h, hipMemcpy(h->m_col.p, mp.sell.col.data(), mp.sell.col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_slices.alloc((mp.sell.s0.size() + 1) * sizeof(SellSlice)));
+            HIPCHK(h, hipMemcpy(h->m_slices.p, mp.sell.s0.data(), mp.sell.s0.size() * sizeof(SellSlice), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_rows.alloc((mp.sell.rows.size() + 128) * sizeof(int32_t)));
+            if (!mp.sell.rows.empty()) HIPCHK(h, hipMemcpy(h->m_rows.p, mp.sell.rows.data(), mp.sell.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_wave_first.alloc(mp.wave_first.size() * sizeof(int32_t)));
+            HIPCHK(h, hipMemcpy(h->m_wave_first.p, mp.wave_first.data(), mp.wave_first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_window.alloc(mp.window.size() * sizeof(int32_t)));
+            HIPCHK(h, hipMemcpy(h->m_window.p, mp.window.data(), mp.window.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_own.alloc(mp.own.size() * sizeof(int32_t)));
+            HIPCHK(h, hipMemcpy(h->m_own.p, mp.own.data(), mp.own.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIPCHK(h, h->m_exch.alloc((size_t)4 * n_rows * sizeof(double) + 64));
+            HIPCHK(h, h->m_slots.alloc((size_t)2 * kMedMaxGroups * 8 * sizeof(double)));
+            HIPCHK(h, h->m_err.alloc(64));
+            h->med_groups = mp.groups; h->med_window = mp.window_pairs;
+            h->medium_ok = true;
+        }
+    }
     h->peer_ok = false;
     h->wt_rb.clear(); h->wt_re.clear();
     if (h->win) {
@@ -2145,6 +2180,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->pr_fused = false;
     h->hs_pend_mu = 0;
     h->small = false;
+    h->medium = false;
     h->gather = false;
     h->cb_session = h->cb != nullptr && inv_diag == nullptr;
     h->prec = inv_diag != nullptr || h->cb_session;
@@ -2207,6 +2243,9 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         h->small = h->fused && !h->fused_comm && h->want_small && !h->prec && pipe_recompute(variant) &&
                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
                    small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
+        // few-workgroup solver for the systems the one-workgroup solver cannot hold: same conditions, up to 131,072 rows
+        h->medium = !h->small && h->medium_ok && h->want_medium && h->fused && !h->fused_comm && !h->prec && pipe_recompute(variant) &&
+                    !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) && !h->multi();
         HIPCHK(h, h->rst.ensure(h->prec ? (size_t)2 * ne * D : 16, h->sc));
         if (h->prec) h->rs_cur = h->rst.d();
         HIPCHK(h, h->wu.ensure((size_t)2 * n * D, h->sc));
@@ -2433,6 +2472,31 @@ int prcg_iterate(prcg_t* h, int iters) {
         h->k += iters;
         return PRCG_OK;
     }
+    if (h->medium && iters > 0) {
+        // all `iters` iterations inside one launch of a few co-operating workgroups (prcg_medium.hip)
+        for (int left = iters; left > 0;) {
+            const int now = left < (1 << 20) ? left : (1 << 20);
+            MediumArgs ma{};
+            ma.n = (int)h->n; ma.G = h->med_groups;
+            ma.slices = static_cast<const int4*>(h->m_slices.p);
+            ma.val = h->m_val.d(); ma.col16 = static_cast<const unsigned short*>(h->m_col.p);
+            ma.rows = static_cast<const int*>(h->m_rows.p); ma.indptr = h->indptr.i();
+            ma.wave_first = static_cast<const int*>(h->m_wave_first.p);
+            ma.wg_window = static_cast<const int2*>(h->m_window.p);
+            ma.wg_own = static_cast<const int2*>(h->m_own.p);
+            ma.xp = h->xp.d(); ma.rs = h->rs_cur; ma.exch = h->m_exch.d(); ma.slots = h->m_slots.d();
+            ma.dots = h->dots.d(); ma.coef = h->coef.d();
+            ma.k0 = h->k; ma.iters = now; ma.meurant = meurant(h->variant);
+            ma.seq = ++h->med_seq; ma.err = static_cast<unsigned*>(h->m_err.p);
+            bool on = false;
+            prof_begin(h, h->ev_spmv, h->n_ev_spmv, 0, on);
+            LAUNCHCHK(h, launch_medium_pipe_pr(h->sc, ma, h->med_window));
+            prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+            h->k += now;
+            left -= now;
+        }
+        return PRCG_OK;
+    }
     for (int i = 0; i < iters; ++i) {
         const int k = h->k + 1;
         int rc;
@@ -2478,6 +2542,12 @@ int prcg_sync(prcg_t* h) {
                                             "(communication stream starved or a peer stalled); results are invalid. "
                                             "PRCG_FUSED_COMM=0 selects the two-kernel schedule");
     }
+    if (h->in_session && h->medium && h->m_err.p) {
+        unsigned err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->m_err.p, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(h, PRCG_EHIP, "the few-workgroup solver waited more than its bound for one of its workgroups (not all of them "
+                                           "resident?); results are invalid.  PRCG_MEDIUM=0 selects one launch per iteration");
+    }
     return PRCG_OK;
 }
 
@@ -2496,7 +2566,7 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
     return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) |
-           (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+           (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->medium ? PRCG_SCHED_MEDIUM : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            (h->stream_stores ? PRCG_SCHED_STREAM_STORES : 0) | ((h->sell && h->sell_sigma > 64) ? PRCG_SCHED_SELL_SORTED : 0) |
            ((h->sell && h->sell_nt) ? PRCG_SCHED_NT_LOADS : 0) |

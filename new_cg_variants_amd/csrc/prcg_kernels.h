@@ -353,9 +353,10 @@ struct MediumArgs {
     const double* val; const unsigned short* col16; const int* rows; const int* indptr;
     const int* wave_first;                       // [16 G + 1]: first slice of every wave
     const int2* wg_window;                       // [G]: {first column, columns} of the workgroup's window
+    const int2* wg_own;                          // [G]: the workgroup's own rows [first, end) -- every row of its slices, nobody else's
     double* xp; double* rs;                      // pairs (x,p), (r,s): read at entry, written at exit
     double* exch;                                // [2][n] pairs: the exchange buffer
-    double* slots;                               // [G][8] doubles: four partial sums, ..., tag
+    double* slots;                               // [2][kMedMaxGroups][8] doubles: per workgroup four partial sums ... tag; "rows visible" tags
     double* dots; double* coef;                  // [max_iter+1][kPartialStride], [max_iter+1][4]
     int k0, iters, meurant;
     unsigned long long seq;                      // launch number: the tags of this launch are (seq << 24) + iteration

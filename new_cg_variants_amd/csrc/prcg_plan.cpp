@@ -865,6 +865,74 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     return true;
 }
 
+bool plan_medium(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, int max_groups, int max_slices,
+                 int max_window, MediumPlan& out) {
+    out = MediumPlan{};
+    if (n < 1 || n > (int64_t)max_groups * 16 * max_slices * 64) return false;
+    SellOptions so;
+    so.max_overhead = 8.0;           // (short ragged rows pad heavily; the whole operator stays in the L2 anyway)
+    so.planes = 0;
+    if (!plan_sell(n, indptr, indices, data, nullptr, so, out.sell)) return false;
+    const int nsl = (int)out.sell.s0.size();
+    // slices per wave; a workgroup (16 waves) holds whole sorting windows, so that its rows are one contiguous range
+    const int per_window = std::max(1, out.sell.sigma / 64);
+    int per = 1;
+    for (; per <= max_slices; ++per)
+        if ((16 * per) % per_window == 0 && (int64_t)max_groups * 16 * per >= nsl) break;
+    if (per > max_slices) return false;
+    // (no more workgroups than the slices need; each at least one wave's worth)
+    int G = (nsl + 16 * per - 1) / (16 * per);
+    if (G < 1) G = 1;
+    // spread over as many workgroups as give every wave a slice: a smaller `per` where the windows allow it
+    const int W = G * 16;
+    out.groups = G;
+    out.wave_first.resize((size_t)W + 1);
+    for (int w = 0; w <= W; ++w) out.wave_first[(size_t)w] = std::min(nsl, w * per);
+    out.window.assign((size_t)2 * G, 0);
+    out.own.assign((size_t)2 * G, 0);
+    auto slice_row = [&](const SellSlice& sl, int l) { return sl.rows_off < 0 ? sl.rb + l : out.sell.rows[2 * ((size_t)sl.rows_off + l)]; };
+    int64_t prev_hi = 0;
+    for (int g = 0; g < G; ++g) {
+        int64_t rmin = INT64_MAX, rmax = -1, cmin = INT64_MAX, cmax = -1;
+        const int s_lo = out.wave_first[(size_t)g * 16], s_hi = out.wave_first[(size_t)(g + 1) * 16];
+        for (int si = s_lo; si < s_hi; ++si) {
+            const SellSlice& sl = out.sell.s0[(size_t)si];
+            for (int l = 0; l < sl.re - sl.rb; ++l) {
+                const int row = slice_row(sl, l);
+                rmin = std::min<int64_t>(rmin, row); rmax = std::max<int64_t>(rmax, row);
+                for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q) {
+                    if (indices[q] < 0 || indices[q] >= n) return false;
+                    cmin = std::min<int64_t>(cmin, indices[q]); cmax = std::max<int64_t>(cmax, indices[q]);
+                }
+            }
+        }
+        if (rmax < 0) { rmin = prev_hi; rmax = prev_hi - 1; }
+        if (rmin < prev_hi) return false;                 // (the workgroups' row ranges must not interleave)
+        prev_hi = rmax + 1;
+        out.own[(size_t)2 * g] = (int32_t)rmin;
+        out.own[(size_t)2 * g + 1] = (int32_t)(rmax + 1);
+        cmin = std::min(cmin, rmin); cmax = std::max(cmax, rmax);
+        if (cmax < 0) { cmin = 0; cmax = 0; }
+        // (a skip code lands between two columns of a row, a padded position stays on the row's last column: inside the window)
+        const int64_t wlen = cmax - cmin + 1;
+        if (wlen > max_window) return false;
+        out.window[(size_t)2 * g] = (int32_t)cmin;
+        out.window[(size_t)2 * g + 1] = (int32_t)wlen;
+        out.window_pairs = std::max(out.window_pairs, (int)wlen);
+        for (int si = s_lo; si < s_hi; ++si) {
+            SellSlice& sl = out.sell.s0[(size_t)si];
+            bool outside = false;
+            for (int l = 0; l < sl.re - sl.rb && !outside; ++l) {
+                const int row = slice_row(sl, l);
+                for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q)
+                    if (indices[q] < rmin || indices[q] > rmax) { outside = true; break; }
+            }
+            sl.flags = outside ? 1 : 0;
+        }
+    }
+    return true;
+}
+
 int plan_gather_sources(int rank, int T, const double* tab, int n_peers, const int32_t* peer_rank,
                         const int64_t* recv_ptr, int64_t slot, int32_t* src) {
     for (int q = 0; q < n_peers; ++q) {

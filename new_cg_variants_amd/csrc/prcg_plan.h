@@ -168,6 +168,20 @@ struct SellPlan {
 bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
                const SellOptions& opt, SellPlan& out);
 
+// ---- mid-size systems (prcg_medium.hip): the sliced layout + which wave of which workgroup owns which slices ----
+// G workgroups of 16 waves; wave w (0 .. 16 G) owns the slices [wave_first[w], wave_first[w+1]) -- at most `max_slices`;
+// workgroup g stages the columns [window[2g], window[2g] + window[2g+1]) of the (r,s) pairs in LDS: every column its rows
+// touch and its own rows [own[2g], own[2g+1]) -- exactly the rows of its slices (workgroups are cut at sorting-window
+// boundaries); a slice with a column outside its workgroup's own rows is flagged (SellSlice::flags = 1: its products wait for
+// the other workgroups' rows).  false: the system does not qualify (too many slices, or a window beyond `max_window` pairs).
+struct MediumPlan {
+    SellPlan sell;
+    std::vector<int32_t> wave_first, window, own;
+    int groups = 0, window_pairs = 0;
+};
+bool plan_medium(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, int max_groups, int max_slices,
+                 int max_window, MediumPlan& out);
+
 // Merged exchange (small halos ride on the one all-gather per iteration):
 // every rank contributes a slot of `slot` doubles = 8 (partial sums) + 2 x its packed send rows;
 // `tab` holds every rank's send table, `T` doubles per rank: [n_peers, (peer, first row of the

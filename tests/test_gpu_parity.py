@@ -915,6 +915,80 @@ def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
     multi.close()
 
 
+@pytest.mark.parametrize('name', ['bcsstk16', 'bcsstk18', 'bcsstm25', 'band60k', 'lap200'])
+def test_few_workgroup_solver_for_mid_size_systems(amd, name):
+    """Systems too large for the one-workgroup solver and too small to fill the chip (the paper's bcsstk16 / 18, bcsstm25;
+    up to 131,072 rows), nothing but the recurrence residual recorded: the whole solve runs in ONE launch of a few
+    co-operating workgroups (csrc/prcg_medium.hip: rows in slices, x and p in registers, (r,s) through a double-buffered
+    exchange array and an LDS window, one all-to-all of partial sums per iteration).  Per element the arithmetic is the one
+    of the multi-launch schedules: from identical state the vectors agree bit for bit, the inner products to 1e-12; the
+    run is deterministic and does not depend on how it is cut into prcg_iterate calls.
+    Opt-in (PRCG_MEDIUM=1): measured on MI355X a grid-wide hand-off (drained sc1 stores, flag, poll) costs ~5 us and an
+    iteration needs two of them -- bcsstm25 10 us, bcsstk18 24 us per iteration against 9 / 8 us with one launch per
+    iteration; the test prints both."""
+    import os
+    import time
+    from conftest import GOLDEN
+    L, P = amd['L'], amd['problems']
+    if name == 'band60k':
+        A = P.banded_ex2b(60_000, 7)
+    elif name == 'lap200':
+        A = P.laplace_2d(200, 200)
+    else:
+        z = np.load(os.path.join(GOLDEN, f'tablemat_{name}.npz'))
+        nz = int(z['n'])
+        A = sp.csr_matrix((z['data'], z['indices'], z['indptr']), shape=(nz, nz))
+    n = A.shape[0]
+    b, x0, _ = P.reference_rhs(A, n)
+    med = amd['device'].DeviceCSR(A, knobs={'PRCG_MEDIUM': '1'})      # (opt-in: see below)
+    multi = amd['device'].DeviceCSR(A)
+    for op in (med, multi):
+        op.begin(L.PIPE_PR, b, x0, 64)
+    assert med.schedule()['medium'] and not med.schedule()['small'], med.schedule()
+    assert not multi.schedule()['medium']
+    worst = 0.0
+    for k in range(12):
+        for v in ('x', 'r', 'p', 's'):
+            med.set_vector(v, multi.get_vector(v))
+        med.set_scalars(k, multi.get_scalars(k))
+        med.set_iteration(k)
+        med.iterate(1)
+        multi.iterate(1)
+        for v in ('x', 'r', 'p', 's'):
+            assert np.array_equal(med.get_vector(v), multi.get_vector(v)), (k, v)
+        a, c = med.get_scalars(k + 1)[:5], multi.get_scalars(k + 1)[:5]
+        worst = max(worst, float(np.max(np.abs(a - c) / np.abs(c))))
+        assert np.allclose(med.get_coefficients(k + 1)[:2], multi.get_coefficients(k + 1)[:2], rtol=1e-12, atol=0)
+    assert worst <= 1e-12, worst
+    iters = 2000
+    runs, times = [], []
+    for chunks in ((iters,), (700, 1, 2, 1297)):
+        med.begin(L.PIPE_PR, b, x0, iters + 1, hist_mask=1)
+        t0 = time.perf_counter()
+        for c in chunks:
+            med.iterate(c)
+        med.sync()
+        times.append(time.perf_counter() - t0)
+        runs.append(med.history()['updated_residual_2_norm'])
+    assert np.array_equal(runs[0], runs[1], equal_nan=True)
+    multi.begin(L.PIPE_PR, b, x0, iters + 1, hist_mask=1)
+    t0 = time.perf_counter()
+    multi.iterate(iters)
+    multi.sync()
+    dt_multi = time.perf_counter() - t0
+    ref = multi.history()['updated_residual_2_norm']
+    np.testing.assert_allclose(runs[0][:5], ref[:5], rtol=1e-12)
+    # same convergence: the residual reduction reached after the run, within the noise of a different summation order
+    with np.errstate(all='ignore'):
+        got_red, ref_red = np.nanmin(runs[0]) / runs[0][0], np.nanmin(ref) / ref[0]
+    assert abs(np.log10(got_red) - np.log10(ref_red)) <= 1.5, (got_red, ref_red)
+    print(f'{name} (n={n}, nnz={A.nnz}): {iters} iterations in one launch of {med.schedule()} {times[0] * 1e3:.2f} ms '
+          f'({times[0] / iters * 1e6:.2f} us/iteration) vs one launch per iteration {dt_multi * 1e3:.2f} ms '
+          f'({dt_multi / iters * 1e6:.2f} us/iteration); forced-step scalar deviation {worst:.1e}')
+    med.close()
+    multi.close()
+
+
 def test_device_results_are_reproducible(amd, matrices):
     A, z = matrices['nos7']
     cbs = [amd['cbs'].updated_residual_2_norm]
