@@ -146,7 +146,8 @@ struct prcg_handle {
                                          // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
     int sell_nt = 0;                     // the value / code streams are read with nontemporal loads: chosen per operator in prcg_set_csr
     int sell_nt_opt = -1;                // PRCG_SELL_NT=0|1 overrides
-    int sell_sigma = 0, sell_planes = 0; // what the planner chose (prcg_schedule_info)
+    int sell_sigma = 0, sell_planes = 0, sell_run = 1; // what the planner chose
+    bool sell_runs_opt = true;           // PRCG_SELL_RUNS=0: a column code per nonzero even where the rows are runs of three
     int64_t sell_stride = 0;
     bool want_big = true;                // PRCG_WIN_BIG=0: short launches keep the small workgroups too
     int win_order = 0;                   // 1: XCD-chunked tile order of the window launches (opt-in: PRCG_WIN_ORDER=1)
@@ -275,7 +276,7 @@ struct prcg_handle {
                       win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
-    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt}; }
+    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt, sell_run}; }
     const double* val_sell() const { return static_cast<const double*>(sval.p); }
     const void* sslice_ptr(int first = 0) const { return static_cast<const char*>(sslices.p) + (size_t)first * 32; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -1275,6 +1276,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL_GRID_PER_CU") h->sell_per_cu = (v >= 1 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
     else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 0;
+    else if (k == "PRCG_SELL_RUNS") h->sell_runs_opt = v != 0;
     else if (k == "PRCG_SELL_NT") { h->sell_nt_opt = v != 0; h->sell_nt = v != 0; }
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1289,7 +1291,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_RUNS", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1620,6 +1622,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         SellOptions so;
         so.sigma = h->sell_sigma_opt;
         so.planes = h->sell_planes_opt;
+        so.allow_runs = h->sell_runs_opt;
         h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, so, sp);
     }
     const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels
@@ -1764,7 +1767,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         // what a product reads of the operator: 8 B per (padded) value, 2 B per (padded) column code, the slice descriptors, and
         // the row pointers (slices of consecutive rows) or the slices' (row, stored length) pairs
         h->sell_bytes = sp.padded_nnz * 8 + sp.col_entries * 2 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4;
-        h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows;
+        h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows; h->sell_run = sp.run;
         sp = SellPlan{};
     }
     // mid-size systems (no ghosts, at most 131,072 rows): the plan of the few-workgroup solver, used by pipelined sessions
@@ -2853,18 +2856,18 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
 }
 
 int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-                       double max_overhead, int sigma, int planes, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
+                       double max_overhead, int sigma, int planes, int allow_runs, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
                        int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity, int64_t* stats) {
     if (n < 0 || !indptr || (indptr[n] > 0 && (!indices || !data)) || (!slices_out && capacity > 0)) return -1;
     SellPlan sp;
     SellOptions so;
-    so.max_overhead = max_overhead; so.sigma = sigma; so.planes = planes;
+    so.max_overhead = max_overhead; so.sigma = sigma; so.planes = planes; so.allow_runs = allow_runs != 0;
     if (!plan_sell(n, indptr, indices, data, row_class, so, sp)) return 0;
     const int64_t total = (int64_t)sp.s0.size() + (int64_t)sp.s1.size();
     if (stats) {
         stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz;
         stats[4] = sp.sigma; stats[5] = sp.stride_rows; stats[6] = sp.planes; stats[7] = (int64_t)sp.rows.size();
-        stats[8] = sp.col_entries;
+        stats[8] = sp.col_entries; stats[9] = sp.run;
     }
     if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity) ||
         (rows_out && (int64_t)sp.rows.size() > rows_capacity)) return -total;

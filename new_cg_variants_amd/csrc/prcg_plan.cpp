@@ -738,55 +738,70 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     }
     if (sigma < 64) sigma = 64;
     out.sigma = sigma;
+    // --- column RUNS: if every row consists of aligned runs of 3 consecutive columns (an assembled matrix with three unknowns
+    // per node and full 3 x 3 blocks: Queen_4147's structure), ONE code per run is stored instead of one per nonzero
+    // (8 + 2/3 instead of 10 bytes per nonzero)
+    int run = 1;
+    if (opt.allow_runs && nnz >= 3) {
+        bool ok3 = true;
+        for (int64_t r = 0; r < n && ok3; ++r) {
+            const int32_t lo = indptr[r], len = indptr[r + 1] - lo;
+            if (len % 3) { ok3 = false; break; }
+            for (int32_t q = 0; q < len; q += 3)
+                if (indices[lo + q + 1] != indices[lo + q] + 1 || indices[lo + q + 2] != indices[lo + q] + 2) { ok3 = false; break; }
+        }
+        if (ok3) run = 3;
+    }
+    out.run = run;
     // pass 1: slices, widths, offsets.  A row's columns are stored as 16-bit DELTAS (prcg_plan.h); a gap too wide for one
     // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips
     std::vector<SellSlice> all;
     std::vector<uint8_t> cls_of;
     std::vector<int32_t>& perm = out.rows;        // (row, stored length) pairs in lane order, 64 pairs per slice that has them
-    std::vector<int32_t> run;
-    auto skips_of = [&](int32_t row, int32_t base) {
+    std::vector<int32_t> rrun;
+    auto skips_of = [&](int32_t row, int32_t base) {       // extra stored POSITIONS of the row: `run` per skip code
         int sk = 0;
         int64_t prev = base;
-        for (int32_t q = indptr[row]; q < indptr[row + 1]; ++q) {
+        for (int32_t q = indptr[row]; q < indptr[row + 1]; q += run) {
             int64_t dlt = (int64_t)indices[q] - prev;
             if (dlt > kSellDeltaMax) sk += (int)((dlt - kSellDeltaMax + kSellSkipFwd - 1) / kSellSkipFwd);
             else if (dlt < kSellDeltaMin) sk += (int)((kSellDeltaMin - dlt + kSellSkipBack - 1) / kSellSkipBack);
             prev = indices[q];
         }
-        return sk;
+        return sk * run;
     };
     int64_t voff = 0, coff = 0, r = 0;
     while (r < n) {
         const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
         int64_t e = r + 1;
         if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
-        run.clear();
-        sell_run_order(indptr, r, e, sigma, run);
-        for (size_t i = 0; i < run.size(); i += 64) {
-            const size_t je = std::min(run.size(), i + 64);
+        rrun.clear();
+        sell_run_order(indptr, r, e, sigma, rrun);
+        for (size_t i = 0; i < rrun.size(); i += 64) {
+            const size_t je = std::min(rrun.size(), i + 64);
             int32_t rmin = INT32_MAX, cbase = INT32_MAX;
             for (size_t j = i; j < je; ++j) {
-                rmin = std::min(rmin, run[j]);
-                if (indptr[run[j] + 1] > indptr[run[j]]) cbase = std::min(cbase, indices[indptr[run[j]]]);
+                rmin = std::min(rmin, rrun[j]);
+                if (indptr[rrun[j] + 1] > indptr[rrun[j]]) cbase = std::min(cbase, indices[indptr[rrun[j]]]);
             }
             if (cbase == INT32_MAX) cbase = 0;
             int width = 0;
             bool any_skip = false;
             for (size_t j = i; j < je; ++j) {
-                const int sk = skips_of(run[j], cbase);
+                const int sk = skips_of(rrun[j], cbase);
                 any_skip |= sk > 0;
-                width = std::max(width, indptr[run[j] + 1] - indptr[run[j]] + sk);
+                width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]] + sk);
             }
-            const int w2 = (width + 1) & ~1, w8 = (width + 7) & ~7;
+            const int w2 = (width + 1) & ~1, w8 = ((width + run - 1) / run + 7) & ~7;      // value slots (even), codes (whole 16-byte chunks)
             if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w8 * 64 >= (int64_t)INT32_MAX - 4096) return false;
             int rows_off = -1;
             if (sigma > 64 || any_skip) {
                 rows_off = (int)(perm.size() / 2);
-                for (size_t j = i; j < je; ++j) { perm.push_back(run[j]); perm.push_back(indptr[run[j] + 1] - indptr[run[j]] + skips_of(run[j], cbase)); }
+                for (size_t j = i; j < je; ++j) { perm.push_back(rrun[j]); perm.push_back(indptr[rrun[j] + 1] - indptr[rrun[j]] + skips_of(rrun[j], cbase)); }
                 for (size_t j = je; j < i + 64; ++j) { perm.push_back(-1); perm.push_back(0); }
             }
             // (rows_off < 0: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
-            const int first = rows_off < 0 ? run[i] : rmin;
+            const int first = rows_off < 0 ? rrun[i] : rmin;
             all.push_back(SellSlice{first, first + (int)(je - i), (int)voff, (int)coff, width, cbase, rows_off, 0});
             cls_of.push_back(cls);
             voff += (int64_t)w2 * 64;
@@ -814,15 +829,15 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
                 const int32_t lo = indptr[row];
                 const int len = indptr[row + 1] - lo;
                 int64_t prev = sl.cbase;
-                int u = 0;                                  // stored position
-                auto put = [&](uint16_t code) { out.col[(size_t)sl.coff + ((size_t)(u >> 3) * 64 + l) * 8 + (u & 7)] = code; };
-                for (int q = 0; q < len; ++q) {
+                int u = 0;                                  // stored position (a multiple of `run` at every run start)
+                auto put = [&](uint16_t code) { const int c = u / run; out.col[(size_t)sl.coff + ((size_t)(c >> 3) * 64 + l) * 8 + (c & 7)] = code; };
+                for (int q = 0; q < len; q += run) {
                     int64_t dlt = (int64_t)indices[lo + q] - prev;
-                    while (dlt > kSellDeltaMax) { put(kSellCodeSkipFwd); ++u; prev += kSellSkipFwd; dlt -= kSellSkipFwd; }
-                    while (dlt < kSellDeltaMin) { put(kSellCodeSkipBack); ++u; prev -= kSellSkipBack; dlt += kSellSkipBack; }
+                    while (dlt > kSellDeltaMax) { put(kSellCodeSkipFwd); u += run; prev += kSellSkipFwd; dlt -= kSellSkipFwd; }
+                    while (dlt < kSellDeltaMin) { put(kSellCodeSkipBack); u += run; prev -= kSellSkipBack; dlt += kSellSkipBack; }
                     put((uint16_t)(dlt + kSellDeltaBias));
-                    out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + q];
-                    ++u;
+                    for (int e2 = 0; e2 < run; ++e2, ++u)
+                        out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + q + e2];
                     prev = indices[lo + q];
                 }
             }
@@ -872,6 +887,7 @@ bool plan_medium(int64_t n, const int32_t* indptr, const int32_t* indices, const
     SellOptions so;
     so.max_overhead = 8.0;           // (short ragged rows pad heavily; the whole operator stays in the L2 anyway)
     so.planes = 0;
+    so.allow_runs = false;           // (the few-workgroup solver reads one code per nonzero)
     if (!plan_sell(n, indptr, indices, data, nullptr, so, out.sell)) return false;
     const int nsl = (int)out.sell.s0.size();
     // slices per wave; a workgroup (16 waves) holds whole sorting windows, so that its rows are one contiguous range

@@ -133,6 +133,11 @@ bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const in
 // span 65,536 columns: Queen_4147's size.)  Shorter rows are padded with value 0 / code 16384 (column stays; never
 // multiplied: the kernels mask by the stored length).  A TRIP (positions 8 j .. 8 j + 7) is what the wave reads with four
 // 16-byte value loads and one 16-byte code load per lane.  The arrays end with a whole trip of padding.
+// RUNS (SellPlan::run = 3): when every row of the operator consists of aligned runs of three consecutive columns -- three
+// unknowns per node, full 3 x 3 blocks: what an assembled 3-D elasticity matrix such as Queen_4147 is -- ONE code is stored
+// per run: code c of a row covers its stored positions 3 c .. 3 c + 2, moves the running column to the run's FIRST column
+// (delta from the previous run's first column) and the positions are the columns +0, +1, +2; a skip code costs a whole run
+// of unused value slots; code c sits at col16[coff + ((c/8)*64 + l)*8 + c%8]: 8 + 2/3 bytes per nonzero instead of 10.
 // Which rows: rows_off = -1: the slice holds the consecutive rows [rb, re), their stored lengths are the row pointers'
 // (no skips).  Otherwise lane l holds row rows[2 * (rows_off + l)] with stored length rows[2 * (rows_off + l) + 1]
 // (64 pairs per slice; row -1, length 0 behind the last) and rb is the smallest of them: slices of a sorting window wider
@@ -153,6 +158,7 @@ struct SellOptions {
     double target64 = 1.06;          //    256, 1024, 4096 that pads <= target (else the one that pads least)
     double target = 1.04;
     int planes = 8;                  // class-0 slices of this many consecutive grid planes are interleaved in the table (<= 1: row order)
+    bool allow_runs = true;          // operators whose rows are aligned runs of 3 consecutive columns store one code per run
 };
 struct SellPlan {
     std::vector<SellSlice> s0, s1;       // interior slices (in PROCESSING order), slices touching ghost columns
@@ -164,6 +170,7 @@ struct SellPlan {
     int sigma = 64;
     int64_t stride_rows = 0;             // the operator's dominant far column offset (a grid plane), 0: none found
     int planes = 0;                      // > 0: the class-0 table interleaves groups of this many planes
+    int run = 1;                         // 3: one column code per aligned run of three consecutive columns (see below), else one per nonzero
 };
 bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
                const SellOptions& opt, SellPlan& out);

@@ -38,20 +38,21 @@ __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) 
     return d;
 }
 
-// 8 stored positions of every row of the slice: four value chunks (2 doubles per lane each), one chunk of eight 16-bit
-// column-delta codes
+// One TRIP of every row of the slice: eight column codes (one 16-byte chunk per lane) and the 8 RUN stored positions they
+// cover -- 4 RUN value chunks of 2 doubles per lane.  RUN = 1: a code per nonzero; RUN = 3: a code per aligned run of three
+// consecutive columns (prcg_plan.h)
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-struct Trip { d2_t v[4]; u4_t c; };
+template <int RUN> struct Trip { d2_t v[4 * RUN]; u4_t c; };
 
-template <bool NT>
-__device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip& T) {
-    // chunk index of position u: values u / 2, codes u / 8.  Value chunks past the slice's width (the slice's last trip) belong
-    // to the following slice: the lane reads its first chunk of the trip again instead (no branch around a load -- the
+template <bool NT, int RUN>
+__device__ __forceinline__ void load_trip(const SellDev& A, const SDesc& d, int u0, int lane, Trip<RUN>& T) {
+    // chunk index of position u: values u / 2, codes u / (8 RUN).  Value chunks past the slice's width (the slice's last trip)
+    // belong to the following slice: the lane reads its first chunk of the trip again instead (no branch around a load -- the
     // compiler's wait counts at a join assume the worst -- and no bytes from memory that nobody uses: 7 % of the stream)
     const int64_t vb = (int64_t)d.voff + ((int64_t)(u0 >> 1) * 64 + lane) * 2;
-    const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 >> 3) * 64 + lane) * 8;
+    const int64_t cb = (int64_t)d.coff + ((int64_t)(u0 / (8 * RUN)) * 64 + lane) * 8;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4 * RUN; ++k) {
         const int kk = (u0 + 2 * k < d.width) ? k : 0;                      // wave-uniform select
         const d2_t* q = reinterpret_cast<const d2_t*>(A.val + vb + (int64_t)kk * 128);
         T.v[k] = NT ? __builtin_nontemporal_load(q) : *q;
@@ -72,7 +73,7 @@ __device__ __forceinline__ int2 slice_row(const SellDev& A, const SDesc& d, int 
     return reinterpret_cast<const int2*>(A.rows)[d.rows_off + lane];
 }
 
-template <int NV, int EPI, bool NT>
+template <int NV, int EPI, bool NT, int RUN>
 __global__ __launch_bounds__(kBlock) void k_sell_tiles(
     SellDev A, const int4* __restrict__ slices, int nslices,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -106,12 +107,13 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
     const int W = nblk * kWaves;
     int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
 
-    Trip cur, nxt;
+    Trip<RUN> cur, nxt;
+    constexpr int TP = 8 * RUN;           // stored positions per trip
     SDesc d = {0, 0, 0, 0, 0, 0, -1}, dn = {0, 0, 0, 0, 0, 0, -1};
     int2 rl = make_int2(-1, 0);            // row and length of the lane's row in the CURRENT slice (requested a slice ahead)
     if (t < nslices) {
         d = read_sdesc(slices, t);
-        load_trip<NT>(A, d, 0, lane, cur);
+        load_trip<NT, RUN>(A, d, 0, lane, cur);
         rl = slice_row(A, d, lane);
         if (t + W < nslices) dn = read_sdesc(slices, t + W);
     }
@@ -133,35 +135,44 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
         }
         V sum; vzero(sum);
         int colacc = d.cbase;
-        for (int u0 = 0; u0 < d.width; u0 += 8) {                            // wave-uniform trip count
+        for (int u0 = 0; u0 < d.width; u0 += TP) {                           // wave-uniform trip count
             // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
-            const bool more = u0 + 8 < d.width;
-            if (more) load_trip<NT>(A, d, u0 + 8, lane, nxt);
-            else if (t + W < nslices) load_trip<NT>(A, dn, 0, lane, nxt);
-            // the lane's running column: every position moves it by code - 16384; codes 0 and 65535 only move it (skips)
+            const bool more = u0 + TP < d.width;
+            if (more) load_trip<NT, RUN>(A, d, u0 + TP, lane, nxt);
+            else if (t + W < nslices) load_trip<NT, RUN>(A, dn, 0, lane, nxt);
+            // the lane's running column: every code moves it by code - 16384 (to the first column of its run); codes 0 and
+            // 65535 only move it (skips)
             int code[8], col[8];
             code[0] = cur.c.x & 0xffffu; code[1] = cur.c.x >> 16; code[2] = cur.c.y & 0xffffu; code[3] = cur.c.y >> 16;
             code[4] = cur.c.z & 0xffffu; code[5] = cur.c.z >> 16; code[6] = cur.c.w & 0xffffu; code[7] = cur.c.w >> 16;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { colacc += code[k] - 16384; col[k] = colacc; }
-            V g[8];
+            // (two codes at a time: 2 RUN gathers in flight per lane beside the next trip's stream loads)
 #pragma unroll
+            for (int k2 = 0; k2 < 8; k2 += 2) {
+                V g[2 * RUN];
+#pragma unroll
+                for (int k = 0; k < 2 * RUN; ++k) {
+                    const int c0 = col[k2 + k / RUN] + k % RUN;
 #if defined(PRCG_SELL_DIAG_NOGATHER) && PRCG_SELL_DIAG_NOGATHER == 2   // TIMING ONLY (wrong products): no gather instruction at all
-            for (int k = 0; k < 8; ++k) { g[k] = own; if constexpr (NV == 2) g[k].x += (double)col[k]; else g[k] += (double)col[k]; }
+                    g[k] = own; if constexpr (NV == 2) g[k].x += (double)c0; else g[k] += (double)c0;
 #elif defined(PRCG_SELL_DIAG_NOGATHER)      // TIMING ONLY (wrong products): every gather hits the same 64 entries -- what the kernel costs without gather misses
-            for (int k = 0; k < 8; ++k) g[k] = X[d.cbase + (col[k] & 63)];
+                    g[k] = X[d.cbase + (c0 & 63)];
 #else
-            for (int k = 0; k < 8; ++k) g[k] = X[col[k]];                   // (padding positions stay at the row's last column, a skip lands between two
-                                                                            //  of the row's columns: valid entries, never used)
+                    g[k] = X[c0];                                           // (padding positions stay at the row's last column, a skip lands between
+                                                                            //  two of the row's columns: valid entries, never used)
 #endif
+                }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double a = (k & 1) ? cur.v[k >> 1].y : cur.v[k >> 1].x;
-                if (u0 + k < len && (unsigned)(code[k] - 1) < 65534u) vacc(sum, vmul(a, g[k]));   // left to right, product rounded, then added
+                for (int k = 0; k < 2 * RUN; ++k) {
+                    const int pos = k2 * RUN + k;                           // position inside the trip
+                    const double a = (pos & 1) ? cur.v[pos >> 1].y : cur.v[pos >> 1].x;
+                    if (u0 + pos < len && (unsigned)(code[k2 + k / RUN] - 1) < 65534u) vacc(sum, vmul(a, g[k]));   // left to right, product rounded, then added
+                }
             }
             cur = nxt;
         }
-        if (d.width == 0 && t + W < nslices) load_trip<NT>(A, dn, 0, lane, cur);
+        if (d.width == 0 && t + W < nslices) load_trip<NT, RUN>(A, dn, 0, lane, cur);
         if constexpr (epi_fused(EPI)) {
             if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
         } else {
@@ -213,8 +224,9 @@ template <int NV, int EPI>
 int launch_sell(hipStream_t st, const SellDev& A, const void* slices, int nslices, const void* x, void* y, int write_mask,
                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz, int per_cu)
 {
-    auto k = A.nt ? k_sell_tiles<NV, EPI, true> : k_sell_tiles<NV, EPI, false>;
-    const int grid = sell_grid(k_sell_tiles<NV, EPI, false>, nslices, per_cu);
+    auto k = A.run == 3 ? (A.nt ? k_sell_tiles<NV, EPI, true, 3> : k_sell_tiles<NV, EPI, false, 3>)
+                        : (A.nt ? k_sell_tiles<NV, EPI, true, 1> : k_sell_tiles<NV, EPI, false, 1>);
+    const int grid = sell_grid(k_sell_tiles<NV, EPI, false, 1>, nslices, per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r, ep_d,
                        ep_st, partials, aux, fz);
     return hipGetLastError() == hipSuccess ? grid : -1;

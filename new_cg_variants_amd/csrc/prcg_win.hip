@@ -837,9 +837,24 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
 // bounded; a timeout sets *err and lets the wave continue (wrong numbers, never a hang).
 // (the deferred dictionary kernels of the 64-row geometries are asked to fit four workgroups per CU -- 128 VGPRs: they
 //  are bound by what one wave can overlap, and a few spilled scalars cost less than a quarter of the resident waves)
-constexpr int win_min_blocks(int m, bool vd, int def, int wpb = 4) { return (def > 0 && vd && m == 1 && wpb <= 4) ? 4 : 1; }
+// Waves per workgroup.  Every workgroup of the one-launch iteration sums the previous launch's partial rows in its
+// prologue (one row per workgroup): B workgroups read B rows each, and at 2048 two-wave workgroups that was ~7 us
+// of a 160 us launch (S3), a quarter of a 37 us one (one eighth of S3).  Four-wave workgroups halve B at the same
+// number of resident waves (S3 +4 %, S1 +14 %, S3/8 +25 %, profiles/r02_sweeps.md) -- unless a four-wave
+// workgroup's LDS no longer lets two of them share a CU (the 12-page plain geometry: S2 plain -16 %), then two.
+constexpr int lds_bytes_per_wave(int nv, int pg, int cw, bool vd) {
+    if (cw == 32) return 16 + 16 + 16 + 16 + pg * 64 * 8 * nv;             // pattern tiles: the window only
+    return (vd ? 16 : kWinSlots * 8) + (vd ? kWinSlots : 16) + kWinSlots * (cw / 8) + (vd ? kWinDictMax * 8 : 16) + pg * 64 * 8 * nv;
+}
+// (... as many of the four as the workgroup's LDS -- window, streams, the stashed sums -- lets a CU hold: asking for more only
+//  draws a compiler warning)
+constexpr int win_min_blocks(int m, bool vd, int def, int wpb = 4, int nv = 2, int pg = 2, int cw = 8) {
+    if (!(def > 0 && vd && m == 1 && wpb <= 4)) return 1;
+    const int fit = (160 * 1024) / (wpb * (lds_bytes_per_wave(nv, pg, cw, vd) + def * 64 * 16) + 256);
+    return fit >= 4 ? 4 : (fit >= 1 ? fit : 1);
+}
 template <int NV, int EPI, int M, int PG, int CW, bool VD, int WPB, int DEPTH, int DEF = 0>
-__global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF, WPB)) void k_win_tiles(
+__global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF, WPB, NV, PG, CW)) void k_win_tiles(
     WinDev A, const int4* __restrict__ wt, int ntiles,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
     const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,
@@ -1186,15 +1201,6 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF, WPB)) void k_w
     }
 }
 
-// Waves per workgroup.  Every workgroup of the one-launch iteration sums the previous launch's partial rows in its
-// prologue (one row per workgroup): B workgroups read B rows each, and at 2048 two-wave workgroups that was ~7 us
-// of a 160 us launch (S3), a quarter of a 37 us one (one eighth of S3).  Four-wave workgroups halve B at the same
-// number of resident waves (S3 +4 %, S1 +14 %, S3/8 +25 %, profiles/r02_sweeps.md) -- unless a four-wave
-// workgroup's LDS no longer lets two of them share a CU (the 12-page plain geometry: S2 plain -16 %), then two.
-constexpr int lds_bytes_per_wave(int nv, int pg, int cw, bool vd) {
-    if (cw == 32) return 16 + 16 + 16 + 16 + pg * 64 * 8 * nv;             // pattern tiles: the window only
-    return (vd ? 16 : kWinSlots * 8) + (vd ? kWinSlots : 16) + kWinSlots * (cw / 8) + (vd ? kWinDictMax * 8 : 16) + pg * 64 * 8 * nv;
-}
 constexpr int waves_per_block(int nv, int pg, int cw, bool vd) {
 #ifdef PRCG_WIN_WPB
     return PRCG_WIN_WPB;

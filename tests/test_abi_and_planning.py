@@ -372,7 +372,7 @@ def test_missing_x_true_is_refused_for_large_systems():
         cg_variants.pipe_pr_cg(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), 5, callbacks=[error_A_norm])
 
 
-def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8):
+def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8, allow_runs=True):
     A = A.tocsr()
     n = A.shape[0]
     indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
@@ -386,7 +386,7 @@ def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8):
     val = np.zeros(arr_cap)
     col = np.zeros(arr_cap, dtype=np.uint16)
     rows = np.zeros((cap * 64, 2), dtype=np.int32)
-    got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), int(sigma), int(planes),
+    got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), int(sigma), int(planes), int(allow_runs),
                                  L.ptr(slices), cap, L.ptr(val), L.ptr(col), arr_cap, L.ptr(rows), rows.size, L.ptr(stats))
     return got, slices[:max(got, 0)], val, col, stats, rows
 
@@ -403,7 +403,7 @@ def slice_rows(sl, rows):
     return [(int(r), int(ln)) for r, ln in ent[:k]]
 
 
-@pytest.mark.parametrize('name', ['fem', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256', 'wide_gaps'])
+@pytest.mark.parametrize('name', ['fem', 'fem_runs_off', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256', 'wide_gaps'])
 def test_sliced_row_layout_holds_exactly_the_matrix(name):
     """Host planner of the lane-per-row kernels (prcg_plan.cpp: plan_sell): every row in exactly one slice (classes apart,
     class 0 first), and reading the re-laid arrays back with the kernel's index formula gives the caller's CSR rows,
@@ -415,8 +415,8 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
     rng = np.random.default_rng(9)
     row_class = None
     sigma = 0
-    if name == 'fem':
-        A = problems.fem_like_3d(9, 3)
+    if name in ('fem', 'fem_runs_off'):
+        A = problems.fem_like_3d(9, 3)       # three unknowns per node, full 3 x 3 blocks: aligned runs of three columns -> one code per run
         sigma = 64
     elif name == 'ragged':
         n = 5000
@@ -446,7 +446,7 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
         full = problems.fem_like_3d(10, 3)
         A, ghost_ids = partition.localize(full[900:2100], 900, 2100)
         row_class = np.array([(A.indices[A.indptr[i]:A.indptr[i + 1]] >= 1200).any() for i in range(1200)])
-    got, slices, val, col, stats, rows = plan_sell(A, row_class, sigma=sigma)
+    got, slices, val, col, stats, rows = plan_sell(A, row_class, sigma=sigma, allow_runs=name != 'fem_runs_off')
     assert got > 0, got
     n = A.shape[0]
     sig = int(stats[4])
@@ -454,6 +454,8 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
     if name == 'irregular':
         assert sig > 64                                  # consecutive rows would pad by ~30 %
         assert stats[3] <= 1.10 * A.nnz
+    run = int(stats[9])
+    assert run == (3 if name in ('fem', 'ghosts', 'fem_runs_off') and name != 'fem_runs_off' else 1), (name, run)
     lens_all = np.diff(A.indptr)
     seen = np.zeros(n, dtype=int)
     used_v = np.zeros(int(stats[1]), dtype=bool)
@@ -476,17 +478,23 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
             stored_max = max(stored_max, stored)
             u = np.arange(stored)
             vi = voff + ((u >> 1) * 64 + lane) * 2 + (u & 1)
-            ci = coff + ((u >> 3) * 64 + lane) * 8 + (u & 7)
-            # decode as the kernel does: a running column moved by code - 16384 per position; codes 0 / 65535 name no nonzero
+            # decode as the kernel does: one code per run of `run` positions; a running column moved by code - 16384 per code (to the
+            # run's first column); codes 0 / 65535 name no nonzeros
+            assert stored % run == 0
+            cidx = np.arange(stored // run)
+            ci = coff + ((cidx >> 3) * 64 + lane) * 8 + (cidx & 7)
             code = col[ci].astype(np.int64)
-            running = cbase + np.cumsum(code - 16384)
-            real = (code != 0) & (code != 65535)
+            start = cbase + np.cumsum(code - 16384)
+            real_run = (code != 0) & (code != 65535)
+            running = (np.repeat(start, run) + np.tile(np.arange(run), cidx.size))
+            real = np.repeat(real_run, run)
             assert real.sum() == hi - lo and (ln is not None or real.all())
             assert np.array_equal(running[real], A.indices[lo:hi])
             assert np.array_equal(val[vi][real].view(np.uint64), A.data[lo:hi].view(np.uint64))
             used_v[vi[real]] = True
             # behind the row: code 16384 (the column stays), up to the slice's width
-            tail = np.arange(stored, (width + 7) // 8 * 8)
+            ncodes = ((width + run - 1) // run + 7) // 8 * 8
+            tail = np.arange(stored // run, ncodes)
             assert np.all(col[coff + ((tail >> 3) * 64 + lane) * 8 + (tail & 7)] == 16384)
         assert width == stored_max
     assert np.all(seen == 1)
