@@ -352,23 +352,7 @@ def main():
     sched = dev.schedule()
     spmv = product_rates(dev, sched, n, nnz_total) if world == 1 else None
 
-    # N > 1: the paper's contrast in one run -- after the default schedule (one launch per iteration, direct peer exchange) the same
-    # loop on the RCCL schedule (update kernel + two-vector SpMM, halo and the single all-reduce on side streams: the GPU form of
-    # scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173), a short second leg
     rccl_leg = None
-    if world > 1 and args.variant.startswith('pipe_') and fallback is None and sched.get('peer') and not args.no_rccl_leg:
-        try:
-            op2 = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
-            e2, q2, tim2, fin2, err2 = timed_run(op2.dev, variant, b, x0, inv_diag, K=min(K, 100))
-            s2 = op2.dev.schedule()
-            rccl_leg = {'what': 'the same loop on the RCCL side-stream schedule (PRCG_PEER=0): update kernel + SpMM, halo send/recv or merged '
-                                'all-gather and ONE all-reduce per iteration on communication streams',
-                        'rccl_ranks': world, 'value': min(K, 100) / e2 if not err2 else None, 'unit': 'iters/s', 'steps': min(K, 100),
-                        'ms_per_step': e2 / min(K, 100) * 1e3, 'residual_finite': fin2, 'error': err2,
-                        'merged_exchange': s2.get('gather'), 'one_launch': s2.get('fused_comm'), 'host_enqueue_us_per_step': q2 / min(K, 100) * 1e6}
-            op2.dev.close()
-        except Exception as exc:
-            rccl_leg = {'rccl_ranks': world, 'error': str(exc)[:300]}
 
     # An operator whose values do not repeat (an assembled FEM matrix) streams the doubles themselves: time
     # that path too, same matrix, value dictionary off.  This leg IS what SURVEY.md 8d's algorithmic bytes
@@ -540,6 +524,28 @@ def main():
         except Exception as exc:
             others['small_systems_error'] = str(exc)[:300]
 
+    def run_rccl_leg():
+        """N > 1: the paper's contrast in one run -- after the default schedule (one launch per iteration, direct peer exchange) the same
+        loop on the RCCL schedule (update kernel + two-vector SpMM, halo and the single all-reduce on side streams: the GPU form of
+        scaling_experiments_petsc/cg_impls/pipeprcg.c:154-173), a short second leg.  Runs LAST, behind a watchdog on rank 0: if it has
+        not finished after 120 s the line is written without it -- a second schedule must never cost the run its first number."""
+        if not (world > 1 and args.variant.startswith('pipe_') and fallback is None and sched.get('peer') and not args.no_rccl_leg):
+            return None
+        try:
+            op2 = scaling.RowBlockOperator(comm, A_rows, device=local_rank, knobs={'PRCG_FUSED_COMM': '0', 'PRCG_PEER': '0'})
+            k2 = min(K, 100)
+            e2, q2, tim2, fin2, err2 = timed_run(op2.dev, variant, b, x0, inv_diag, K=k2)
+            s2 = op2.dev.schedule()
+            leg = {'what': 'the same loop on the RCCL side-stream schedule (PRCG_PEER=0): update kernel + SpMM, halo send/recv or merged '
+                           'all-gather and ONE all-reduce per iteration on communication streams',
+                   'rccl_ranks': world, 'value': k2 / e2 if not err2 else None, 'unit': 'iters/s', 'steps': k2,
+                   'ms_per_step': e2 / k2 * 1e3, 'residual_finite': fin2, 'error': err2,
+                   'merged_exchange': s2.get('gather'), 'one_launch': s2.get('fused_comm'), 'host_enqueue_us_per_step': q2 / k2 * 1e6}
+            op2.dev.close()
+            return leg
+        except Exception as exc:
+            return {'rccl_ranks': world, 'error': str(exc)[:300]}
+
     if rank == 0:
         fused = sched['fused']
         kbytes, kname = launch_bytes(args.variant, sched, n_local, nnz_local)
@@ -621,8 +627,6 @@ def main():
             roof['spmv'] = spmv
         if multi:
             roof['multi_rank_schedule'] = multi
-        if rccl_leg:
-            roof['rccl_schedule'] = rccl_leg
         out = {
             'metric': f'{args.variant} iterations/sec (synthetic banded CSR, fp64)',
             'value': K / elapsed, 'unit': 'iters/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -647,8 +651,32 @@ def main():
             out['cpu_baseline'] = cpu_baseline(A_rows.tocsr(), b, x0, FAMILY[args.variant], args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        line_written = []
+
+        def write_line():
+            if not line_written:
+                line_written.append(1)
+                sys.stdout.flush()
+                os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+        if world > 1:
+            import threading
+
+            def give_up():
+                out['roofline']['rccl_schedule'] = {'rccl_ranks': world, 'error': 'the RCCL second leg did not finish within 120 s: line written without it'}
+                write_line()
+                os._exit(0)
+            dog = threading.Timer(120.0, give_up)
+            dog.daemon = True
+            dog.start()
+            leg = run_rccl_leg()
+            dog.cancel()
+            if leg:
+                out['roofline']['rccl_schedule'] = leg
+                out['config']['rccl_ranks'] = world if not leg.get('error') else out['config']['rccl_ranks']
+        write_line()
+    elif world > 1:
+        run_rccl_leg()
 
     dev.close()
     if world > 1:

@@ -221,6 +221,13 @@ struct prcg_handle {
     prcg_replace_fn replace_fn = nullptr; void* replace_ctx = nullptr;       // gv_cg's w_replace predicate (prcg_set_replace_hook)
     std::vector<double> cb_in, cb_out;
     DevBuf cb_stage, ut;         // staging for strided operands; u~ = M^-1 u of the pipelined variants
+    bool pr_packed = false;      // ... unpreconditioned, no per-iteration vector recorder: inside a prcg_iterate call the state lives PACKED,
+                                 // one 32-byte entry (z, zs, p, x) per row in q / q2 (kEpiPROneQ: 16-byte accesses only); packed at the
+                                 // call's first iteration, unpacked into r, s, p, x at its end
+    bool pr_q_valid = false;     // ... the packed copy q_cur is the current state
+    int want_pr_pack = -1;       // PRCG_PR_PACK=0|1; default: pattern-tile operators only (S2: +7.6 %; S3 +-0; S2 with plain values -12 %)
+    double* q_cur = nullptr;
+    DevBuf q, q2;
     bool pr_fused = false;       // non-pipelined predict-and-recompute (pr, m) on a window operator: ONE launch per iteration
                                  // (window formed as (z - a zs) + b p_old); z, zs, p double-buffered:
     double* cur_r = nullptr; double* cur_s = nullptr; double* cur_rt = nullptr; double* cur_st = nullptr;
@@ -306,10 +313,10 @@ struct prcg_handle {
     bool debug_short_sources = false;    // PRCG_DEBUG_SHORT_SOURCES=1 (TESTS ONLY): Hestenes-Stiefel sessions allocate r without
                                          // the spare entries a window source needs -- the launch must be refused, not fault
     // every vector a window launch may stage (the pointer handed to the launch lies inside one of them)
-    const DevBuf* owner(const void* q) const {
+    const DevBuf* owner(const void* ptr) const {
         const DevBuf* all[] = {&tmp_ext, &t1, &x, &xp, &p, &p2, &rs, &rs2, &rst, &rst2, &wu, &wt, &wv, &r, &r2, &s, &s2, &rt, &rt2,
-                               &st, &st2, &b, &xt, &dinv, &e_ext, &w, &w2, &u, &u2, &tvec, &t2, &ut, &cb_stage};
-        const char* c = static_cast<const char*>(q);
+                               &st, &st2, &b, &xt, &dinv, &e_ext, &w, &w2, &u, &u2, &tvec, &t2, &ut, &cb_stage, &q, &q2};
+        const char* c = static_cast<const char*>(ptr);
         for (const DevBuf* d : all)
             if (d->p && c >= static_cast<const char*>(d->p) && c < static_cast<const char*>(d->p) + d->bytes) return d;
         return nullptr;
@@ -550,6 +557,7 @@ double* dots_at(prcg_t* h, int k) { return h->dots.d() + (size_t)k * kNS; }
 double* coef_at(prcg_t* h, int k) { return h->coef.d() + (size_t)k * kCoefStride; }
 
 void fused_flush(prcg_t* h);
+void pr_unpack(prcg_t* h);
 void hs_flush(prcg_t* h);
 void cg_flush(prcg_t* h);
 int apply_prec(prcg_t* h, const double* src, int sstride, double* dst, int dstride);
@@ -560,7 +568,7 @@ int record(prcg_t* h, int k) {
     if (!(m & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM))) return PRCG_OK;
     if (h->fused && !h->fused_comm) fused_flush(h);    // the recorders reuse the partials buffers
     if (h->hs_fused) hs_flush(h);
-    if (h->pr_fused) fused_flush(h);
+    if (h->pr_fused) { fused_flush(h); pr_unpack(h); }
     if (h->cg_one) cg_flush(h);
     if (h->fused_comm && h->red_pending) HIPCHK(h, hipStreamWaitEvent(h->sc, h->red_event, 0));
     if (h->peer && h->pend_parts > 0) {
@@ -997,17 +1005,46 @@ int iterate_pr_fused(prcg_t* h, int k) {
     f.pr.z_new = z_new; f.pr.zs_new = zs_new; f.pr.p_new = p_new;
     f.pr.x = h->x.d();
     f.pr.r = jac ? h->r.d() : nullptr; f.pr.s = jac ? h->s.d() : nullptr; f.pr.d = jac ? h->dinv.d() : nullptr;
+    if (h->pr_packed) {
+        // the state as 16-byte pairs (z, zs) and (p, x): packed once per prcg_iterate call (pr_unpack at its end); each of q / q2
+        // holds the (z, zs) pairs with ghost room and spare entries, then the (p, x) pairs
+        const size_t half = (size_t)2 * (h->n + h->g + kGatherPad);
+        if (!h->pr_q_valid) {
+            h->q_cur = h->q.d();
+            launch_copy(h->sc, h->q_cur + 0, 2, z_cur, 1, h->n);
+            launch_copy(h->sc, h->q_cur + 1, 2, zs_cur, 1, h->n);
+            launch_copy(h->sc, h->q_cur + half + 0, 2, h->p_cur, 1, h->n);
+            launch_copy(h->sc, h->q_cur + half + 1, 2, h->x.d(), 1, h->n);
+            h->pr_q_valid = true;
+        }
+        double* q_other = (h->q_cur == h->q.d()) ? h->q2.d() : h->q.d();
+        f.pr.q_old = h->q_cur; f.pr.px_old = h->q_cur + half;
+        f.pr.q_new = q_other; f.pr.px_new = q_other + half;
+    }
     double* part_out = (h->pend_buf == h->partB.d()) ? h->partC.d() : h->partB.d();
     bool on = false;
-    SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.p_old, 1});
+    if (h->pr_packed) SRCCHK2(h, {f.pr.q_old, 2}, {f.pr.px_old, 2});
+    else SRCCHK2(h, {f.pr.z_old, 1}, {f.pr.zs_old, 1}, {f.pr.p_old, 1});
     prof_begin(h, h->ev_spmv, h->n_ev_spmv, k, on);
     const int grid = launch_win_pr_one(h->sc, h->wdev(), h->wtile_ptr(0), h->nwt_int + h->nwt_bnd, h->win_geom, f,
                                        (meurant(h->variant) ? 1 : 0) | (h->stream_stores ? 2 : 0), part_out, coef_at(h, k), h->win_per_cu);
     LAUNCHCHK(h, grid);
     prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
     h->pend_parts = grid; h->pend_k = k; h->pend_buf = part_out; h->last_grid = grid;
-    z_cur = z_new; zs_cur = zs_new; h->p_cur = p_new;
+    if (h->pr_packed) h->q_cur = f.pr.q_new;
+    else { z_cur = z_new; zs_cur = zs_new; h->p_cur = p_new; }
     return PRCG_OK;
+}
+
+// end of a prcg_iterate call of a packed predict-and-recompute session: the packed entries back into r, s, p, x
+void pr_unpack(prcg_t* h) {
+    if (!h->pr_packed || !h->pr_q_valid) return;
+    const size_t half = (size_t)2 * (h->n + h->g + kGatherPad);
+    launch_copy(h->sc, h->cur_r, 1, h->q_cur + 0, 2, h->n);
+    launch_copy(h->sc, h->cur_s, 1, h->q_cur + 1, 2, h->n);
+    launch_copy(h->sc, h->p_cur, 1, h->q_cur + half + 0, 2, h->n);
+    launch_copy(h->sc, h->x.d(), 1, h->q_cur + half + 1, 2, h->n);
+    h->pr_q_valid = false;
 }
 
 PrArgs pr_args(prcg_t* h, int k) {
@@ -1277,6 +1314,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
     else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 0;
     else if (k == "PRCG_SELL_RUNS") h->sell_runs_opt = v != 0;
+    else if (k == "PRCG_PR_PACK") h->want_pr_pack = v != 0 ? 1 : 0;
     else if (k == "PRCG_SELL_NT") { h->sell_nt_opt = v != 0; h->sell_nt = v != 0; }
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1291,7 +1329,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_RUNS", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_RUNS", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -2181,6 +2219,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->hs_fused = false;
     h->cg_fused = false;
     h->pr_fused = false;
+    h->pr_packed = false;
     h->hs_pend_mu = 0;
     h->small = false;
     h->medium = false;
@@ -2404,6 +2443,11 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->rt2.ensure((h->pr_fused && h->prec) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->st2.ensure((h->pr_fused && h->prec) ? (size_t)ne * D : 16, h->sc));
         HIPCHK(h, h->partC.ensure(h->pr_fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));
+        h->pr_packed = h->pr_fused && (h->want_pr_pack < 0 ? h->win_pat : h->want_pr_pack != 0) && !h->prec &&
+                       !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM));
+        h->pr_q_valid = false;
+        HIPCHK(h, h->q.ensure(h->pr_packed ? (size_t)4 * ne * D : 16, h->sc));
+        HIPCHK(h, h->q2.ensure(h->pr_packed ? (size_t)4 * ne * D : 16, h->sc));
         h->cur_r = h->r.d(); h->cur_s = h->s.d(); h->cur_rt = h->rt.d(); h->cur_st = h->st.d();
         h->pend_parts = 0; h->pend_k = -1; h->pend_buf = nullptr;
         launch_sub(sc, h->r.d(), 1, h->b.d(), 1, t1, 1, n);                 // r = b - A x
@@ -2515,7 +2559,7 @@ int prcg_iterate(prcg_t* h, int iters) {
     }
     if (h->fused && !h->fused_comm) fused_flush(h);    // dots of the last iteration: one reduction per call, not per iteration
     if (h->hs_fused) hs_flush(h);
-    if (h->pr_fused) fused_flush(h);
+    if (h->pr_fused) { fused_flush(h); pr_unpack(h); }
     if (h->cg_one) cg_flush(h);
     if (h->fused_comm && h->red_pending) {
         // the caller may read or rewrite state next (recorders, teacher forcing): finish the exchange of the last iteration

@@ -76,6 +76,11 @@ struct FusedPrev {
         double* z_new; double* zs_new; double* p_new;
         double* x; double* r; double* s; const double* d;
         double* rt; const double* st;      // Ghysels-Vanroose with Jacobi: r~ (updated in place) and s~ of the row
+        // PACKED form of the unpreconditioned iteration (kEpiPROneQ): the four values of a row as two 16-byte pairs, (z, zs) in
+        // q_old / q_new and (p, x) in px_old / px_new -- window pages: two 16-byte loads per lane instead of three 8-byte ones
+        // (the row's own x rides along), row results: two 16-byte stores, each a contiguous kilobyte per wave, instead of
+        // four 8-byte ones; the separate arrays above are not touched
+        const double* q_old; double* q_new; const double* px_old; double* px_new;
     } pr;
     // ONE launch per iteration of Chronopoulos-Gear / Ghysels-Vanroose (launch_win_cg_one): the p, s (u) update of the
     // previous iteration is deferred INTO this launch -- see the comment there.  z0, z1, z2: the three old vectors the
@@ -125,8 +130,9 @@ enum SpmvEpilogue {
     kEpiCGOne = 15,  // window kernels only: ONE launch per Chronopoulos-Gear iteration (launch_win_cg_one)
     kEpiCGOneJ = 16, // ... with Jacobi
     kEpiGVOne = 17,  // window kernels only: ONE launch per Ghysels-Vanroose iteration (unpreconditioned)
+    kEpiPROneQ = 18, // window kernels only: one-launch predict-and-recompute iteration on the PACKED state, pairs (z, zs) and (p, x) (PrOne::q_old, px_old)
 };
-constexpr bool epi_pr_one(int e) { return e == kEpiPROne || e == kEpiPROneJ; }
+constexpr bool epi_pr_one(int e) { return e == kEpiPROne || e == kEpiPROneJ || e == kEpiPROneQ; }
 constexpr bool epi_cg_w(int e) { return e == kEpiCGW || e == kEpiCGWJ; }
 constexpr bool epi_gv_w(int e) { return e == kEpiGVW || e == kEpiGVWJ; }
 // the launches that form their window from several old vectors and update the row's own vectors (FusedPrev::PrOne)

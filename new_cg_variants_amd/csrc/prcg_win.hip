@@ -106,7 +106,7 @@ template <> struct RegV<4> { using type = d4_t; };
 // (Chronopoulos-Gear product launch: (r, s[, d]) -> r~ = [d] (r - a s))
 constexpr int win_nw(int nv, int epi) {
     return (epi == kEpiHS || epi == kEpiCGW || epi == kEpiGVW) ? 2
-         : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ || epi == kEpiCGOne || epi == kEpiGVOne) ? 3 : (epi == kEpiCGOneJ ? 4 : nv));
+         : (epi == kEpiPROneQ ? 4 : ((epi_pr_one(epi) || epi == kEpiCGWJ || epi == kEpiGVWJ || epi == kEpiCGOne || epi == kEpiGVOne) ? 3 : (epi == kEpiCGOneJ ? 4 : nv)));
 }
 // The one-launch pr / cg / gv kernels need the RAW window triple of the lane's own row beside the formed window entry; the
 // row lies inside the tile's pages, which the wave holds raw in registers when it parks them: a cross-lane read instead of
@@ -241,7 +241,14 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
 #else
         if (p < d.np && !(CW == 32 && carry_ok && ((d.vdf >> (18 + p)) & 1))) {   // wave-uniform (sweep tables: a page the wave's previous tile left in LDS)
 #endif
+#ifdef PRCG_DEBUG_PAGE1_LANES         // TIMING EXPERIMENT (correct only for bands of half-bandwidth < PRCG_DEBUG_PAGE1_LANES / 2): the tile's last page is loaded by its first lanes only
+            if (p == d.np - 1 && p > 0 && lane >= PRCG_DEBUG_PAGE1_LANES) continue;
+#endif
             if constexpr (EPI == kEpiHS) { R.w[p].x = X[d.pc[p] + lane]; R.w[p].y = X2[d.pc[p] + lane]; }
+            else if constexpr (EPI == kEpiPROneQ) {                         // (z, zs) and (p, x): two 16-byte loads
+                const d2_t a = reinterpret_cast<const d2_t*>(pr.q_old)[d.pc[p] + lane], b = reinterpret_cast<const d2_t*>(pr.px_old)[d.pc[p] + lane];
+                R.w[p].x = a.x; R.w[p].y = a.y; R.w[p].z = b.x; R.w[p].w = b.y;
+            }
             else if constexpr (epi_pr_one(EPI)) {
                 R.w[p].x = pr.z_old[d.pc[p] + lane]; R.w[p].y = pr.zs_old[d.pc[p] + lane]; R.w[p].z = pr.p_old[d.pc[p] + lane];
             }
@@ -294,6 +301,12 @@ __device__ __forceinline__ void issue_loads(const WinDev& A, const WDesc<PG>& d,
             if constexpr (EPI == kEpiCGOneJ) R.dd[j] = lg->d[rr];
             if constexpr (EPI == kEpiGVOne) { R.rsx[j].x = lg->r[rr]; R.rsx[j].y = lg->s[rr]; }
         }
+        if constexpr (EPI == kEpiPROneQ) {
+            if constexpr (!row_from_pages(EPI, M, PG)) {
+                const d2_t a = reinterpret_cast<const d2_t*>(pr.q_old)[rr], b = reinterpret_cast<const d2_t*>(pr.px_old)[rr];
+                R.zrow[j].x = a.x; R.zrow[j].y = a.y; R.zrow[j].z = b.x; R.xp[j].x = b.y;
+            }
+        } else
         if constexpr (epi_rowset(EPI)) {
             if constexpr (!row_from_pages(EPI, M, PG)) { R.zrow[j].x = pr.z_old[rr]; R.zrow[j].y = pr.zs_old[rr]; R.zrow[j].z = pr.p_old[rr]; }
             R.xp[j].x = pr.x[rr];
@@ -452,6 +465,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
     int rs_[M], re_[M];
     FusedRowIn fin[M];
     d3_t zr[M];
+    double xq = 0.0;                        // packed predict-and-recompute, rows taken from the pages: the row's x
     if constexpr (row_from_pages(EPI, M, PG)) {
         // row rb + lane sits at window index own + lane: lane (own + lane) % 64 of page (own + lane) / 64 holds its raw triple
         const int p0 = dcur.own >> 6, src = (dcur.own + lane) & 63;
@@ -465,6 +479,16 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         const double ax = __shfl(a.x, src, 64), ay = __shfl(a.y, src, 64), az = __shfl(a.z, src, 64);
         const double bx = __shfl(b.x, src, 64), by = __shfl(b.y, src, 64), bz = __shfl(b.z, src, 64);
         zr[0].x = second ? bx : ax; zr[0].y = second ? by : ay; zr[0].z = second ? bz : az;
+        if constexpr (EPI == kEpiPROneQ) {                                  // the row's x: the fourth component of its page entry
+            double aw = 0.0, bw = 0.0;
+#pragma unroll
+            for (int p = 0; p < PG; ++p) {
+                if (p == p0) aw = R.w[p].w;
+                if (p == p0 + 1) bw = R.w[p].w;
+            }
+            const double sa = __shfl(aw, src, 64), sb = __shfl(bw, src, 64);
+            xq = second ? sb : sa;
+        }
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -477,7 +501,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
         }
         if constexpr (epi_rowset(EPI)) {
             if constexpr (!row_from_pages(EPI, M, PG)) zr[j] = R.zrow[j];
-            fin[j].xp.x = R.xp[j].x;
+            if constexpr (EPI == kEpiPROneQ && row_from_pages(EPI, M, PG)) fin[j].xp.x = xq; else fin[j].xp.x = R.xp[j].x;
             if constexpr (EPI == kEpiPROneJ) { fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y); fin[j].d = R.dd[j]; }
             if constexpr (EPI == kEpiCGWJ) fin[j].d = R.dd[j];
             if constexpr (epi_gv_w(EPI)) fin[j].rs = make_double2(R.rsx[j].x, R.rsx[j].y);
@@ -703,6 +727,12 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                 const double zn = zr[j].x - cf.al * zr[j].y;                // r~ -= a s~   (r -= a s without Jacobi)
                 const double pn = zn + cf.bt * zr[j].z;                     // p = r~ + b p_old
                 const bool st = c.fr.stream;
+                if constexpr (EPI == kEpiPROneQ) {
+                    // the row's packed pairs (z, zs = s) and (p, x): two 16-byte stores, a contiguous kilobyte per wave each
+                    store_pair(reinterpret_cast<double2*>(c.pr.q_new) + row, make_double2(zn, sum), st);
+                    store_pair(reinterpret_cast<double2*>(c.pr.px_new) + row, make_double2(pn, xn), st);
+                    acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
+                } else {
                 store_one(c.pr.x + row, xn, st);
                 store_one(c.pr.z_new + row, zn, st);
                 store_one(c.pr.p_new + row, pn, st);
@@ -716,6 +746,7 @@ __device__ __forceinline__ bool win_step(const WinDev& A, const WCtx<NV>& c, WRe
                 } else {
                     store_one(c.pr.zs_new + row, sum, st);
                     acc[0] += pn * sum; acc[1] += zn * sum; acc[2] += sum * sum; acc[3] += zn * zn;
+                }
                 }
             }
         } else if constexpr (EPI == kEpiCGOne || EPI == kEpiCGOneJ) {
@@ -1192,7 +1223,7 @@ __global__ __launch_bounds__(64 * WPB, win_min_blocks(M, VD, DEF, WPB, NV, PG, C
     }
 
     if constexpr (FUSED) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
-    else if constexpr (PR1) { if constexpr (EPI == kEpiPROne) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
+    else if constexpr (PR1) { if constexpr (EPI != kEpiPROneJ) acc[4] = acc[3]; win_block_reduce_store<WPB, 5>(acc, partials); }
     else if constexpr (epi_cg_w(EPI) || epi_gv_w(EPI) || epi_lag(EPI)) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI == kEpiCG) win_block_reduce_store<WPB, 5>(acc, partials);
     else if constexpr (EPI != kEpiNone) {
@@ -1463,6 +1494,9 @@ int launch_win_pr_one(hipStream_t st, const WinDev& A, const WTile* tiles, int n
     const int mask = 3 | ((meurant & 1) ? 4 : 0) | ((meurant & 2) ? 8 : 0);      // (bit 1 of `meurant`: streaming stores)
     if (f.pr.d)
         return launch_win<1, kEpiPROneJ>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, f.pr.d, nullptr, partials,
+                                         coef_out, f, per_cu);
+    if (f.pr.q_old)
+        return launch_win<1, kEpiPROneQ>(geom, st, A, tiles, ntiles, f.pr.q_old, f.pr.q_new, mask, nullptr, nullptr, nullptr, partials,
                                          coef_out, f, per_cu);
     return launch_win<1, kEpiPROne>(geom, st, A, tiles, ntiles, f.pr.z_old, f.pr.zs_new, mask, nullptr, nullptr, nullptr, partials,
                                     coef_out, f, per_cu);

@@ -757,7 +757,11 @@ def test_host_callback_preconditioner_tilde_vectors(amd, matrices, method):
 @pytest.mark.parametrize('source,variant,prec,knobs', [
     ('bcsstk03', 'PR', None, {}), ('nos7', 'PR', 'jacobi', {}), ('494_bus', 'M', 'jacobi', {}), ('nos4', 'M', None, {}),
     ('s3_small', 'PR', None, {}), ('s3_small', 'M', None, {'PRCG_VALDICT': '0'}), ('s1_small', 'PR', 'jacobi', {}),
-    ('lap3d_20', 'PR', None, {'PRCG_VALDICT': '0'})])
+    ('lap3d_20', 'PR', None, {'PRCG_VALDICT': '0'}),
+    # the PACKED state of the unpreconditioned iteration (pairs (z, zs) and (p, x), 16-byte accesses only; the default on pattern
+    # tiles -- lap3d_20 with its dictionary): band, pattern tiles, 2-byte window indices with plain values, a paper matrix
+    ('s3_small', 'PR', None, {'PRCG_PR_PACK': '1'}), ('lap3d_20', 'PR', None, {}), ('lap3d_20', 'PR', None, {'PRCG_PR_PACK': '0'}),
+    ('lap3d_20', 'M', None, {'PRCG_VALDICT': '0', 'PRCG_PR_PACK': '1'}), ('nos7', 'PR', None, {'PRCG_PR_PACK': '1'})])
 def test_one_launch_predict_and_recompute(amd, matrices, source, variant, prec, knobs):
     """pr_cg / m_cg (pr_pcg, m_pcg) on a window operator run ONE launch per iteration: the staged window of the new
     direction is formed as (r~ - a s~) + b p_old while it is parked (pr_cg.py:148,151), s = A p follows, the row's own
