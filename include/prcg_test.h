@@ -94,10 +94,11 @@ int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices
  * running column by code - 16384 and -- unless the code is 0 or 65535 (skips: -16384 / +49151, no nonzero) -- names a
  * nonzero at the column reached; shorter rows are padded (value 0, code 16384; never multiplied).
  * sigma: sorting window in rows -- 64: a slice holds consecutive rows [first row, end row); larger (SELL-C-sigma): every
- * window of sigma consecutive rows of one class is sorted by descending length (stable) before it is cut; slices of such
+ * window of sigma consecutive rows of one class is sorted by descending number of trips (ceil(length / 8), or / 24 with run
+ * codes; stable) before it is cut; slices of such
  * windows, and slices with a row that needs skips, name their rows: lane l holds row rows_out[2 * (rows_off + l)] of STORED
  * length rows_out[2 * (rows_off + l) + 1] (row -1, length 0 behind the last); 0: 64 while that pads by at most 6 %, else the
- * smallest of 256, 1024, 4096 whose padding stays within 4 % (else the one that pads least).  planes > 1: the class-0 table
+ * smallest of 256, 1024, 4096, 16384 whose padding stays within 4 % or within 1 % of the least.  planes > 1: the class-0 table
  * interleaves groups of that many grid planes when the operator has a dominant far column offset (any table order is correct).
  * slices_out: 8 int32 per slice {first (smallest) row, that + rows, voff, coff, longest stored row, cbase, rows_off or -1, 0};
  * allow_runs != 0: an operator whose every row consists of aligned runs of three consecutive columns stores ONE code per run

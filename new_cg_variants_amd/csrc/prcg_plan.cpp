@@ -642,26 +642,29 @@ namespace {
 // rows of one class run [a, b) in slice order for a sorting window of `sigma` rows: windows of sigma consecutive rows,
 // inside a window the rows by descending length (stable: rows of equal length keep their order, so an operator whose
 // rows all have the window's length keeps consecutive rows); sigma <= 64: no sorting
-void sell_run_order(const int32_t* indptr, int64_t a, int64_t b, int sigma, std::vector<int32_t>& perm) {
+void sell_run_order(const int32_t* indptr, int64_t a, int64_t b, int sigma, int trip, std::vector<int32_t>& perm) {
     const size_t first = perm.size();
     for (int64_t r = a; r < b; ++r) perm.push_back((int32_t)r);
     if (sigma <= 64) return;
     for (int64_t w = a; w < b; w += sigma) {
         int32_t* lo = perm.data() + first + (w - a);
         int32_t* hi = perm.data() + first + (std::min<int64_t>(w + sigma, b) - a);
-        std::stable_sort(lo, hi, [&](int32_t x, int32_t y) { return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y]; });
+        // by descending number of TRIPS, not of nonzeros: a wave walks a slice trip by trip (`trip` positions each), rows of 57 and of
+        // 64 nonzeros cost it the same eight -- and within a class the rows keep their order, so a slice's lanes hold longer runs of
+        // neighbouring rows (whose gathers share cache lines: what a sorted slice loses against consecutive rows, r04_sweeps.md B)
+        std::stable_sort(lo, hi, [&](int32_t x, int32_t y) { return (indptr[x + 1] - indptr[x] + trip - 1) / trip > (indptr[y + 1] - indptr[y] + trip - 1) / trip; });
     }
 }
 
 // padded nonzeros of the sliced layout for a sorting window of sigma rows
-int64_t sell_padded(int64_t n, const int32_t* indptr, const uint8_t* row_class, int sigma) {
+int64_t sell_padded(int64_t n, const int32_t* indptr, const uint8_t* row_class, int sigma, int trip) {
     int64_t tot = 0, r = 0;
     std::vector<int32_t> perm;
     while (r < n) {
         int64_t e = r + 1;
         if (row_class) { while (e < n && (row_class[e] != 0) == (row_class[r] != 0)) ++e; } else e = n;
         perm.clear();
-        sell_run_order(indptr, r, e, sigma, perm);
+        sell_run_order(indptr, r, e, sigma, trip, perm);
         for (size_t i = 0; i < perm.size(); i += 64) {
             int w = 0;
             for (size_t j = i; j < std::min(perm.size(), i + 64); ++j) w = std::max(w, indptr[perm[j] + 1] - indptr[perm[j]]);
@@ -724,20 +727,6 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         for (int64_t r = 0; r < n; ++r) longest = std::max(longest, indptr[r + 1] - indptr[r]);
         if (longest > 1024 && (int64_t)longest * n > 16 * std::max<int64_t>(nnz, 1)) return false;
     }
-    // --- the sorting window (SELL-C-sigma): 64 (rows stay consecutive: coalesced row operands, the smallest gather footprint)
-    // while that pads by at most opt.target64; else the smallest of 256, 1024, 4096 whose padding is within opt.target of
-    // the nonzeros, else the one that pads least
-    int sigma = opt.sigma;
-    if (sigma <= 0) {
-        int64_t best_pad = -1;
-        for (int cand : {64, 256, 1024, 4096}) {
-            const int64_t pd = sell_padded(n, indptr, row_class, cand);
-            if (best_pad < 0 || pd < best_pad) { best_pad = pd; sigma = cand; }
-            if ((double)pd <= (cand == 64 ? opt.target64 : opt.target) * (double)std::max<int64_t>(nnz, 1)) { sigma = cand; break; }
-        }
-    }
-    if (sigma < 64) sigma = 64;
-    out.sigma = sigma;
     // --- column RUNS: if every row consists of aligned runs of 3 consecutive columns (an assembled matrix with three unknowns
     // per node and full 3 x 3 blocks: Queen_4147's structure), ONE code per run is stored instead of one per nonzero
     // (8 + 2/3 instead of 10 bytes per nonzero)
@@ -753,6 +742,26 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         if (ok3) run = 3;
     }
     out.run = run;
+    // --- the sorting window (SELL-C-sigma): 64 (rows stay consecutive: coalesced row operands, the smallest gather footprint)
+    // while that pads by at most opt.target64; else the smallest of 256, 1024, 4096 whose padding is within opt.target of
+    // the nonzeros, else the one that pads least
+    int sigma = opt.sigma;
+    if (sigma <= 0) {
+        int64_t best_pad = -1;
+        int64_t pads[5];
+        const int cands[5] = {64, 256, 1024, 4096, 16384};
+        for (int i = 0; i < 5; ++i) {
+            pads[i] = sell_padded(n, indptr, row_class, cands[i], 8 * run);
+            if (best_pad < 0 || pads[i] < best_pad) best_pad = pads[i];
+            if (i == 0 && (double)pads[0] <= opt.target64 * (double)std::max<int64_t>(nnz, 1)) break;
+        }
+        sigma = 64;
+        if ((double)pads[0] > opt.target64 * (double)std::max<int64_t>(nnz, 1))
+            for (int i = 1; i < 5; ++i)
+                if ((double)pads[i] <= opt.target * (double)std::max<int64_t>(nnz, 1) || (double)pads[i] <= 1.01 * (double)best_pad) { sigma = cands[i]; break; }
+    }
+    if (sigma < 64) sigma = 64;
+    out.sigma = sigma;
     // pass 1: slices, widths, offsets.  A row's columns are stored as 16-bit DELTAS (prcg_plan.h); a gap too wide for one
     // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips
     std::vector<SellSlice> all;
@@ -776,7 +785,7 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         int64_t e = r + 1;
         if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
         rrun.clear();
-        sell_run_order(indptr, r, e, sigma, rrun);
+        sell_run_order(indptr, r, e, sigma, 8 * run, rrun);
         for (size_t i = 0; i < rrun.size(); i += 64) {
             const size_t je = std::min(rrun.size(), i + 64);
             int32_t rmin = INT32_MAX, cbase = INT32_MAX;

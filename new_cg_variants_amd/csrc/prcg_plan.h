@@ -141,9 +141,9 @@ bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const in
 // Which rows: rows_off = -1: the slice holds the consecutive rows [rb, re), their stored lengths are the row pointers'
 // (no skips).  Otherwise lane l holds row rows[2 * (rows_off + l)] with stored length rows[2 * (rows_off + l) + 1]
 // (64 pairs per slice; row -1, length 0 behind the last) and rb is the smallest of them: slices of a sorting window wider
-// than 64 (SELL-C-sigma: every window of sigma consecutive rows of one class is sorted by descending row length --
-// stable -- before it is cut into slices, so that rows of similar length share a slice and the padding stays small for
-// operators whose row lengths vary), and slices with a row that needs skips.  Every row is still summed left to right
+// than 64 (SELL-C-sigma: every window of sigma consecutive rows of one class is sorted by descending number of TRIPS --
+// ceil(length / (8 run)), what a wave pays for a row; stable, so rows of one trip count stay neighbours -- before it is cut
+// into slices, so that rows of similar length share a slice and the padding stays small for operators whose row lengths vary), and slices with a row that needs skips.  Every row is still summed left to right
 // by ONE lane: the products are scipy's bit for bit whatever the order.
 // Returns false (nothing built) if the operator does not qualify: padding would exceed `max_overhead` x nnz.
 constexpr int kSellDeltaBias = 16384;
@@ -154,8 +154,8 @@ struct SellSlice { int rb, re, voff, coff, width, cbase, rows_off, flags; };
 static_assert(sizeof(SellSlice) == 32, "the kernels read a slice descriptor as two int4");
 struct SellOptions {
     double max_overhead = 1.25;      // most padded nonzeros per nonzero
-    int sigma = 0;                   // sorting window in rows (64: none); 0: 64 if that pads <= target64, else the smallest of
-    double target64 = 1.06;          //    256, 1024, 4096 that pads <= target (else the one that pads least)
+    int sigma = 0;                   // sorting window in rows (64: none); 0: 64 if that pads <= target64, else the smallest of 256,
+    double target64 = 1.06;          //    1024, 4096, 16384 that pads <= target or within 1 % of the one that pads least
     double target = 1.04;
     int planes = 8;                  // class-0 slices of this many consecutive grid planes are interleaved in the table (<= 1: row order)
     bool allow_runs = true;          // operators whose rows are aligned runs of 3 consecutive columns store one code per run
