@@ -767,7 +767,8 @@ def test_bench_launched_as_the_driver_does_with_processes_sharing_the_gpu(world,
     through tests/transport/libprocs_ccl.so (PRCG_RCCL_LIB; RCCL refuses ranks that share a device).  What runs is the
     product's N > 1 path end to end: row blocks, halo plan over gloo, exchange buffers mapped ACROSS PROCESSES with hipIpc,
     the self-check of the one-launch schedule against the two-kernel schedule, the timed loop in which every rank's
-    launches wait in-kernel for the other processes' launches, max-over-ranks timing, one JSON line from rank 0."""
+    launches wait in-kernel for the other processes' launches, max-over-ranks timing, the second leg on the RCCL side-stream
+    schedule, one JSON line from rank 0."""
     import json
     env = dict(os.environ)
     env.update({'MASTER_ADDR': '127.0.0.1', 'OMP_NUM_THREADS': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'PRCG_BENCH_DEVICE': '0',
@@ -788,6 +789,11 @@ def test_bench_launched_as_the_driver_does_with_processes_sharing_the_gpu(world,
     assert d['config']['schedule_fallback'] is None, d['config']['schedule_fallback']
     assert s['peer'] and s['fused_comm'] and s['window'] and d['config']['residual_finite'], s
     assert d['value'] > 1        # (processes time-share the GPU while their launches wait for each other: no performance figure)
+    # the second, short leg of an N > 1 run: the same loop on the RCCL side-stream schedule (the paper's contrast from one run)
+    leg = d['roofline'].get('rccl_schedule')
+    assert leg and leg.get('rccl_ranks') == world and not leg.get('error') and leg['value'] > 1 and leg['residual_finite'], leg
+    assert d['config']['rccl_ranks'] == world
+    print(f"   RCCL side-stream schedule, same run: {leg['value']:.0f} it/s (merged exchange {leg['merged_exchange']})")
 
 
 @pytest.mark.gpu
