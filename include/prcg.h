@@ -215,6 +215,7 @@ int prcg_iteration(const prcg_t* h);
 #define PRCG_SCHED_STREAM_STORES 131072 /* the one-launch iteration writes its row results with nontemporal stores (vectors far larger than the caches) */
 #define PRCG_SCHED_SELL_SORTED 262144  /* sliced rows with a sorting window wider than a slice (SELL-C-sigma: row lengths vary) */
 #define PRCG_SCHED_NT_LOADS 524288     /* sliced rows: value / column-code streams read with nontemporal loads (operator far larger than the Infinity Cache) */
+#define PRCG_SCHED_SELL_WINDOW 2097152 /* sliced rows with WINDOW codes: a slice's input entries staged in LDS, per nonzero an LDS read instead of a gather */
 #define PRCG_SCHED_MEDIUM 1048576      /* mid-size system: the whole pipelined solve in one launch of a few co-operating workgroups */
 #define PRCG_SCHED_WINDOW 4096  /* row-per-lane window kernels (bands, stencils): the column stream holds indices into the tile's
                                    LDS-staged window of the input vector */

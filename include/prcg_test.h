@@ -103,13 +103,19 @@ int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices
  * slices_out: 8 int32 per slice {first (smallest) row, that + rows, voff, coff, longest stored row, cbase, rows_off or -1, 0};
  * allow_runs != 0: an operator whose every row consists of aligned runs of three consecutive columns stores ONE code per run
  * (code c of a row: its positions 3c..3c+2 at the run's first column +0, +1, +2; c at col16[coff + ((c/8)*64 + l)*8 + c%8]).
- * stats[0..10) = {class-0 slices, elements of val, elements of col16, padded nonzeros, sigma chosen, far stride in rows
- * (0: none), planes interleaved (0: row order), elements of rows, column codes in use, positions per code (1 | 3)}.
+ * window_granules > 0: when the rows stay consecutive (sigma 64) and EVERY slice's columns fit that many granules of 16
+ * consecutive columns, WINDOW codes are stored instead of deltas: slice descriptor {.., cbase = its first entry of gran_out,
+ * rows_off = -1, flags = 2 | granules << 8}; a code is 16 g + (column - gran_out[cbase + g]) for the last granule g that starts
+ * at or before the (run's first) column; no skips, padding code 0.  The kernels stage the granules in LDS (at most 48).
+ * stats[0..12) = {class-0 slices, elements of val, elements of col16, padded nonzeros, sigma chosen, far stride in rows
+ * (0: none), planes interleaved (0: row order), elements of rows, column codes in use, positions per code (1 | 3), the most
+ * granules of a slice (0: delta codes), elements of gran}.
  * Returns the number of slices, 0 if the operator does not qualify (padding beyond max_overhead x nnz), -needed if a
  * capacity is too small, -1 on a bad argument.  What prcg_set_csr runs for rows of 24 nonzeros and more. */
 int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-                       double max_overhead, int sigma, int planes, int allow_runs, int32_t* slices_out, int64_t capacity, double* val_out,
-                       uint16_t* col_out, int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity, int64_t* stats);
+                       double max_overhead, int sigma, int planes, int allow_runs, int window_granules, int32_t* slices_out, int64_t capacity,
+                       double* val_out, uint16_t* col_out, int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity,
+                       int32_t* gran_out, int64_t gran_capacity, int64_t* stats);
 /* Merged exchange of the multi-GPU pipelined loop (small halos ride on the one all-gather per
  * iteration): where in the gathered buffer do this rank's ghost rows lie?  `tables`: every rank's
  * send table, doubles_per_table doubles each: [n_peers, (peer, first row of its list, rows)...];

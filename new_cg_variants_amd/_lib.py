@@ -81,7 +81,8 @@ _SIGNATURES = {
     'prcg_solve': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_uint32, _P, _P, C.POINTER(Timings)]),
     'prcg_stream_ceiling': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     'prcg_plan_gather': (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int64, _P]),
-    'prcg_plan_sell': (C.c_int64, [C.c_int64, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, _P]),
+    'prcg_plan_sell': (C.c_int64, [C.c_int64, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, _P,
+                                    C.c_int64, _P]),
     'prcg_plan_tiles': (C.c_int64, [C.c_int64, _P, _P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64)]),
     'prcg_plan_window': (C.c_int64, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int)]),

@@ -140,12 +140,15 @@ struct prcg_handle {
     bool sell = false;
     int nst_int = 0, nst_bnd = 0;        // interior slices first, then slices touching ghost columns
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
-    DevBuf sval, scol, sslices, srows;
+    DevBuf sval, scol, sslices, srows, sgran;
+    int sell_window = 0;                 // > 0: WINDOW codes -- the kernels stage a slice's input entries in LDS (prcg_plan.h); the most granules of a slice
+    int sell_window_opt = 48;            // PRCG_SELL_WINDOW=0 turns them off (delta codes, gathers from memory)
     int sell_sigma_opt = 0;              // PRCG_SELL_SIGMA: sorting window of the sliced layout in rows (0: chosen by the planner)
     int sell_planes_opt = 0;             // PRCG_SELL_PLANES: grid planes interleaved in the slice table (<= 1: row order, the default:
                                          // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
     int sell_nt = 0;                     // the value / code streams are read with nontemporal loads: chosen per operator in prcg_set_csr
     int sell_nt_opt = -1;                // PRCG_SELL_NT=0|1 overrides
+    int sell_gb = 0, sell_defer = 0;     // PRCG_SELL_GB=0|4|8, PRCG_SELL_DEFER=0|1: request orders inside the sliced-row kernels (prcg_sell.hip)
     int sell_sigma = 0, sell_planes = 0, sell_run = 1; // what the planner chose
     bool sell_runs_opt = true;           // PRCG_SELL_RUNS=0: a column code per nonzero even where the rows are runs of three
     int64_t sell_stride = 0;
@@ -283,7 +286,7 @@ struct prcg_handle {
                       win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
-    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt, sell_run}; }
+    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt, sell_run, sell_gb, sell_defer, sell_window > 0 ? static_cast<const int*>(sgran.p) : nullptr}; }
     const double* val_sell() const { return static_cast<const double*>(sval.p); }
     const void* sslice_ptr(int first = 0) const { return static_cast<const char*>(sslices.p) + (size_t)first * 32; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -1314,7 +1317,10 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
     else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 0;
     else if (k == "PRCG_SELL_RUNS") h->sell_runs_opt = v != 0;
+    else if (k == "PRCG_SELL_WINDOW") h->sell_window_opt = v != 0 ? 48 : 0;
     else if (k == "PRCG_PR_PACK") h->want_pr_pack = v != 0 ? 1 : 0;
+    else if (k == "PRCG_SELL_GB") h->sell_gb = (v == 4 || v == 8) ? (int)v : 0;
+    else if (k == "PRCG_SELL_DEFER") h->sell_defer = v != 0;
     else if (k == "PRCG_SELL_NT") { h->sell_nt_opt = v != 0; h->sell_nt = v != 0; }
     else if (k == "PRCG_STREAM_STORES") h->stream_override = v != 0;
     else if (k == "PRCG_EXT_SIGNAL") h->ext_signal = v != 0;
@@ -1329,7 +1335,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_RUNS", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_GB", "PRCG_SELL_DEFER", "PRCG_SELL_RUNS", "PRCG_SELL_WINDOW", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1661,6 +1667,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         so.sigma = h->sell_sigma_opt;
         so.planes = h->sell_planes_opt;
         so.allow_runs = h->sell_runs_opt;
+        so.window_granules = h->sell_window_opt;
         h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, so, sp);
     }
     const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels
@@ -1804,7 +1811,13 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         if (!sp.rows.empty()) HIPCHK(h, hipMemcpy(h->srows.p, sp.rows.data(), sp.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         // what a product reads of the operator: 8 B per (padded) value, 2 B per (padded) column code, the slice descriptors, and
         // the row pointers (slices of consecutive rows) or the slices' (row, stored length) pairs
-        h->sell_bytes = sp.padded_nnz * 8 + sp.col_entries * 2 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4;
+        HIPCHK(h, h->sgran.alloc((sp.gran.size() + 64) * sizeof(int32_t)));
+        if (!sp.gran.empty()) HIPCHK(h, hipMemcpy(h->sgran.p, sp.gran.data(), sp.gran.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->sell_window = sp.window;
+        // ... and with WINDOW codes the granule starts (the window pages themselves are vector traffic: every entry a slice touches,
+        // read once per slice instead of once per nonzero)
+        h->sell_bytes = sp.padded_nnz * 8 + sp.col_entries * 2 + (int64_t)sall.size() * 32 + 4 * (n_rows + 1) + (int64_t)sp.rows.size() * 4 +
+                        (int64_t)sp.gran.size() * 4;
         h->sell_sigma = sp.sigma; h->sell_planes = sp.planes; h->sell_stride = sp.stride_rows; h->sell_run = sp.run;
         sp = SellPlan{};
     }
@@ -2616,7 +2629,7 @@ int prcg_schedule(const prcg_t* h) {
            (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->medium ? PRCG_SCHED_MEDIUM : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            (h->stream_stores ? PRCG_SCHED_STREAM_STORES : 0) | ((h->sell && h->sell_sigma > 64) ? PRCG_SCHED_SELL_SORTED : 0) |
-           ((h->sell && h->sell_nt) ? PRCG_SCHED_NT_LOADS : 0) |
+           ((h->sell && h->sell_nt) ? PRCG_SCHED_NT_LOADS : 0) | ((h->sell && h->sell_window > 0) ? PRCG_SCHED_SELL_WINDOW : 0) |
            ((h->win ? h->win_vd : h->vd_int) ? PRCG_SCHED_VALDICT : 0) |
            (h->win ? (h->win_pat ? PRCG_SCHED_PATTERN : (h->win_geom < 2 ? PRCG_SCHED_COL8 : PRCG_SCHED_COL16)) | PRCG_SCHED_WINDOW
                    : (h->c8_int ? PRCG_SCHED_COL8 : (h->c16_int ? PRCG_SCHED_COL16 : 0)));
@@ -2900,27 +2913,30 @@ int prcg_plan_window_images(int64_t n, int64_t n_cols, const int32_t* indptr, co
 }
 
 int64_t prcg_plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
-                       double max_overhead, int sigma, int planes, int allow_runs, int32_t* slices_out, int64_t capacity, double* val_out, uint16_t* col_out,
-                       int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity, int64_t* stats) {
+                       double max_overhead, int sigma, int planes, int allow_runs, int window_granules, int32_t* slices_out, int64_t capacity,
+                       double* val_out, uint16_t* col_out, int64_t array_capacity, int32_t* rows_out, int64_t rows_capacity,
+                       int32_t* gran_out, int64_t gran_capacity, int64_t* stats) {
     if (n < 0 || !indptr || (indptr[n] > 0 && (!indices || !data)) || (!slices_out && capacity > 0)) return -1;
     SellPlan sp;
     SellOptions so;
     so.max_overhead = max_overhead; so.sigma = sigma; so.planes = planes; so.allow_runs = allow_runs != 0;
+    so.window_granules = window_granules;
     if (!plan_sell(n, indptr, indices, data, row_class, so, sp)) return 0;
     const int64_t total = (int64_t)sp.s0.size() + (int64_t)sp.s1.size();
     if (stats) {
         stats[0] = (int64_t)sp.s0.size(); stats[1] = (int64_t)sp.val.size(); stats[2] = (int64_t)sp.col.size(); stats[3] = sp.padded_nnz;
         stats[4] = sp.sigma; stats[5] = sp.stride_rows; stats[6] = sp.planes; stats[7] = (int64_t)sp.rows.size();
-        stats[8] = sp.col_entries; stats[9] = sp.run;
+        stats[8] = sp.col_entries; stats[9] = sp.run; stats[10] = sp.window; stats[11] = (int64_t)sp.gran.size();
     }
     if (total > capacity || (val_out && (int64_t)sp.val.size() > array_capacity) || (col_out && (int64_t)sp.col.size() > array_capacity) ||
-        (rows_out && (int64_t)sp.rows.size() > rows_capacity)) return -total;
+        (rows_out && (int64_t)sp.rows.size() > rows_capacity) || (gran_out && (int64_t)sp.gran.size() > gran_capacity)) return -total;
     int64_t o = 0;
     for (const auto* v : {&sp.s0, &sp.s1})
         for (const auto& t : *v) { memcpy(slices_out + 8 * o, &t, 8 * sizeof(int32_t)); ++o; }
     if (val_out) memcpy(val_out, sp.val.data(), sp.val.size() * sizeof(double));
     if (col_out) memcpy(col_out, sp.col.data(), sp.col.size() * sizeof(uint16_t));
     if (rows_out && !sp.rows.empty()) memcpy(rows_out, sp.rows.data(), sp.rows.size() * sizeof(int32_t));
+    if (gran_out && !sp.gran.empty()) memcpy(gran_out, sp.gran.data(), sp.gran.size() * sizeof(int32_t));
     return total;
 }
 

@@ -330,6 +330,8 @@ struct SellDev {
     const int* rows;          // slices with rows_off >= 0 (a sorting window wider than a slice): (row, length) of lane l at pair rows_off + l (row -1: none)
     int nt;                   // 1: value / code streams read with nontemporal loads (operators far larger than the Infinity Cache)
     int run;                  // 1: a column code per nonzero; 3: a code per aligned run of three consecutive columns (prcg_plan.h)
+    int gb, defer;            // order of a trip's gathers / the next trip's loads, and of a slice's row stores (prcg_sell.hip)
+    const int* gran;          // non-null: WINDOW codes (prcg_plan.h) -- the first column of every granule, slice after slice
 };
 int launch_sell_spmv(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* x, double* y, SpmvEpilogue epi,
                      const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu);

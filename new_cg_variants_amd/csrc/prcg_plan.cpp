@@ -763,7 +763,8 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     if (sigma < 64) sigma = 64;
     out.sigma = sigma;
     // pass 1: slices, widths, offsets.  A row's columns are stored as 16-bit DELTAS (prcg_plan.h); a gap too wide for one
-    // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips
+    // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips.  With WINDOW codes (tried first
+    // when the rows stay consecutive) there are no skips; the attempt ends at the first slice with too many granules
     std::vector<SellSlice> all;
     std::vector<uint8_t> cls_of;
     std::vector<int32_t>& perm = out.rows;        // (row, stored length) pairs in lane order, 64 pairs per slice that has them
@@ -779,44 +780,73 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         }
         return sk * run;
     };
-    int64_t voff = 0, coff = 0, r = 0;
-    while (r < n) {
-        const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
-        int64_t e = r + 1;
-        if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
-        rrun.clear();
-        sell_run_order(indptr, r, e, sigma, 8 * run, rrun);
-        for (size_t i = 0; i < rrun.size(); i += 64) {
-            const size_t je = std::min(rrun.size(), i + 64);
-            int32_t rmin = INT32_MAX, cbase = INT32_MAX;
-            for (size_t j = i; j < je; ++j) {
-                rmin = std::min(rmin, rrun[j]);
-                if (indptr[rrun[j] + 1] > indptr[rrun[j]]) cbase = std::min(cbase, indices[indptr[rrun[j]]]);
+    int64_t voff = 0, coff = 0;
+    bool windowed = opt.window_granules > 0 && sigma == 64 && opt.window_granules * kSellGranule <= 65536;
+    std::vector<int32_t> cols;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        all.clear(); cls_of.clear(); perm.clear(); out.gran.clear(); out.window = 0;
+        voff = 0; coff = 0;
+        bool failed = false;
+        int64_t r = 0;
+        while (r < n && !failed) {
+            const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
+            int64_t e = r + 1;
+            if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
+            rrun.clear();
+            sell_run_order(indptr, r, e, sigma, 8 * run, rrun);
+            for (size_t i = 0; i < rrun.size() && !failed; i += 64) {
+                const size_t je = std::min(rrun.size(), i + 64);
+                int32_t rmin = INT32_MAX, cbase = INT32_MAX;
+                for (size_t j = i; j < je; ++j) {
+                    rmin = std::min(rmin, rrun[j]);
+                    if (indptr[rrun[j] + 1] > indptr[rrun[j]]) cbase = std::min(cbase, indices[indptr[rrun[j]]]);
+                }
+                if (cbase == INT32_MAX) cbase = 0;
+                int width = 0, flags = 0;
+                bool any_skip = false;
+                if (windowed) {
+                    // the slice's granules: the sorted distinct (run-first) columns, each covered together with its run
+                    cols.clear();
+                    for (size_t j = i; j < je; ++j) {
+                        for (int32_t q = indptr[rrun[j]]; q < indptr[rrun[j] + 1]; q += run) cols.push_back(indices[q]);
+                        width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]]);
+                    }
+                    std::sort(cols.begin(), cols.end());
+                    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                    const size_t g0 = out.gran.size();
+                    for (int32_t c : cols)
+                        if (out.gran.size() == g0 || c + run - 1 > out.gran.back() + kSellGranule - 1) out.gran.push_back(c);
+                    const int ng = (int)(out.gran.size() - g0);
+                    if (ng > opt.window_granules || out.gran.size() >= (size_t)INT32_MAX / 2) { failed = true; break; }
+                    out.window = std::max(out.window, ng);
+                    cbase = (int)g0;
+                    flags = 2 | (ng << 8);
+                } else {
+                    for (size_t j = i; j < je; ++j) {
+                        const int sk = skips_of(rrun[j], cbase);
+                        any_skip |= sk > 0;
+                        width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]] + sk);
+                    }
+                }
+                const int w2 = (width + 1) & ~1, w8 = ((width + run - 1) / run + 7) & ~7;      // value slots (even), codes (whole 16-byte chunks)
+                if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w8 * 64 >= (int64_t)INT32_MAX - 4096) return false;
+                int rows_off = -1;
+                if (sigma > 64 || any_skip) {
+                    rows_off = (int)(perm.size() / 2);
+                    for (size_t j = i; j < je; ++j) { perm.push_back(rrun[j]); perm.push_back(indptr[rrun[j] + 1] - indptr[rrun[j]] + skips_of(rrun[j], cbase)); }
+                    for (size_t j = je; j < i + 64; ++j) { perm.push_back(-1); perm.push_back(0); }
+                }
+                // (rows_off < 0: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
+                const int first = rows_off < 0 ? rrun[i] : rmin;
+                all.push_back(SellSlice{first, first + (int)(je - i), (int)voff, (int)coff, width, cbase, rows_off, flags});
+                cls_of.push_back(cls);
+                voff += (int64_t)w2 * 64;
+                coff += (int64_t)w8 * 64;
             }
-            if (cbase == INT32_MAX) cbase = 0;
-            int width = 0;
-            bool any_skip = false;
-            for (size_t j = i; j < je; ++j) {
-                const int sk = skips_of(rrun[j], cbase);
-                any_skip |= sk > 0;
-                width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]] + sk);
-            }
-            const int w2 = (width + 1) & ~1, w8 = ((width + run - 1) / run + 7) & ~7;      // value slots (even), codes (whole 16-byte chunks)
-            if (voff + (int64_t)w2 * 64 >= (int64_t)INT32_MAX - 4096 || coff + (int64_t)w8 * 64 >= (int64_t)INT32_MAX - 4096) return false;
-            int rows_off = -1;
-            if (sigma > 64 || any_skip) {
-                rows_off = (int)(perm.size() / 2);
-                for (size_t j = i; j < je; ++j) { perm.push_back(rrun[j]); perm.push_back(indptr[rrun[j] + 1] - indptr[rrun[j]] + skips_of(rrun[j], cbase)); }
-                for (size_t j = je; j < i + 64; ++j) { perm.push_back(-1); perm.push_back(0); }
-            }
-            // (rows_off < 0: rb .. re are the slice's rows; else re - rb is their count and rb the smallest of them)
-            const int first = rows_off < 0 ? rrun[i] : rmin;
-            all.push_back(SellSlice{first, first + (int)(je - i), (int)voff, (int)coff, width, cbase, rows_off, 0});
-            cls_of.push_back(cls);
-            voff += (int64_t)w2 * 64;
-            coff += (int64_t)w8 * 64;
+            r = e;
         }
-        r = e;
+        if (!failed) break;
+        windowed = false;                      // (second attempt: delta codes)
     }
     if (getenv("PRCG_PLAN_DEBUG"))
         fprintf(stderr, "plan_sell: sigma %d, %zu slices, padded / nnz = %.4f\n", sigma, all.size(), (double)voff / (double)std::max<int64_t>(nnz, 1));
@@ -825,7 +855,7 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     out.col_entries = coff;
     // pass 2: fill (padding: value 0, delta 0 -- the column stays where it is)
     out.val.assign((size_t)voff + 1024, 0.0);
-    out.col.assign((size_t)coff + 1024, (uint16_t)kSellDeltaBias);
+    out.col.assign((size_t)coff + 1024, windowed ? (uint16_t)0 : (uint16_t)kSellDeltaBias);
     unsigned nt = std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > 16) nt = 16;
@@ -840,6 +870,17 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
                 int64_t prev = sl.cbase;
                 int u = 0;                                  // stored position (a multiple of `run` at every run start)
                 auto put = [&](uint16_t code) { const int c = u / run; out.col[(size_t)sl.coff + ((size_t)(c >> 3) * 64 + l) * 8 + (c & 7)] = code; };
+                if (sl.flags & 2) {                         // WINDOW codes: 16 g + offset inside the last granule that starts at or before the column
+                    const int32_t* g0 = out.gran.data() + sl.cbase;
+                    const int ng = sl.flags >> 8;
+                    for (int q = 0; q < len; q += run) {
+                        const int g = (int)(std::upper_bound(g0, g0 + ng, indices[lo + q]) - g0) - 1;
+                        put((uint16_t)(g * kSellGranule + (indices[lo + q] - g0[g])));
+                        for (int e2 = 0; e2 < run; ++e2, ++u)
+                            out.val[(size_t)sl.voff + ((size_t)(u >> 1) * 64 + l) * 2 + (u & 1)] = data[lo + q + e2];
+                    }
+                    continue;
+                }
                 for (int q = 0; q < len; q += run) {
                     int64_t dlt = (int64_t)indices[lo + q] - prev;
                     while (dlt > kSellDeltaMax) { put(kSellCodeSkipFwd); u += run; prev += kSellSkipFwd; dlt -= kSellSkipFwd; }

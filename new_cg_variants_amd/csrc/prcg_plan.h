@@ -145,7 +145,17 @@ bool plan_sweep_tiles(int64_t n, int64_t n_cols, const int32_t* indptr, const in
 // ceil(length / (8 run)), what a wave pays for a row; stable, so rows of one trip count stay neighbours -- before it is cut
 // into slices, so that rows of similar length share a slice and the padding stays small for operators whose row lengths vary), and slices with a row that needs skips.  Every row is still summed left to right
 // by ONE lane: the products are scipy's bit for bit whatever the order.
+// WINDOW codes (SellPlan::window > 0; every slice holds consecutive rows): the kernel stages the input-vector entries a slice's
+// rows touch in LDS and the row walk reads them there -- per nonzero an LDS read instead of a gather from memory (the gathers'
+// instructions, not their misses, cost the Queen-size stand-in 95 of 600 us: r04_sweeps.md B).  The entries are described by
+// GRANULES of 16 consecutive columns (first column in `gran`; granules may overlap): granule g of the slice is staged at window
+// entries 16 g .. 16 g + 15, four granules per wave-wide load.  A code is then the WINDOW INDEX of the (run's first) column,
+// 16 g + (column - gran[g]); a run never straddles a granule; no deltas, no skips, padding code 0.  SellSlice::cbase = the
+// slice's first entry in `gran`, flags = 2 | granules << 8.  Chosen when EVERY slice needs at most
+// SellOptions::window_granules granules (an assembled 3-D matrix in natural ordering: 9 lines of neighbours per slice, 45
+// granules for 3 unknowns per node); otherwise delta codes as above.
 // Returns false (nothing built) if the operator does not qualify: padding would exceed `max_overhead` x nnz.
+constexpr int kSellGranule = 16;
 constexpr int kSellDeltaBias = 16384;
 constexpr int kSellDeltaMin = -16383, kSellDeltaMax = 49150;       // deltas one code can hold (codes 1 .. 65534)
 constexpr int kSellSkipFwd = 49151, kSellSkipBack = 16384;         // what the skip codes 65535 / 0 move the column by
@@ -159,6 +169,7 @@ struct SellOptions {
     double target = 1.04;
     int planes = 8;                  // class-0 slices of this many consecutive grid planes are interleaved in the table (<= 1: row order)
     bool allow_runs = true;          // operators whose rows are aligned runs of 3 consecutive columns store one code per run
+    int window_granules = 0;         // > 0: slices of consecutive rows (sigma 64) whose columns fit this many 16-entry granules get WINDOW codes
 };
 struct SellPlan {
     std::vector<SellSlice> s0, s1;       // interior slices (in PROCESSING order), slices touching ghost columns
@@ -171,6 +182,8 @@ struct SellPlan {
     int64_t stride_rows = 0;             // the operator's dominant far column offset (a grid plane), 0: none found
     int planes = 0;                      // > 0: the class-0 table interleaves groups of this many planes
     int run = 1;                         // 3: one column code per aligned run of three consecutive columns (see below), else one per nonzero
+    int window = 0;                      // > 0: WINDOW codes (below); the most granules a slice has
+    std::vector<int32_t> gran;           // first column of every granule, slice after slice (slice: gran[cbase .. cbase + (flags >> 8)))
 };
 bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const double* data, const uint8_t* row_class,
                const SellOptions& opt, SellPlan& out);

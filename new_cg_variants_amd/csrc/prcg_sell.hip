@@ -18,6 +18,10 @@
 //     pipelined update), so every schedule that runs on CSR-adaptive tiles runs on slices.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <type_traits>
+
 #include "prcg_device.hpp"
 #include "prcg_kernels.h"
 
@@ -26,7 +30,7 @@ namespace {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-struct SDesc { int rb, re, voff, coff, width, cbase, rows_off; };
+struct SDesc { int rb, re, voff, coff, width, cbase, rows_off, flags; };
 
 __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) {
     const int4 a = st[2 * t], b = st[2 * t + 1];
@@ -34,7 +38,7 @@ __device__ __forceinline__ SDesc read_sdesc(const int4* __restrict__ st, int t) 
     d.rb = __builtin_amdgcn_readfirstlane(a.x); d.re = __builtin_amdgcn_readfirstlane(a.y);
     d.voff = __builtin_amdgcn_readfirstlane(a.z); d.coff = __builtin_amdgcn_readfirstlane(a.w);
     d.width = __builtin_amdgcn_readfirstlane(b.x); d.cbase = __builtin_amdgcn_readfirstlane(b.y);
-    d.rows_off = __builtin_amdgcn_readfirstlane(b.z);
+    d.rows_off = __builtin_amdgcn_readfirstlane(b.z); d.flags = __builtin_amdgcn_readfirstlane(b.w);
     return d;
 }
 
@@ -73,7 +77,15 @@ __device__ __forceinline__ int2 slice_row(const SellDev& A, const SDesc& d, int 
     return reinterpret_cast<const int2*>(A.rows)[d.rows_off + lane];
 }
 
-template <int NV, int EPI, bool NT, int RUN>
+// The wave's memory counter retires in issue order as far as a wait can tell: a wait for ANY load is a wait for everything
+// issued before it.  Two orders follow from that (GB, DEFER; both measured, r04_sweeps.md B):
+//   GB     0: the next trip's stream loads first, then this trip's gathers two codes at a time -- the first gather wait is a
+//             wait for the whole next trip, and nothing of the stream is in flight for the wave while the trip is summed;
+//             4 / 8: the gathers of the trip's first 4 / 8 codes, THEN the next trip's loads (they stay in flight);
+//   DEFER  the fused iteration's row results of slice k are stored right in front of the first gathers of slice k + 1 (their
+//             acknowledgement is covered by the gathers' round trip) instead of at the end of slice k, where the next
+//             slice's first address computation -- a wait for everything -- found them as the youngest requests
+template <int NV, int EPI, bool NT, int RUN, int GB, bool DEFER>
 __global__ __launch_bounds__(kBlock) void k_sell_tiles(
     SellDev A, const int4* __restrict__ slices, int nslices,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -109,7 +121,25 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
 
     Trip<RUN> cur, nxt;
     constexpr int TP = 8 * RUN;           // stored positions per trip
-    SDesc d = {0, 0, 0, 0, 0, 0, -1}, dn = {0, 0, 0, 0, 0, 0, -1};
+#if defined(PRCG_SELL_DIAG_LDSGATHER)
+    __shared__ V diag_win[kWaves * 768];
+    for (int i = threadIdx.x; i < kWaves * 768; i += kBlock) vzero(diag_win[i]);
+    __syncthreads();
+#endif
+    // DEFER: the previous slice's row, sums and operands until they are stored
+    int prow = -1;
+    V psum; vzero(psum);
+    FusedRowIn pq = {};
+    V pown; vzero(pown);
+    auto flush_row = [&]() {
+        if constexpr (DEFER && epi_fused(EPI)) {
+#if !defined(PRCG_SELL_DIAG_NOEPI)
+            if (prow >= 0) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(prow, psum, pq, pown, fr, cf, acc);
+#endif
+            prow = -1;
+        }
+    };
+    SDesc d = {0, 0, 0, 0, 0, 0, -1, 0}, dn = {0, 0, 0, 0, 0, 0, -1, 0};
     int2 rl = make_int2(-1, 0);            // row and length of the lane's row in the CURRENT slice (requested a slice ahead)
     if (t < nslices) {
         d = read_sdesc(slices, t);
@@ -128,18 +158,32 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
         FusedRowIn q;
         V own; vzero(own);
         if constexpr (epi_fused(EPI)) {
+#if defined(PRCG_SELL_DIAG_NOOWN)               // TIMING ONLY (wrong results): the row's own operands are not loaded
+            q.xp = make_double2(1.0, (double)rr); own = V{};
+            if constexpr (false) {
+#else
             q.xp = fr.XP[rr];
             own = X[rr];
+            {
+#endif
             if constexpr (epi_prec(EPI)) { q.rs = fr.RS[rr]; q.d = fr.D[rr]; }
             if constexpr (!epi_recompute(EPI)) { q.w = fr.W[rr]; if constexpr (epi_prec(EPI)) q.wt = fr.WT[rr]; }
+            }
         }
         V sum; vzero(sum);
         int colacc = d.cbase;
         for (int u0 = 0; u0 < d.width; u0 += TP) {                           // wave-uniform trip count
             // the next trip -- of this slice, or the first of the wave's next slice -- is requested before this one is used
+            // (no branch around the loads: at a join the compiler's wait counts assume the path WITHOUT them, and the first
+            //  gather wait would then cover part of the stream -- the wave's very last trip reads itself once more instead)
             const bool more = u0 + TP < d.width;
-            if (more) load_trip<NT, RUN>(A, d, u0 + TP, lane, nxt);
-            else if (t + W < nslices) load_trip<NT, RUN>(A, dn, 0, lane, nxt);
+            const bool other = !more && t + W < nslices;
+            auto request_next = [&]() {
+                SDesc s = d;
+                s.voff = other ? dn.voff : d.voff; s.coff = other ? dn.coff : d.coff; s.width = other ? dn.width : d.width;
+                load_trip<NT, RUN>(A, s, more ? u0 + TP : other ? 0 : u0, lane, nxt);
+            };
+            if constexpr (GB == 0) request_next();
             // the lane's running column: every code moves it by code - 16384 (to the first column of its run); codes 0 and
             // 65535 only move it (skips)
             int code[8], col[8];
@@ -147,14 +191,17 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
             code[4] = cur.c.z & 0xffffu; code[5] = cur.c.z >> 16; code[6] = cur.c.w & 0xffffu; code[7] = cur.c.w >> 16;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { colacc += code[k] - 16384; col[k] = colacc; }
-            // (two codes at a time: 2 RUN gathers in flight per lane beside the next trip's stream loads)
+            if (u0 == 0) flush_row();                                       // wave-uniform
+            constexpr int CB = GB == 0 ? 2 : GB;                            // codes per batch of gathers
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2 += 2) {
-                V g[2 * RUN];
+            for (int k2 = 0; k2 < 8; k2 += CB) {
+                V g[CB * RUN];
 #pragma unroll
-                for (int k = 0; k < 2 * RUN; ++k) {
+                for (int k = 0; k < CB * RUN; ++k) {
                     const int c0 = col[k2 + k / RUN] + k % RUN;
-#if defined(PRCG_SELL_DIAG_NOGATHER) && PRCG_SELL_DIAG_NOGATHER == 2   // TIMING ONLY (wrong products): no gather instruction at all
+#if defined(PRCG_SELL_DIAG_LDSGATHER)       // TIMING ONLY (wrong products): the gathers read an (unfilled) LDS window of the wave instead of memory
+                    g[k] = diag_win[wv * 768 + ((c0 - d.cbase + 384) & 0x3ff) % 768];
+#elif defined(PRCG_SELL_DIAG_NOGATHER) && PRCG_SELL_DIAG_NOGATHER == 2   // TIMING ONLY (wrong products): no gather instruction at all
                     g[k] = own; if constexpr (NV == 2) g[k].x += (double)c0; else g[k] += (double)c0;
 #elif defined(PRCG_SELL_DIAG_NOGATHER)      // TIMING ONLY (wrong products): every gather hits the same 64 entries -- what the kernel costs without gather misses
                     g[k] = X[d.cbase + (c0 & 63)];
@@ -163,8 +210,15 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
                                                                             //  two of the row's columns: valid entries, never used)
 #endif
                 }
+                if constexpr (GB != 0) {
+                    if (k2 == 0) {                                          // (the scheduler must not move the stream loads in front of the gathers)
+                        __builtin_amdgcn_sched_barrier(0);
+                        request_next();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
-                for (int k = 0; k < 2 * RUN; ++k) {
+                for (int k = 0; k < CB * RUN; ++k) {
                     const int pos = k2 * RUN + k;                           // position inside the trip
                     const double a = (pos & 1) ? cur.v[pos >> 1].y : cur.v[pos >> 1].x;
                     if (u0 + pos < len && (unsigned)(code[k2 + k / RUN] - 1) < 65534u) vacc(sum, vmul(a, g[k]));   // left to right, product rounded, then added
@@ -174,13 +228,175 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
         }
         if (d.width == 0 && t + W < nslices) load_trip<NT, RUN>(A, dn, 0, lane, cur);
         if constexpr (epi_fused(EPI)) {
-            if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
+#if defined(PRCG_SELL_DIAG_NOEPI)               // TIMING ONLY (wrong results): nothing is stored per row
+            if constexpr (NV == 2) { if (active) acc[0] += sum.x + sum.y + q.xp.x + q.xp.y + own.x + own.y; }
+#else
+            if constexpr (DEFER) {
+                if (d.width == 0) flush_row();                              // (a slice without trips had no place for it)
+                prow = active ? row : -1; psum = sum; pq = q; pown = own;
+            } else {
+                if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
+            }
+#endif
         } else {
             if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
         }
         t += W;
         d = dn;
         if (t + W < nslices) dn = read_sdesc(slices, t + W);
+    }
+
+    flush_row();
+    if constexpr (epi_fused(EPI)) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+    else if constexpr (EPI == kEpiCG) block_reduce_store<5>(acc, partials, 0);
+    else if constexpr (EPI != kEpiNone) {
+        double a3[3] = {acc[0], acc[1], acc[2]};
+        block_reduce_store<3>(a3, partials, 0);
+    }
+}
+
+// ---- WINDOW codes (prcg_plan.h): the input-vector entries a slice touches are staged in LDS, the row walk reads them there ----
+// Per nonzero an LDS read (its own counter, its own pipe) instead of a gather from memory: the gathers' INSTRUCTIONS, not their
+// misses, cost the Queen-size stand-in 95 of 600 us (r04_sweeps.md B: every gather redirected to one line, same time; no gather
+// instruction, or the gathers read from an unfilled LDS window, 509-513 against 658).  Every slice holds consecutive rows and
+// names its window by granules of 16 consecutive entries; the wave's window is its own (no barrier: LDS traffic of ONE wave is
+// processed in issue order).  Software pipeline per wave, all requests a whole slice ahead of their use:
+//   slice t   : window pages (kSellWindowPages wave-wide loads, four granules each) sit in registers -> LDS;
+//               the pages of slice t + W are requested with the granule starts `gbn` (lane g holds granule g's first column);
+//               the granule starts of slice t + 2 W are requested;  then the trips, as k_sell_tiles walks them.
+// Always all kSellWindowPages pages (granule index clamped: the last granule again): no branch around a load (the compiler's
+// wait counts at a join assume the path without it).
+constexpr int kSellWindowMax = 48;                       // granules per slice the kernels hold (SellOptions::window_granules)
+constexpr int kSellWindowPages = kSellWindowMax / 4;
+constexpr int kSellWindowEntries = kSellWindowMax * 16;
+
+// (pages and window entries as native vectors: arrays of the HIP double2 class that live across the slice loop stay in scratch memory)
+template <int NV> struct PageT;
+template <> struct PageT<1> { using type = double; };
+template <> struct PageT<2> { using type = d2_t; };
+__device__ __forceinline__ double from_page(double w) { return w; }
+__device__ __forceinline__ double2 from_page(d2_t w) { return make_double2(w.x, w.y); }
+
+template <typename V>
+__device__ __forceinline__ void request_pages(const V* __restrict__ X, int ng, int gb, int lane, V (&pg)[kSellWindowPages]) {
+#pragma unroll
+    for (int j = 0; j < kSellWindowPages; ++j) {
+        int g = 4 * j + (lane >> 4);
+        g = g < ng ? g : ng - 1;
+        const int base = __builtin_amdgcn_ds_bpermute(g << 2, gb);
+        pg[j] = X[base + (lane & 15)];
+    }
+}
+
+template <int NV, int EPI, bool NT, int RUN>
+__global__ __launch_bounds__(kBlock) void k_sell_win(
+    SellDev A, const int4* __restrict__ slices, int nslices,
+    const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
+    const double* __restrict__ ep_r, const double* __restrict__ ep_d, double* __restrict__ ep_st,
+    double* __restrict__ partials, double* __restrict__ aux, FusedPrev fz)
+{
+    using V = typename VecT<NV>::type;
+    const V* __restrict__ X = reinterpret_cast<const V*>(xin_);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    using PV = typename PageT<NV>::type;
+    const PV* __restrict__ XPG = reinterpret_cast<const PV*>(xin_);
+    __shared__ PV win_all[kWaves * kSellWindowEntries];
+    PV* const win = win_all + wv * kSellWindowEntries;
+
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    Coefs cf = {0.0, 0.0, 0.0};
+    const FusedRowPtrs fr{reinterpret_cast<double2*>(yout_), reinterpret_cast<double2*>(ep_st), reinterpret_cast<double2*>(fz.rs),
+                          ep_d, fz.w, fz.wt, (write_mask & 8) != 0};
+    if constexpr (epi_fused(EPI)) {
+        if (fz.nprev > 0) {
+            double dsum[5];
+            sum_prev_partials<5, kWaves>(fz.prev_partials, fz.nprev, 0, dsum);
+            if (blockIdx.x == 0 && threadIdx.x < 5) fz.dots_prev_out[threadIdx.x] = dsum[threadIdx.x];
+            cf = predict(dsum, (write_mask >> 2) & 1);
+        } else {
+            cf = predict(ep_r, (write_mask >> 2) & 1);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { aux[0] = cf.al; aux[1] = cf.bt; aux[2] = cf.nup; }
+    }
+
+    const int nblk = gridDim.x;
+    const int W = nblk * kWaves;
+    int t = xcd_remap(blockIdx.x, nblk) * kWaves + wv;
+    if (t >= nslices) {                                   // (every wave joins the block's reduction)
+        if constexpr (epi_fused(EPI)) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
+        else if constexpr (EPI == kEpiCG) block_reduce_store<5>(acc, partials, 0);
+        else if constexpr (EPI != kEpiNone) { double a3[3] = {acc[0], acc[1], acc[2]}; block_reduce_store<3>(a3, partials, 0); }
+        return;
+    }
+
+    constexpr int TP = 8 * RUN;
+    Trip<RUN> cur, nxt;
+    PV pg[kSellWindowPages];
+    // granule starts of a slice, lane g <- granule g (clamped); a page load: lane l reads entry l % 16 of granule 4 j + l / 16
+    auto granule_starts = [&](const SDesc& s) { const int ng = s.flags >> 8; return A.gran[s.cbase + (lane < ng ? lane : ng > 0 ? ng - 1 : 0)]; };   // (a slice of empty rows has none)
+    SDesc d = read_sdesc(slices, t);
+    SDesc dn = t + W < nslices ? read_sdesc(slices, t + W) : d;
+    request_pages<PV>(XPG, d.flags >> 8, granule_starts(d), lane, pg);
+    int gbn = granule_starts(dn);
+    load_trip<NT, RUN>(A, d, 0, lane, cur);
+    int2 rl = slice_row(A, d, lane);
+    while (t < nslices) {
+        const int row = rl.x;
+        const bool active = row >= 0;
+        const int rr = active ? row : d.rb;
+        const int len = rl.y;
+        // this slice's window; then everything the next slices need
+#pragma unroll
+        for (int j = 0; j < kSellWindowPages; ++j) win[64 * j + lane] = pg[j];
+        wave_lds_sync();
+        request_pages<PV>(XPG, dn.flags >> 8, gbn, lane, pg);
+        const SDesc dnn = t + 2 * W < nslices ? read_sdesc(slices, t + 2 * W) : dn;
+        gbn = granule_starts(dnn);
+        rl = slice_row(A, dn, lane);
+        FusedRowIn q;
+        V own; vzero(own);
+        if constexpr (epi_fused(EPI)) {
+            q.xp = fr.XP[rr];
+            own = X[rr];
+            if constexpr (epi_prec(EPI)) { q.rs = fr.RS[rr]; q.d = fr.D[rr]; }
+            if constexpr (!epi_recompute(EPI)) { q.w = fr.W[rr]; if constexpr (epi_prec(EPI)) q.wt = fr.WT[rr]; }
+        }
+        V sum; vzero(sum);
+        for (int u0 = 0; u0 < d.width; u0 += TP) {                           // wave-uniform trip count
+            const bool more = u0 + TP < d.width;
+            {
+                SDesc s = d;
+                s.voff = more ? d.voff : dn.voff; s.coff = more ? d.coff : dn.coff; s.width = more ? d.width : dn.width;
+                load_trip<NT, RUN>(A, s, more ? u0 + TP : 0, lane, nxt);      // (the wave's last slice: its own first trip once more)
+            }
+            int code[8];
+            code[0] = cur.c.x & 0xffffu; code[1] = cur.c.x >> 16; code[2] = cur.c.y & 0xffffu; code[3] = cur.c.y >> 16;
+            code[4] = cur.c.z & 0xffffu; code[5] = cur.c.z >> 16; code[6] = cur.c.w & 0xffffu; code[7] = cur.c.w >> 16;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2 += 2) {
+                V g[2 * RUN];
+#pragma unroll
+                for (int k = 0; k < 2 * RUN; ++k) g[k] = from_page(win[code[k2 + k / RUN] + k % RUN]);
+#pragma unroll
+                for (int k = 0; k < 2 * RUN; ++k) {
+                    const int pos = k2 * RUN + k;
+                    const double a = (pos & 1) ? cur.v[pos >> 1].y : cur.v[pos >> 1].x;
+                    if (u0 + pos < len) vacc(sum, vmul(a, g[k]));               // left to right, product rounded, then added
+                }
+            }
+            cur = nxt;
+        }
+        if (d.width == 0) load_trip<NT, RUN>(A, dn, 0, lane, cur);
+        wave_lds_sync();                                                     // (the window is rewritten at the head of the next slice)
+        if constexpr (epi_fused(EPI)) {
+            if (active) fused_row_update<epi_prec(EPI), epi_recompute(EPI)>(row, sum, q, own, fr, cf, acc);
+        } else {
+            if (active) finish_row<NV, EPI>(row, sum, yout_, write_mask, X, ep_r, ep_d, ep_st, acc, cf, fr);
+        }
+        t += W;
+        d = dn;
+        dn = dnn;
     }
 
     if constexpr (epi_fused(EPI)) { if constexpr (!epi_prec(EPI)) acc[4] = acc[3]; block_reduce_store<5>(acc, partials, 0); }
@@ -195,7 +411,15 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
 // occupancy API's register bound is the bound), at most `per_cu` per CU
 template <typename K>
 int sell_grid(K kernel, int nslices, int per_cu) {
-    static int cached = 0;
+    // (per kernel: every instantiation has the same signature, hence the same K)
+    static std::map<const void*, int> cache;
+    static std::mutex mu;
+    int cached = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(reinterpret_cast<const void*>(kernel));
+        if (it != cache.end()) cached = it->second;
+    }
     if (cached == 0) {
         int dev = 0, cus = 256, occ = 4;
         if (hipGetDevice(&dev) == hipSuccess) {
@@ -204,6 +428,8 @@ int sell_grid(K kernel, int nslices, int per_cu) {
         }
         if (occ > 2) occ = 2;      // (s4b: 2 workgroups per CU 3955 it/s, 3: 3840, 4: 3813 -- more requests in flight cost bandwidth)
         cached = occ * 1024 + cus;
+        std::lock_guard<std::mutex> lk(mu);
+        cache[reinterpret_cast<const void*>(kernel)] = cached;
     }
     int occ = cached / 1024;
     const int cus = cached % 1024;
@@ -224,9 +450,36 @@ template <int NV, int EPI>
 int launch_sell(hipStream_t st, const SellDev& A, const void* slices, int nslices, const void* x, void* y, int write_mask,
                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz, int per_cu)
 {
-    auto k = A.run == 3 ? (A.nt ? k_sell_tiles<NV, EPI, true, 3> : k_sell_tiles<NV, EPI, false, 3>)
-                        : (A.nt ? k_sell_tiles<NV, EPI, true, 1> : k_sell_tiles<NV, EPI, false, 1>);
-    const int grid = sell_grid(k_sell_tiles<NV, EPI, false, 1>, nslices, per_cu);
+    if (A.gran) {                                       // WINDOW codes
+        auto kw = A.run == 3 ? (A.nt ? k_sell_win<NV, EPI, true, 3> : k_sell_win<NV, EPI, false, 3>)
+                             : (A.nt ? k_sell_win<NV, EPI, true, 1> : k_sell_win<NV, EPI, false, 1>);
+        const int gridw = sell_grid(kw, nslices, per_cu);
+        hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r,
+                           ep_d, ep_st, partials, aux, fz);
+        return hipGetLastError() == hipSuccess ? gridw : -1;
+    }
+    auto pick = [&](auto gb, auto df) {
+        constexpr int G = decltype(gb)::value;
+        constexpr bool D = decltype(df)::value;
+        return A.run == 3 ? (A.nt ? k_sell_tiles<NV, EPI, true, 3, G, D> : k_sell_tiles<NV, EPI, false, 3, G, D>)
+                          : (A.nt ? k_sell_tiles<NV, EPI, true, 1, G, D> : k_sell_tiles<NV, EPI, false, 1, G, D>);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    auto k = pick(I0{}, std::false_type{});
+    if constexpr (EPI == kEpiPipeFused) {                // (the experiment's orders: the unpreconditioned pipelined iteration only)
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        const int sel = (A.gb == 8 ? 2 : A.gb == 4 ? 1 : 0) * 2 + (A.defer ? 1 : 0);
+        switch (sel) {
+        case 1: k = pick(I0{}, std::true_type{}); break;
+        case 2: k = pick(I4{}, std::false_type{}); break;
+        case 3: k = pick(I4{}, std::true_type{}); break;
+        case 4: k = pick(I8{}, std::false_type{}); break;
+        case 5: k = pick(I8{}, std::true_type{}); break;
+        default: break;
+        }
+    }
+    const int grid = sell_grid(k, nslices, per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r, ep_d,
                        ep_st, partials, aux, fz);
     return hipGetLastError() == hipSuccess ? grid : -1;

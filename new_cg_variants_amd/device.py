@@ -229,7 +229,7 @@ class DeviceCSR:
                 'dual_comm': bool(s & 16), 'value_dict': bool(s & 32),
                 'col_bytes': 0 if s & 65536 else (1 if s & 64 else (2 if s & 128 else 4)), 'tile_steps': (s >> 8) & 15,
                 'pattern': bool(s & 65536), 'window': bool(s & 4096), 'fused_comm': bool(s & 8192), 'peer': bool(s & 16384), 'sliced_rows': bool(s & 32768),
-                'stream_stores': bool(s & 131072), 'sorted_windows': bool(s & 262144), 'nt_loads': bool(s & 524288),
+                'stream_stores': bool(s & 131072), 'sorted_windows': bool(s & 262144), 'nt_loads': bool(s & 524288), 'window_codes': bool(s & 2097152),
                 'medium': bool(s & 1048576)}
 
     def layout(self):

@@ -372,22 +372,25 @@ def test_missing_x_true_is_refused_for_large_systems():
         cg_variants.pipe_pr_cg(A, np.ones(A.shape[0]), np.zeros(A.shape[0]), 5, callbacks=[error_A_norm])
 
 
-def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8, allow_runs=True):
+def plan_sell(A, row_class=None, max_overhead=1.25, sigma=0, planes=8, allow_runs=True, window=0):
     A = A.tocsr()
     n = A.shape[0]
     indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
     indices = np.ascontiguousarray(A.indices, dtype=np.int32)
     data = np.ascontiguousarray(A.data, dtype=np.float64)
     rc = None if row_class is None else np.ascontiguousarray(row_class, dtype=np.uint8)
-    stats = np.zeros(10, dtype=np.int64)
+    stats = np.zeros(12, dtype=np.int64)
     cap = n // 60 + 64 + (0 if rc is None else int(np.count_nonzero(np.diff(rc.astype(np.int8)))) + 2)
     slices = np.zeros((cap, 8), dtype=np.int32)
     arr_cap = int(max_overhead * A.nnz * 1.3) + 64 * 130 * 4 + 4096
     val = np.zeros(arr_cap)
     col = np.zeros(arr_cap, dtype=np.uint16)
     rows = np.zeros((cap * 64, 2), dtype=np.int32)
+    gran = np.zeros(cap * 64 + 64, dtype=np.int32)
     got = L.lib().prcg_plan_sell(n, L.ptr(indptr), L.ptr(indices), L.ptr(data), L.ptr(rc), float(max_overhead), int(sigma), int(planes), int(allow_runs),
-                                 L.ptr(slices), cap, L.ptr(val), L.ptr(col), arr_cap, L.ptr(rows), rows.size, L.ptr(stats))
+                                 int(window), L.ptr(slices), cap, L.ptr(val), L.ptr(col), arr_cap, L.ptr(rows), rows.size, L.ptr(gran), gran.size,
+                                 L.ptr(stats))
+    plan_sell.gran = gran[:int(stats[11])]               # (granule starts of the last call: WINDOW codes)
     return got, slices[:max(got, 0)], val, col, stats, rows
 
 
@@ -403,21 +406,34 @@ def slice_rows(sl, rows):
     return [(int(r), int(ln)) for r, ln in ent[:k]]
 
 
-@pytest.mark.parametrize('name', ['fem', 'fem_runs_off', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256', 'wide_gaps'])
+@pytest.mark.parametrize('name', ['fem', 'fem_runs_off', 'ragged', 'ghosts', 'irregular', 'irregular_sigma256', 'wide_gaps', 'fem_window', 'fem_window_runs_off',
+                                  'ghosts_window', 'fem_window_unsorted'])
 def test_sliced_row_layout_holds_exactly_the_matrix(name):
     """Host planner of the lane-per-row kernels (prcg_plan.cpp: plan_sell): every row in exactly one slice (classes apart,
     class 0 first), and reading the re-laid arrays back with the kernel's index formula gives the caller's CSR rows,
     values bit for bit and columns exactly, in order; padding is zero.  With a sorting window wider than a slice
     (SELL-C-sigma: operators whose row lengths vary) the slices name their rows and lengths, rows of one window only,
-    most trips first."""
+    most trips first.  WINDOW codes (the `_window` cases: slices of consecutive rows whose columns fit 48 granules of 16) name a
+    place in the slice's granule list instead of a delta; an operator with one slice that needs more granules keeps deltas."""
     import scipy.sparse as sp
     from new_cg_variants_amd import partition
     rng = np.random.default_rng(9)
     row_class = None
     sigma = 0
+    window = 48 if '_window' in name else 0
+    unsorted = name.endswith('_unsorted')
+    name = name.replace('_window', '').replace('_unsorted', '')
     if name in ('fem', 'fem_runs_off'):
         A = problems.fem_like_3d(9, 3)       # three unknowns per node, full 3 x 3 blocks: aligned runs of three columns -> one code per run
         sigma = 64
+        if unsorted:                         # the runs of some rows in another order (a row's columns need not ascend)
+            A = A.copy()
+            for r in range(0, A.shape[0], 7):
+                lo, hi = A.indptr[r], A.indptr[r + 1]
+                k = (hi - lo) // 3
+                o = (np.arange(k)[::-1][:, None] * 3 + np.arange(3)[None, :]).ravel()
+                A.indices[lo:hi] = A.indices[lo:hi][o]; A.data[lo:hi] = A.data[lo:hi][o]
+            A.has_sorted_indices = False
     elif name == 'ragged':
         n = 5000
         lens = rng.integers(40, 51, size=n)
@@ -446,8 +462,11 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
         full = problems.fem_like_3d(10, 3)
         A, ghost_ids = partition.localize(full[900:2100], 900, 2100)
         row_class = np.array([(A.indices[A.indptr[i]:A.indptr[i + 1]] >= 1200).any() for i in range(1200)])
-    got, slices, val, col, stats, rows = plan_sell(A, row_class, sigma=sigma, allow_runs=name != 'fem_runs_off')
+        sigma = 64 if window else 0          # (WINDOW codes need consecutive rows)
+    got, slices, val, col, stats, rows = plan_sell(A, row_class, sigma=sigma, allow_runs=name != 'fem_runs_off', window=window)
+    gran = plan_sell.gran
     assert got > 0, got
+    assert (stats[10] > 0) == (window > 0) and stats[10] <= 48
     n = A.shape[0]
     sig = int(stats[4])
     assert sig == (sigma or sig) and sig in (64, 256, 1024, 4096, 16384)
@@ -460,9 +479,14 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
     seen = np.zeros(n, dtype=int)
     used_v = np.zeros(int(stats[1]), dtype=bool)
     for si, sl in enumerate(slices):
-        rb, re, voff, coff, width, cbase, rows_off, _ = sl
+        rb, re, voff, coff, width, cbase, rows_off, flags = sl
         assert 0 < re - rb <= 64
+        assert (flags & 2 != 0) == (window > 0)
         lanes = slice_rows(sl, rows)
+        if window:
+            ng = flags >> 8
+            g0 = gran[cbase:cbase + ng]
+            assert 0 < ng <= 48 and rows_off < 0 and np.all(np.diff(g0) > 0)
         assert rows_off >= 0 or sig == 64
         rws = np.array([r for r, _ in lanes])
         seen[rws] += 1
@@ -484,8 +508,15 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
             cidx = np.arange(stored // run)
             ci = coff + ((cidx >> 3) * 64 + lane) * 8 + (cidx & 7)
             code = col[ci].astype(np.int64)
-            start = cbase + np.cumsum(code - 16384)
-            real_run = (code != 0) & (code != 65535)
+            if window:
+                # a code is a place in the slice's window: granule code // 16 (staged at window entries 16 g .. 16 g + 15), entry
+                # code % 16; the whole run lies inside the granule
+                assert np.all(code // 16 < ng) and np.all(code % 16 + run <= 16)
+                start = g0[code // 16] + code % 16
+                real_run = np.ones(code.size, dtype=bool)
+            else:
+                start = cbase + np.cumsum(code - 16384)
+                real_run = (code != 0) & (code != 65535)
             running = (np.repeat(start, run) + np.tile(np.arange(run), cidx.size))
             real = np.repeat(real_run, run)
             assert real.sum() == hi - lo and (ln is not None or real.all())
@@ -495,13 +526,14 @@ def test_sliced_row_layout_holds_exactly_the_matrix(name):
             # behind the row: code 16384 (the column stays), up to the slice's width
             ncodes = ((width + run - 1) // run + 7) // 8 * 8
             tail = np.arange(stored // run, ncodes)
-            assert np.all(col[coff + ((tail >> 3) * 64 + lane) * 8 + (tail & 7)] == 16384)
+            assert np.all(col[coff + ((tail >> 3) * 64 + lane) * 8 + (tail & 7)] == (0 if window else 16384))
         assert width == stored_max
     assert np.all(seen == 1)
     assert np.all(val[:int(stats[1])][~used_v] == 0.0)
     assert stats[3] <= 1.25 * max(A.nnz, 1)
     if name == 'wide_gaps':
         assert any(sl[6] >= 0 for sl in slices)          # some rows needed skips: their slices name rows and stored lengths
+        assert plan_sell(A, sigma=64, max_overhead=8.0, window=48)[4][10] == 0     # 72 scattered columns per row: far beyond 48 granules a slice -> deltas
     if stats[6] == 0:
         for part in (slices[:stats[0]], slices[stats[0]:]):
             assert np.all(np.diff(part[:, 0]) > 0) or sig > 64

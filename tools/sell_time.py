@@ -10,7 +10,11 @@ from new_cg_variants_amd import problems as P, _lib as L
 from new_cg_variants_amd.device import DeviceCSR
 
 args = sys.argv[1:]
-wl = P.WORKLOADS[args[0]]
+if args[0].startswith('fem:'):          # fem:<m> -- the s4b stand-in on m^3 nodes (sizes between the committed workloads)
+    _m = int(args[0][4:])
+    wl = {'make': lambda: P.fem_like_3d(_m), 'desc': f'FEM-like stand-in on {_m}^3 nodes'}
+else:
+    wl = P.WORKLOADS[args[0]]
 iters, warm, variant, prof, prewarm = 100, 30, 'PIPE_PR', 0, 0
 cfgs = []
 for a in args[1:]:
