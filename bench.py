@@ -269,7 +269,7 @@ def main():
             # + (r,s) read and written beside (r~,s~) and the diagonal with Jacobi; + w read and written in the 'p' flavours
             kb = fused_bytes(n, nnz) + (40 * n if vname == 'pipe_pr_pcg' else 0) + (16 * n if vname == 'pipe_p_cg' else 0)
             fam = ('k_win_tiles<2,fused>' + (', pattern tiles' if sched.get('pattern') else '')) if sched['window'] else (
-                'k_sell_tiles<2,fused>' if sched.get('sliced_rows') else 'k_spmv_tiles<2,fused>')
+                ('k_sell_win<2,fused>' if sched.get('window_codes') else 'k_sell_tiles<2,fused>') if sched.get('sliced_rows') else 'k_spmv_tiles<2,fused>')
             return kb, 'one-launch pipelined iteration: two-vector SpMM + next vector update + inner products (' + fam + ')'
         if vname.startswith('pipe_'):
             return spmm2_bytes(n, nnz), 'two-vector SpMM, interior launch (' + ('k_win_tiles<2>' if sched['window'] else 'k_spmv_tiles<2>') + ')'
@@ -299,7 +299,7 @@ def main():
                 'operator_bytes': opb, 'operator_bytes_per_nonzero': opb / max(nnz, 1),
                 'window_kernels': sched['window'], 'value_dictionary': sched['value_dict'], 'col_bytes': sched['col_bytes'],
                 'pattern_tiles': sched.get('pattern', False), 'sliced_rows': sched.get('sliced_rows', False),
-                'sorted_windows': sched.get('sorted_windows', False), 'nt_loads': sched.get('nt_loads', False), 'stream_stores': sched.get('stream_stores', False),
+                'sorted_windows': sched.get('sorted_windows', False), 'window_codes': sched.get('window_codes', False), 'nt_loads': sched.get('nt_loads', False), 'stream_stores': sched.get('stream_stores', False),
                 'one_launch': sched['fused'], 'residual_finite': finite}
 
     # ---- the rank's row block of the synthetic operator, right-hand side as the reference --

@@ -106,7 +106,7 @@ int64_t prcg_plan_sweep(int64_t n, const int32_t* indptr, const int32_t* indices
  * window_granules > 0: when the rows stay consecutive (sigma 64) and EVERY slice's columns fit that many granules of 16
  * consecutive columns, WINDOW codes are stored instead of deltas: slice descriptor {.., cbase = its first entry of gran_out,
  * rows_off = -1, flags = 2 | granules << 8}; a code is 16 g + (column - gran_out[cbase + g]) for the last granule g that starts
- * at or before the (run's first) column; no skips, padding code 0.  The kernels stage the granules in LDS (at most 48).
+ * at or before the (run's first) column; no skips, padding code 0.  The kernels stage the granules in LDS (at most 64).
  * stats[0..12) = {class-0 slices, elements of val, elements of col16, padded nonzeros, sigma chosen, far stride in rows
  * (0: none), planes interleaved (0: row order), elements of rows, column codes in use, positions per code (1 | 3), the most
  * granules of a slice (0: delta codes), elements of gran}.

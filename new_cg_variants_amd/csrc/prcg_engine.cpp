@@ -142,7 +142,8 @@ struct prcg_handle {
     int64_t sell_bytes = 0;              // bytes of the re-laid operator a product reads
     DevBuf sval, scol, sslices, srows, sgran;
     int sell_window = 0;                 // > 0: WINDOW codes -- the kernels stage a slice's input entries in LDS (prcg_plan.h); the most granules of a slice
-    int sell_window_opt = 48;            // PRCG_SELL_WINDOW=0 turns them off (delta codes, gathers from memory)
+    int sell_window_opt = 64;            // PRCG_SELL_WINDOW=0 turns them off (delta codes, gathers from memory); 1..64: granules a slice may use
+    double sell_overhead_opt = 0.0;      // PRCG_SELL_MAX_OVERHEAD_PCT: most padded nonzeros per nonzero, in percent (experiments)
     int sell_sigma_opt = 0;              // PRCG_SELL_SIGMA: sorting window of the sliced layout in rows (0: chosen by the planner)
     int sell_planes_opt = 0;             // PRCG_SELL_PLANES: grid planes interleaved in the slice table (<= 1: row order, the default:
                                          // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
@@ -286,7 +287,7 @@ struct prcg_handle {
                       win_period};
     }
     const WTile* wtile_ptr(int first = 0) const { return static_cast<const WTile*>(wtiles.p) + first; }
-    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt, sell_run, sell_gb, sell_defer, sell_window > 0 ? static_cast<const int*>(sgran.p) : nullptr}; }
+    SellDev sdev() const { return SellDev{indptr.i(), val_sell(), static_cast<const unsigned short*>(scol.p), static_cast<const int*>(srows.p), sell_nt, sell_run, sell_gb, sell_defer, sell_window > 0 ? static_cast<const int*>(sgran.p) : nullptr, sell_window}; }
     const double* val_sell() const { return static_cast<const double*>(sval.p); }
     const void* sslice_ptr(int first = 0) const { return static_cast<const char*>(sslices.p) + (size_t)first * 32; }
     // any communicator -- even a 1-rank one -- selects the two-stream schedule
@@ -1317,7 +1318,8 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL_SIGMA") h->sell_sigma_opt = (v >= 64 && v <= (1 << 20)) ? (int)v : 0;
     else if (k == "PRCG_SELL_PLANES") h->sell_planes_opt = (v >= 0 && v <= 64) ? (int)v : 0;
     else if (k == "PRCG_SELL_RUNS") h->sell_runs_opt = v != 0;
-    else if (k == "PRCG_SELL_WINDOW") h->sell_window_opt = v != 0 ? 48 : 0;
+    else if (k == "PRCG_SELL_WINDOW") h->sell_window_opt = v == 1 ? 64 : (v >= 0 && v <= 64) ? (int)v : 64;
+    else if (k == "PRCG_SELL_MAX_OVERHEAD_PCT") h->sell_overhead_opt = (v >= 100 && v <= 800) ? (double)v / 100.0 : 0.0;
     else if (k == "PRCG_PR_PACK") h->want_pr_pack = v != 0 ? 1 : 0;
     else if (k == "PRCG_SELL_GB") h->sell_gb = (v == 4 || v == 8) ? (int)v : 0;
     else if (k == "PRCG_SELL_DEFER") h->sell_defer = v != 0;
@@ -1335,7 +1337,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_GB", "PRCG_SELL_DEFER", "PRCG_SELL_RUNS", "PRCG_SELL_WINDOW", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_GB", "PRCG_SELL_DEFER", "PRCG_SELL_RUNS", "PRCG_SELL_WINDOW", "PRCG_SELL_MAX_OVERHEAD_PCT", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -1668,6 +1670,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
         so.planes = h->sell_planes_opt;
         so.allow_runs = h->sell_runs_opt;
         so.window_granules = h->sell_window_opt;
+        if (h->sell_overhead_opt > 0.0) so.max_overhead = h->sell_overhead_opt;
         h->sell = plan_sell(n_rows, ip.data(), indices, data, n_ghost > 0 ? cls.data() : nullptr, so, sp);
     }
     const bool classic_enc = !h->win && !h->sell;      // column / value re-encodings of the CSR-adaptive kernels

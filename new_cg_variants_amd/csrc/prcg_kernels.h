@@ -332,6 +332,7 @@ struct SellDev {
     int run;                  // 1: a column code per nonzero; 3: a code per aligned run of three consecutive columns (prcg_plan.h)
     int gb, defer;            // order of a trip's gathers / the next trip's loads, and of a slice's row stores (prcg_sell.hip)
     const int* gran;          // non-null: WINDOW codes (prcg_plan.h) -- the first column of every granule, slice after slice
+    int window;               // ... and the most granules a slice has (<= 64)
 };
 int launch_sell_spmv(hipStream_t st, const SellDev& A, const void* slices, int nslices, const double* x, double* y, SpmvEpilogue epi,
                      const double* ep_r, const double* ep_d, double* ep_st, double* partials, int per_cu);

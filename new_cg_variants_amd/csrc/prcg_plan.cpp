@@ -746,6 +746,7 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
     // while that pads by at most opt.target64; else the smallest of 256, 1024, 4096 whose padding is within opt.target of
     // the nonzeros, else the one that pads least
     int sigma = opt.sigma;
+    bool prefer_window = false;              // consecutive rows with WINDOW codes although a sorting window would pad less
     if (sigma <= 0) {
         int64_t best_pad = -1;
         int64_t pads[5];
@@ -756,12 +757,20 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
             if (i == 0 && (double)pads[0] <= opt.target64 * (double)std::max<int64_t>(nnz, 1)) break;
         }
         sigma = 64;
-        if ((double)pads[0] > opt.target64 * (double)std::max<int64_t>(nnz, 1))
+        if ((double)pads[0] > opt.target64 * (double)std::max<int64_t>(nnz, 1)) {
+            int chosen = 0;
             for (int i = 1; i < 5; ++i)
-                if ((double)pads[i] <= opt.target * (double)std::max<int64_t>(nnz, 1) || (double)pads[i] <= 1.01 * (double)best_pad) { sigma = cands[i]; break; }
+                if ((double)pads[i] <= opt.target * (double)std::max<int64_t>(nnz, 1) || (double)pads[i] <= 1.01 * (double)best_pad) { sigma = cands[i]; chosen = i; break; }
+            // sorted slices hold rows from anywhere in their window: their operands are gathered from memory, and those gathers
+            // cost more than the padding of consecutive rows does while that stays below ~1.4 x (s4c at Queen size: 30 % more
+            // bytes, 9 % less time: r04_sweeps.md B) -- consecutive rows are tried first up to opt.window_prefer x the sorted bytes
+            if (opt.window_granules > 0 && chosen > 0 && (double)pads[0] <= opt.window_prefer * (double)pads[chosen] &&
+                (double)pads[0] <= opt.window_max_overhead * (double)std::max<int64_t>(nnz, 1))
+                prefer_window = true;
+        }
     }
     if (sigma < 64) sigma = 64;
-    out.sigma = sigma;
+    const int sigma_sorted = sigma;
     // pass 1: slices, widths, offsets.  A row's columns are stored as 16-bit DELTAS (prcg_plan.h); a gap too wide for one
     // costs the row skip entries, i.e. stored positions: stored length = nonzeros + skips.  With WINDOW codes (tried first
     // when the rows stay consecutive) there are no skips; the attempt ends at the first slice with too many granules
@@ -781,12 +790,14 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
         return sk * run;
     };
     int64_t voff = 0, coff = 0;
-    bool windowed = opt.window_granules > 0 && sigma == 64 && opt.window_granules * kSellGranule <= 65536;
+    bool windowed = opt.window_granules > 0 && (sigma == 64 || prefer_window) && opt.window_granules * kSellGranule <= 65536;
     std::vector<int32_t> cols;
     for (int attempt = 0; attempt < 2; ++attempt) {
         all.clear(); cls_of.clear(); perm.clear(); out.gran.clear(); out.window = 0;
         voff = 0; coff = 0;
         bool failed = false;
+        sigma = windowed ? 64 : sigma_sorted;
+        out.sigma = sigma;
         int64_t r = 0;
         while (r < n && !failed) {
             const uint8_t cls = row_class ? (row_class[r] != 0) : 0;
@@ -794,8 +805,9 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
             if (row_class) { while (e < n && (row_class[e] != 0) == cls) ++e; } else e = n;
             rrun.clear();
             sell_run_order(indptr, r, e, sigma, 8 * run, rrun);
-            for (size_t i = 0; i < rrun.size() && !failed; i += 64) {
-                const size_t je = std::min(rrun.size(), i + 64);
+            for (size_t i = 0, take = 64; i < rrun.size() && !failed; i += take) {
+                take = 64;
+                size_t je = std::min(rrun.size(), i + take);
                 int32_t rmin = INT32_MAX, cbase = INT32_MAX;
                 for (size_t j = i; j < je; ++j) {
                     rmin = std::min(rmin, rrun[j]);
@@ -805,18 +817,27 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
                 int width = 0, flags = 0;
                 bool any_skip = false;
                 if (windowed) {
-                    // the slice's granules: the sorted distinct (run-first) columns, each covered together with its run
-                    cols.clear();
-                    for (size_t j = i; j < je; ++j) {
-                        for (int32_t q = indptr[rrun[j]]; q < indptr[rrun[j] + 1]; q += run) cols.push_back(indices[q]);
-                        width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]]);
-                    }
-                    std::sort(cols.begin(), cols.end());
-                    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                    // the slice's granules: the sorted distinct (run-first) columns, each covered together with its run.  A slice
+                    // whose rows touch more than the kernels' window holds is cut: half the rows, and so on (its other lanes idle)
                     const size_t g0 = out.gran.size();
-                    for (int32_t c : cols)
-                        if (out.gran.size() == g0 || c + run - 1 > out.gran.back() + kSellGranule - 1) out.gran.push_back(c);
-                    const int ng = (int)(out.gran.size() - g0);
+                    int ng = 0;
+                    for (;;) {
+                        cols.clear();
+                        width = 0;
+                        for (size_t j = i; j < je; ++j) {
+                            for (int32_t q = indptr[rrun[j]]; q < indptr[rrun[j] + 1]; q += run) cols.push_back(indices[q]);
+                            width = std::max(width, indptr[rrun[j] + 1] - indptr[rrun[j]]);
+                        }
+                        std::sort(cols.begin(), cols.end());
+                        cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                        out.gran.resize(g0);
+                        for (int32_t c : cols)
+                            if (out.gran.size() == g0 || c + run - 1 > out.gran.back() + kSellGranule - 1) out.gran.push_back(c);
+                        ng = (int)(out.gran.size() - g0);
+                        if (ng <= opt.window_granules || take == 1) break;
+                        take /= 2;
+                        je = std::min(rrun.size(), i + take);
+                    }
                     if (ng > opt.window_granules || out.gran.size() >= (size_t)INT32_MAX / 2) { failed = true; break; }
                     out.window = std::max(out.window, ng);
                     cbase = (int)g0;
@@ -845,12 +866,14 @@ bool plan_sell(int64_t n, const int32_t* indptr, const int32_t* indices, const d
             }
             r = e;
         }
+        // (cut slices idle lanes: the padding bound holds for what was built, not for what was estimated)
+        if (windowed && !failed && (double)voff > std::max(opt.max_overhead, prefer_window ? opt.window_max_overhead : 0.0) * (double)std::max<int64_t>(nnz, 1)) failed = true;
         if (!failed) break;
-        windowed = false;                      // (second attempt: delta codes)
+        windowed = false;                      // (second attempt: delta codes, the sorting window chosen above)
     }
     if (getenv("PRCG_PLAN_DEBUG"))
         fprintf(stderr, "plan_sell: sigma %d, %zu slices, padded / nnz = %.4f\n", sigma, all.size(), (double)voff / (double)std::max<int64_t>(nnz, 1));
-    if ((double)voff > opt.max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
+    if (!windowed && (double)voff > opt.max_overhead * (double)std::max<int64_t>(nnz, 1)) return false;
     out.padded_nnz = voff;
     out.col_entries = coff;
     // pass 2: fill (padding: value 0, delta 0 -- the column stays where it is)

@@ -170,6 +170,8 @@ struct SellOptions {
     int planes = 8;                  // class-0 slices of this many consecutive grid planes are interleaved in the table (<= 1: row order)
     bool allow_runs = true;          // operators whose rows are aligned runs of 3 consecutive columns store one code per run
     int window_granules = 0;         // > 0: slices of consecutive rows (sigma 64) whose columns fit this many 16-entry granules get WINDOW codes
+    double window_prefer = 1.32;     //    ... preferred to a sorting window while consecutive rows pad at most this much more than sorted ones
+    double window_max_overhead = 1.40;   //    and at most this much over the nonzeros
 };
 struct SellPlan {
     std::vector<SellSlice> s0, s1;       // interior slices (in PROCESSING order), slices touching ghost columns

@@ -266,9 +266,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_tiles(
 //               the granule starts of slice t + 2 W are requested;  then the trips, as k_sell_tiles walks them.
 // Always all kSellWindowPages pages (granule index clamped: the last granule again): no branch around a load (the compiler's
 // wait counts at a join assume the path without it).
-constexpr int kSellWindowMax = 48;                       // granules per slice the kernels hold (SellOptions::window_granules)
-constexpr int kSellWindowPages = kSellWindowMax / 4;
-constexpr int kSellWindowEntries = kSellWindowMax * 16;
+// PAGES = 12 or 16 wave-wide page loads per slice (48 or 64 granules: SellPlan::window decides; the window lives in dynamic LDS,
+// 4 waves x PAGES x 1 KB for pairs).
 
 // (pages and window entries as native vectors: arrays of the HIP double2 class that live across the slice loop stay in scratch memory)
 template <int NV> struct PageT;
@@ -277,10 +276,10 @@ template <> struct PageT<2> { using type = d2_t; };
 __device__ __forceinline__ double from_page(double w) { return w; }
 __device__ __forceinline__ double2 from_page(d2_t w) { return make_double2(w.x, w.y); }
 
-template <typename V>
-__device__ __forceinline__ void request_pages(const V* __restrict__ X, int ng, int gb, int lane, V (&pg)[kSellWindowPages]) {
+template <typename V, int PAGES>
+__device__ __forceinline__ void request_pages(const V* __restrict__ X, int ng, int gb, int lane, V (&pg)[PAGES]) {
 #pragma unroll
-    for (int j = 0; j < kSellWindowPages; ++j) {
+    for (int j = 0; j < PAGES; ++j) {
         int g = 4 * j + (lane >> 4);
         g = g < ng ? g : ng - 1;
         const int base = __builtin_amdgcn_ds_bpermute(g << 2, gb);
@@ -288,7 +287,7 @@ __device__ __forceinline__ void request_pages(const V* __restrict__ X, int ng, i
     }
 }
 
-template <int NV, int EPI, bool NT, int RUN>
+template <int NV, int EPI, bool NT, int RUN, int PAGES>
 __global__ __launch_bounds__(kBlock) void k_sell_win(
     SellDev A, const int4* __restrict__ slices, int nslices,
     const void* __restrict__ xin_, void* __restrict__ yout_, int write_mask,
@@ -301,8 +300,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_win(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     using PV = typename PageT<NV>::type;
     const PV* __restrict__ XPG = reinterpret_cast<const PV*>(xin_);
-    __shared__ PV win_all[kWaves * kSellWindowEntries];
-    PV* const win = win_all + wv * kSellWindowEntries;
+    extern __shared__ __align__(16) unsigned char sell_smem[];
+    PV* const win = reinterpret_cast<PV*>(sell_smem) + wv * (PAGES * 64);
 
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     Coefs cf = {0.0, 0.0, 0.0};
@@ -332,12 +331,12 @@ __global__ __launch_bounds__(kBlock) void k_sell_win(
 
     constexpr int TP = 8 * RUN;
     Trip<RUN> cur, nxt;
-    PV pg[kSellWindowPages];
+    PV pg[PAGES];
     // granule starts of a slice, lane g <- granule g (clamped); a page load: lane l reads entry l % 16 of granule 4 j + l / 16
     auto granule_starts = [&](const SDesc& s) { const int ng = s.flags >> 8; return A.gran[s.cbase + (lane < ng ? lane : ng > 0 ? ng - 1 : 0)]; };   // (a slice of empty rows has none)
     SDesc d = read_sdesc(slices, t);
     SDesc dn = t + W < nslices ? read_sdesc(slices, t + W) : d;
-    request_pages<PV>(XPG, d.flags >> 8, granule_starts(d), lane, pg);
+    request_pages<PV, PAGES>(XPG, d.flags >> 8, granule_starts(d), lane, pg);
     int gbn = granule_starts(dn);
     load_trip<NT, RUN>(A, d, 0, lane, cur);
     int2 rl = slice_row(A, d, lane);
@@ -348,9 +347,9 @@ __global__ __launch_bounds__(kBlock) void k_sell_win(
         const int len = rl.y;
         // this slice's window; then everything the next slices need
 #pragma unroll
-        for (int j = 0; j < kSellWindowPages; ++j) win[64 * j + lane] = pg[j];
+        for (int j = 0; j < PAGES; ++j) win[64 * j + lane] = pg[j];
         wave_lds_sync();
-        request_pages<PV>(XPG, dn.flags >> 8, gbn, lane, pg);
+        request_pages<PV, PAGES>(XPG, dn.flags >> 8, gbn, lane, pg);
         const SDesc dnn = t + 2 * W < nslices ? read_sdesc(slices, t + 2 * W) : dn;
         gbn = granule_starts(dnn);
         rl = slice_row(A, dn, lane);
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_sell_win(
 // persistent grid: workgroups that are truly co-resident (the kernel uses no LDS beyond the reduction scratch: the
 // occupancy API's register bound is the bound), at most `per_cu` per CU
 template <typename K>
-int sell_grid(K kernel, int nslices, int per_cu) {
+int sell_grid(K kernel, int nslices, int per_cu, size_t dyn_lds = 0) {
     // (per kernel: every instantiation has the same signature, hence the same K)
     static std::map<const void*, int> cache;
     static std::mutex mu;
@@ -424,7 +423,7 @@ int sell_grid(K kernel, int nslices, int per_cu) {
         int dev = 0, cus = 256, occ = 4;
         if (hipGetDevice(&dev) == hipSuccess) {
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess || occ < 1) occ = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, dyn_lds) != hipSuccess || occ < 1) occ = 2;
         }
         if (occ > 2) occ = 2;      // (s4b: 2 workgroups per CU 3955 it/s, 3: 3840, 4: 3813 -- more requests in flight cost bandwidth)
         cached = occ * 1024 + cus;
@@ -451,10 +450,25 @@ int launch_sell(hipStream_t st, const SellDev& A, const void* slices, int nslice
                 const double* ep_r, const double* ep_d, double* ep_st, double* partials, double* aux, FusedPrev fz, int per_cu)
 {
     if (A.gran) {                                       // WINDOW codes
-        auto kw = A.run == 3 ? (A.nt ? k_sell_win<NV, EPI, true, 3> : k_sell_win<NV, EPI, false, 3>)
-                             : (A.nt ? k_sell_win<NV, EPI, true, 1> : k_sell_win<NV, EPI, false, 1>);
-        const int gridw = sell_grid(kw, nslices, per_cu);
-        hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), 0, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r,
+        auto pickw = [&](auto pages) {
+            constexpr int P = decltype(pages)::value;
+            return A.run == 3 ? (A.nt ? k_sell_win<NV, EPI, true, 3, P> : k_sell_win<NV, EPI, false, 3, P>)
+                              : (A.nt ? k_sell_win<NV, EPI, true, 1, P> : k_sell_win<NV, EPI, false, 1, P>);
+        };
+        const int pages = A.window <= 48 ? 12 : 16;
+        auto kw = pages == 12 ? pickw(std::integral_constant<int, 12>{}) : pickw(std::integral_constant<int, 16>{});
+        const size_t lds = (size_t)kWaves * pages * 64 * sizeof(typename VecT<NV>::type);
+        {
+            static std::map<const void*, bool> raised;
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lk(mu);
+            if (!raised[reinterpret_cast<const void*>(kw)]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                raised[reinterpret_cast<const void*>(kw)] = true;
+            }
+        }
+        const int gridw = sell_grid(kw, nslices, per_cu, lds);
+        hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), lds, st, A, reinterpret_cast<const int4*>(slices), nslices, x, y, write_mask, ep_r,
                            ep_d, ep_st, partials, aux, fz);
         return hipGetLastError() == hipSuccess ? gridw : -1;
     }

@@ -510,9 +510,9 @@ def test_sliced_rows_with_sorting_windows(amd):
     assert lens.max() >= 2.5 * lens.mean() or lens.min() * 3 <= lens.mean()
     x = rng.standard_normal(n)
     ref, ref2 = A @ x, A @ (3.0 * x[::-1])
-    for knobs in ({}, {'PRCG_SELL_SIGMA': '256'}, {'PRCG_SELL_SIGMA': '1024', 'PRCG_SELL_PLANES': '0'}, {'PRCG_SELL_NT': '1'}):
+    for knobs in ({'PRCG_SELL_WINDOW': '0'}, {'PRCG_SELL_SIGMA': '256'}, {'PRCG_SELL_SIGMA': '1024', 'PRCG_SELL_PLANES': '0'}, {'PRCG_SELL_NT': '1', 'PRCG_SELL_WINDOW': '0'}):
         op = amd['device'].DeviceCSR(A, knobs=knobs)
-        assert op.schedule()['sliced_rows'], knobs
+        assert op.schedule()['sliced_rows'] and op.schedule()['sorted_windows'], knobs
         assert np.array_equal(op.matvec(x)[0], ref), knobs
         WU, _ = op.matmat2(np.stack([x, 3.0 * x[::-1]], axis=1))
         assert np.array_equal(WU[:, 0], ref) and np.array_equal(WU[:, 1], ref2), knobs
@@ -534,7 +534,7 @@ def test_sliced_rows_with_sorting_windows(amd):
     # forced steps of the pipelined iteration (one launch) and of Hestenes-Stiefel against the CSR-adaptive kernels
     b, x0, _ = P.reference_rhs(A, n)
     for variant, stored in (('PIPE_PR', ['x', 'r', 'p', 's']), ('HS', ['x', 'r', 'p', 's'])):
-        ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': f}) for f in ('1', '0')]
+        ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': f, 'PRCG_SELL_WINDOW': '0'}) for f in ('1', '0')]
         for op in ops:
             op.begin(getattr(L, variant), b, x0, 20)
         worst = 0.0
@@ -557,20 +557,92 @@ def test_sliced_rows_with_sorting_windows(amd):
 
 
 @pytest.mark.gpu
+def test_sliced_rows_with_window_codes(amd):
+    """WINDOW codes (prcg_plan.h; k_sell_win): for slices of consecutive rows whose columns fit 64 granules of 16 consecutive
+    entries -- an assembled 3-D matrix in natural ordering -- the kernel stages those entries in LDS and every nonzero reads its
+    operand there instead of gathering it from memory.  Same lane, same left-to-right sum: products bit-exact vs scipy's
+    csr_matvec and vs the delta-code kernels, with one code per run of three columns and with one per nonzero, empty rows,
+    rows whose runs are stored in descending order, nontemporal stream loads, a launch with more waves than slices; operators
+    that do not qualify (sorting windows, scattered columns) keep the delta codes."""
+    P = amd['problems']
+    rng = np.random.default_rng(5)
+    A = P.fem_like_3d(14, 3).tolil()
+    for r in rng.integers(0, A.shape[0], size=40):
+        A.rows[r], A.data[r] = [], []                       # empty rows (a whole slice of them too)
+    for r in range(640, 704):
+        A.rows[r], A.data[r] = [], []
+    A = A.tocsr()
+    for r in range(0, A.shape[0], 5):                      # the runs of some rows in descending order
+        lo, hi = A.indptr[r], A.indptr[r + 1]
+        k = (hi - lo) // 3
+        o = (np.arange(k)[::-1][:, None] * 3 + np.arange(3)[None, :]).ravel()
+        A.indices[lo:hi] = A.indices[lo:hi][o]; A.data[lo:hi] = A.data[lo:hi][o]
+    A.has_sorted_indices = False
+    n = A.shape[0]
+    x = rng.standard_normal(n)
+    ref, ref2 = A @ x, A @ (3.0 * x[::-1])
+    for knobs, window in (({}, True), ({'PRCG_SELL_RUNS': '0'}, True), ({'PRCG_SELL_NT': '1'}, True), ({'PRCG_SELL_GRID_PER_CU': '1'}, True),
+                          ({'PRCG_SELL_WINDOW': '0'}, False), ({'PRCG_SELL_SIGMA': '256'}, False)):
+        op = amd['device'].DeviceCSR(A, knobs=knobs)
+        s = op.schedule()
+        assert s['sliced_rows'] and s['window_codes'] == window, (knobs, s)
+        assert np.array_equal(op.matvec(x)[0], ref), knobs
+        WU, _ = op.matmat2(np.stack([x, 3.0 * x[::-1]], axis=1))
+        assert np.array_equal(WU[:, 0], ref) and np.array_equal(WU[:, 1], ref2), knobs
+        op.close()
+    # few slices, many waves (most waves of the launch own nothing)
+    small = P.fem_like_3d(6, 3)
+    op = amd['device'].DeviceCSR(small)
+    assert op.schedule()['window_codes']
+    xs = rng.standard_normal(small.shape[0])
+    assert np.array_equal(op.matvec(xs)[0], small @ xs)
+    op.close()
+    # irregular row lengths: consecutive rows pad by 30 %, a sorting window by 2 % -- but a sorted slice's rows are no neighbours
+    # and gather from memory: consecutive rows with window codes are preferred up to 1.32 x the sorted bytes (prcg_plan.h)
+    C = P.fem_irregular_3d(12)
+    xc = rng.standard_normal(C.shape[0])
+    for knobs, window in (({}, True), ({'PRCG_SELL_WINDOW': '0'}, False)):
+        op = amd['device'].DeviceCSR(C, knobs=knobs)
+        s = op.schedule()
+        assert s['sliced_rows'] and s['window_codes'] == window and s['sorted_windows'] == (not window), (knobs, s)
+        assert np.array_equal(op.matvec(xc)[0], C @ xc), knobs
+        op.close()
+    # the pipelined iteration, free-running: window codes against delta codes, every vector bit for bit (same launches, same sums)
+    L = amd['L']
+    B = P.fem_like_3d(16, 3)
+    b, x0, _ = P.reference_rhs(B, B.shape[0])
+    # (the same slices in both: consecutive rows -- left to itself the planner would sort this small grid's rows when it has no window codes)
+    ops = [amd['device'].DeviceCSR(B, knobs={'PRCG_SELL_WINDOW': f, 'PRCG_SELL_SIGMA': '64'}) for f in ('1', '0')]
+    for variant, inv_diag in ((L.PIPE_PR, None), (L.PIPE_P_M, 1 / B.diagonal()), (L.PR, None)):
+        for op in ops:
+            op.begin(variant, b, x0, 30, inv_diag=inv_diag)
+            op.iterate(25); op.sync()
+        assert ops[0].schedule()['window_codes'] and not ops[1].schedule()['window_codes']
+        for v in ('x', 'r', 'p', 's'):
+            assert np.array_equal(ops[0].get_vector(v), ops[1].get_vector(v)), v
+        assert np.array_equal(ops[0].get_scalars(25), ops[1].get_scalars(25))
+    for op in ops:
+        op.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('window', ['1', '0'])
 @pytest.mark.parametrize('variant,prec', [('PIPE_PR', None), ('PIPE_P_M', 'jacobi'), ('HS', None), ('PR', 'jacobi'), ('CG_CG', None)])
-def test_sliced_row_kernels_run_every_schedule_of_the_tile_kernels(amd, variant, prec):
+def test_sliced_row_kernels_run_every_schedule_of_the_tile_kernels(amd, variant, prec, window):
     """Same row epilogues as the CSR-adaptive family: forced single steps of the solver variants on a FEM-like operator
     agree with the CSR-adaptive kernels (PRCG_SELL=0) bit for bit in every vector and to 1e-12 in the scalars (the inner
-    products are summed slice by slice instead of tile by tile)."""
+    products are summed slice by slice instead of tile by tile) -- with window codes (operands from LDS) and with delta
+    codes (gathers)."""
     L = amd['L']
     A = amd['problems'].fem_like_3d(16, 3)
     n = A.shape[0]
     b, x0, x_true = amd['problems'].reference_rhs(A, n)
     inv_diag = (1 / A.diagonal()) if prec else None
-    ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': f}) for f in ('1', '0')]
+    ops = [amd['device'].DeviceCSR(A, knobs={'PRCG_SELL': f, 'PRCG_SELL_WINDOW': window}) for f in ('1', '0')]
     for op in ops:
         op.begin(getattr(L, variant), b, x0, 40, inv_diag=inv_diag)
     assert ops[0].schedule()['sliced_rows'] and not ops[1].schedule()['sliced_rows']
+    assert ops[0].schedule()['window_codes'] == (window == '1')
     pipelined = variant.startswith('PIPE')
     stored = ['x', 'r', 'p', 's'] + (['rt', 'st'] if (prec and variant != 'HS') else (['rt'] if prec else []))
     if variant == 'CG_CG':

@@ -20,7 +20,7 @@ for arg in sys.argv[1:]:
     except Exception:
         continue
     # the one-launch pipelined iteration: NV = 2, epilogue 3 of whichever kernel family the operator runs on
-    fused = [(k, v) for k, v in d.items() if ('k_win_tiles<2, 3' in k or 'k_spmv_tiles<2, 3' in k or 'k_sell_tiles<2, 3' in k)
+    fused = [(k, v) for k, v in d.items() if ('k_win_tiles<2, 3' in k or 'k_spmv_tiles<2, 3' in k or 'k_sell_tiles<2, 3' in k or 'k_sell_win<2, 3' in k)
              and 'read_bytes_corrected' in v and 'write_bytes' in v]
     if not fused:
         continue

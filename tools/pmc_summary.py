@@ -34,6 +34,6 @@ for k, cs in acc.items():
     if 'TCC_HIT_sum' in d and d['TCC_HIT_sum'] + d.get('TCC_MISS_sum', 0) > 0:
         d['l2_hit_rate'] = d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum'])
     out[k] = d
-keep = {k: v for k, v in out.items() if 'k_spmv_tiles' in k or 'k_pipe_update' in k or 'k_win_tiles' in k or 'k_sell_tiles' in k}
+keep = {k: v for k, v in out.items() if 'k_spmv_tiles' in k or 'k_pipe_update' in k or 'k_win_tiles' in k or 'k_sell_tiles' in k or 'k_sell_win' in k}
 json.dump(keep or out, sys.stdout, indent=1)
 print()
