@@ -33,7 +33,9 @@ int prcg_peer_selftest(prcg_t* h, int k, const double* rows2n, const double* slo
  * 16-byte entries per array (scratch allocated and freed inside the call): mode 0 = pure read (8 loads of 16 B in flight
  * per thread); 1 = the vector traffic of the one-launch pipelined iteration -- per row one pair read and rewritten in
  * place, one pair read from one array and written to another (2 x 16 B in, 2 x 16 B out) -- with plain stores;
- * 2 = the same with nontemporal stores (what the kernels use when the vectors exceed the Infinity Cache).
+ * 2 = the same with nontemporal stores (what the kernels use when the vectors exceed the Infinity Cache);
+ * 3 = pure read as a streaming kernel should issue it: every wave walks contiguous 4 KB chunks with four nontemporal 16-byte
+ * loads in flight, eight waves per CU (tools/readpat.hip: 6.5-7.1 TB/s where mode 0's grid-stride pattern reads 5.1-5.5).
  * gbytes_per_s: bytes moved / time between HIP events around `reps` launches on the handle's compute stream. */
 int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* gbytes_per_s);
 

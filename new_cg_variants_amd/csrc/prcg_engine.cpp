@@ -2171,13 +2171,14 @@ int prcg_spmv(prcg_t* h, const double* x, double* y, int reps, double* ms_avg) {
 
 int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* gbytes_per_s) {
     if (!h) return PRCG_EINVAL;
-    CHECK(h, n_pairs >= 1024 && mode >= 0 && mode <= 2 && reps >= 1 && gbytes_per_s, "prcg_stream_ceiling: bad argument");
+    CHECK(h, n_pairs >= 1024 && mode >= 0 && mode <= 3 && reps >= 1 && gbytes_per_s, "prcg_stream_ceiling: bad argument");
     HIPCHK(h, hipSetDevice(h->dev));
     DevBuf a, b, c;
     const size_t bytes = (size_t)n_pairs * 16;
     HIPCHK(h, a.alloc(bytes));
-    HIPCHK(h, b.alloc(mode ? bytes : 64));
-    HIPCHK(h, c.alloc(mode ? bytes : 64));
+    const bool mix = mode == 1 || mode == 2;
+    HIPCHK(h, b.alloc(mix ? bytes : 64));
+    HIPCHK(h, c.alloc(mix ? bytes : 64));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
@@ -2189,7 +2190,7 @@ int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* 
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    const double moved = (double)bytes * (mode ? 4.0 : 1.0) * reps;
+    const double moved = (double)bytes * (mix ? 4.0 : 1.0) * reps;
     *gbytes_per_s = ms > 0.f ? moved / (ms * 1e-3) * 1e-9 : 0.0;
     return PRCG_OK;
 }

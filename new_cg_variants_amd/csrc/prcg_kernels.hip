@@ -1356,8 +1356,29 @@ __global__ __launch_bounds__(256) void k_stream_pairs(double2* __restrict__ xp, 
         }
     }
 }
+// pure read as a streaming kernel should issue it (tools/readpat.hip: 6.5-7.1 TB/s where the grid-stride form above with eight
+// 1 KB pieces per wave in flight and 16+ waves per CU reads 5.1-5.5): every wave walks contiguous 4 KB chunks, four nontemporal
+// 16-byte loads in flight, eight waves per CU
+__global__ __launch_bounds__(256) void k_stream_read_chunks(const double2* __restrict__ a_, size_t n2, double* out) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* a = reinterpret_cast<const d2*>(a_);
+    const int lane = threadIdx.x & 63;
+    const size_t W = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t chunks = n2 / 256;                                          // 256 pairs = 4 KB
+    double s = 0.0;
+    for (size_t c = w; c < chunks; c += W) {
+        const d2* base = a + c * 256 + lane;
+        d2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(base + u * 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u].x + v[u].y;
+    }
+    if (s == 123.456) out[0] = s;
+}
 void launch_stream_probe(hipStream_t st, int mode, double* a, double* b, double* c, size_t n_pairs) {
     const dim3 grid(kMaxGridBlocks), block(256);
+    if (mode == 3) { hipLaunchKernelGGL(k_stream_read_chunks, dim3(512), block, 0, st, reinterpret_cast<const double2*>(a), n_pairs, c); return; }
     if (mode == 0) hipLaunchKernelGGL(k_stream_read<8>, grid, block, 0, st, reinterpret_cast<const double2*>(a), n_pairs, c);
     else if (mode == 1) hipLaunchKernelGGL((k_stream_pairs<4, false>), grid, block, 0, st, reinterpret_cast<double2*>(a), reinterpret_cast<const double2*>(b), reinterpret_cast<double2*>(c), n_pairs);
     else hipLaunchKernelGGL((k_stream_pairs<4, true>), grid, block, 0, st, reinterpret_cast<double2*>(a), reinterpret_cast<const double2*>(b), reinterpret_cast<double2*>(c), n_pairs);

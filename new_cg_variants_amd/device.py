@@ -290,7 +290,7 @@ class DeviceCSR:
     def stream_ceiling(self, n_pairs, mode, reps=20):
         """GB/s the memory system delivers for a byte mix over arrays of n_pairs 16-byte entries (prcg_test.h:
         prcg_stream_ceiling): mode 0 pure read, 1 = 2 x 16 B in + 2 x 16 B out per row (the one-launch iteration's vector
-        traffic) with plain stores, 2 with nontemporal stores."""
+        traffic) with plain stores, 2 with nontemporal stores, 3 pure read in contiguous 4 KB chunks per wave, nontemporal."""
         g = C.c_double()
         self._check(self._lib.prcg_stream_ceiling(self._h, int(n_pairs), int(mode), int(reps), C.byref(g)))
         return float(g.value)
