@@ -14,10 +14,33 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kElemsPerTrip = kBlock * 2;   // update kernels: 2 elements per thread per trip
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+// The butterfly v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: every lane ends with the same sum, added in the same tree.  The steps
+// inside a row of 16 lanes are data-parallel-primitive moves (VALU, no trip through the LDS crossbar as __shfl_xor makes): row_ror:8 IS
+// lane ^ 8; row_ror:4 hands a lane the value of lane ^ 4 or of (lane ^ 4) ^ 8 -- the same bits, since the ^ 8 step has been done;
+// quad_perm for ^ 2 and ^ 1.  Bit for bit the shuffle form (checked on 262,144 random inputs incl. zeros of both signs).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum(double v) {          // the last four steps: lanes of one row of 16
+    v += dpp_move<0x128>(v);     // row_ror:8
+    v += dpp_move<0x124>(v);     // row_ror:4
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
     return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    return row_sum(v);
+}
+// ... of values that only lanes 0..15 hold (the others would add +0.0: no partial sum here is -0.0, accumulators start at +0.0),
+// the same bits as wave_sum(lane < 16 ? v : 0.0) in every lane
+__device__ __forceinline__ double wave_sum16(double v) {
+    v = row_sum(v);
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a contiguous

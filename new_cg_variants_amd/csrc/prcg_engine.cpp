@@ -1845,7 +1845,7 @@ int prcg_set_csr(prcg_t* h, int64_t n_rows, int64_t n_ghost, int64_t nnz, const 
             HIPCHK(h, h->m_own.alloc(mp.own.size() * sizeof(int32_t)));
             HIPCHK(h, hipMemcpy(h->m_own.p, mp.own.data(), mp.own.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIPCHK(h, h->m_exch.alloc((size_t)4 * n_rows * sizeof(double) + 64));
-            HIPCHK(h, h->m_slots.alloc((size_t)2 * kMedMaxGroups * 8 * sizeof(double)));
+            HIPCHK(h, h->m_slots.alloc((size_t)3 * kMedMaxGroups * 8 * sizeof(double)));      // sums of even / odd iterations, flags
             HIPCHK(h, h->m_err.alloc(64));
             h->med_groups = mp.groups; h->med_window = mp.window_pairs;
             h->medium_ok = true;

@@ -793,10 +793,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
         if (lane == 0) { red[wv * 4 + 0] = acc0; red[wv * 4 + 1] = acc1; red[wv * 4 + 2] = acc2; red[wv * 4 + 3] = acc3; }
         lds_barrier();                                           // nxt complete, red complete
         // 16 wave partials -> every wave sums them with the same butterfly (lanes 0..15 hold them)
-        mu = wave_sum(lane < 16 ? red[lane * 4 + 0] : 0.0);
-        dl = wave_sum(lane < 16 ? red[lane * 4 + 1] : 0.0);
-        gm = wave_sum(lane < 16 ? red[lane * 4 + 2] : 0.0);
-        nu = wave_sum(lane < 16 ? red[lane * 4 + 3] : 0.0);
+        mu = wave_sum16(red[(lane & 15) * 4 + 0]);
+        dl = wave_sum16(red[(lane & 15) * 4 + 1]);
+        gm = wave_sum16(red[(lane & 15) * 4 + 2]);
+        nu = wave_sum16(red[(lane & 15) * 4 + 3]);
         if (tid == 0) {
             double* d = a.dots + (size_t)(a.k0 + it) * kPartialStride;
             d[0] = mu; d[1] = dl; d[2] = gm; d[3] = nu; d[4] = nu;

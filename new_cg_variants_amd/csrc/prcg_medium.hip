@@ -63,7 +63,8 @@ __device__ __forceinline__ bool wait_tags(const double* lines, int G, unsigned l
     if (lane < G) {
         const unsigned long long* tp = reinterpret_cast<const unsigned long long*>(lines + (size_t)lane * 8 + 7);
         unsigned spins = 0;
-        while (__hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+        // (>=: a workgroup that is ahead may already have posted the next iteration's tag -- its flag -- in the same place)
+        while (__hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tag) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) { ok = false; break; }
         }
@@ -144,8 +145,11 @@ __global__ __launch_bounds__(kMedThreads) void k_medium_pipe_pr(MediumArgs a) {
     const int cmin = a.wg_window[g].x, wlen = a.wg_window[g].y;
     const int own_lo = a.wg_own[g].x, own_hi = a.wg_own[g].y;            // rows [own_lo, own_hi) belong to this workgroup
     const int4* __restrict__ slices = a.slices;
-    double* sums = a.slots;                                                // [G][8]: four partial sums ... tag
-    double* flags = a.slots + (size_t)kMedMaxGroups * 8;                   // [G][8]: "rows of iteration it are visible" tag
+    // slots: [2][G][8] four partial sums ... tag, by iteration parity -- a workgroup that has all sums of iteration `it` goes on
+    // and posts its sums of it + 1 while another still reads those of `it` (it cannot post it + 2 before that one has posted its
+    // flag of it + 1, i.e. has finished reading); then [G][8]: "rows of iteration it are visible" tags (monotone, waited for with >=)
+    double* const sums_all = a.slots;
+    double* flags = a.slots + (size_t)2 * kMedMaxGroups * 8;
 
     double xr[kMedSlices], pr[kMedSlices], wr[kMedSlices], us[kMedSlices];
     int row[kMedSlices], len[kMedSlices];
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(kMedThreads) void k_medium_pipe_pr(MediumArgs a) {
     for (int it = 0; it <= a.iters && alive; ++it) {
         double* mine = (it & 1) ? exch1 : exch0;                              // where this iteration's rows went
         const unsigned long long tag = tag0 + (unsigned long long)it;
+        double* sums = sums_all + (size_t)(it & 1) * kMedMaxGroups * 8;
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         if (it > 0) {
             // ---- 1. coefficients (pipe_pr_cg.py:64-66,75) and the own rows' update; w, u from the products of iteration it - 1
@@ -287,6 +292,7 @@ __global__ __launch_bounds__(kMedThreads) void k_medium_pipe_pr(MediumArgs a) {
         // the last iteration's sums: every workgroup has them posted; workgroup 0 writes them to the history
         __syncthreads();
         if (g == 0 && tid < 64) {
+            const double* sums = sums_all + (size_t)(a.iters & 1) * kMedMaxGroups * 8;
             double v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = lane < G ? ld_sc(sums + (size_t)lane * 8 + q) : 0.0;
