@@ -191,6 +191,21 @@ def fem_like_3d(m, dof=3, rows=None, shift=1e-4):
     return _fem_assemble(m, np.full(m ** 3, dof, dtype=np.int8), None, shift, rows)
 
 
+
+def block_band_3dof(nodes, reach, picks=26, seed=3):
+    """Rows of aligned runs of three columns with a WIDE footprint: `nodes` nodes of three unknowns, each coupled (full 3 x 3
+    blocks) to itself and to `picks` nodes drawn within +-reach.  Not symmetric: a test operator for products (the sliced-row
+    planner's window codes need 49..64 granules per slice at reach 120, and more than any window holds beyond ~150)."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for i in range(nodes):
+        c = np.union1d(np.clip(i + rng.integers(-reach, reach + 1, size=picks), 0, nodes - 1), [i])
+        cc = (c[:, None] * 3 + np.arange(3)[None, :]).ravel()
+        for d in range(3):
+            rows.append(np.full(cc.size, 3 * i + d)); cols.append(cc)
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    return sp.csr_matrix((rng.standard_normal(r.size), (r, c)), shape=(3 * nodes, 3 * nodes))
+
 def fem_irregular_3d(m, seed=0, keep=0.8, rows=None, shift=1e-4, dof_choices=(1, 3, 6), dof_probs=(0.3, 0.5, 0.2)):
     """FEM-like locality WITH irregular row lengths (the "CSR-adaptive load-balance stress" of BASELINE config 5,
     labelled stand-in): m^3 nodes carrying 1, 3 or 6 unknowns (seeded draw), 27-point coupling with each node pair

@@ -590,6 +590,22 @@ def test_sliced_rows_with_window_codes(amd):
         WU, _ = op.matmat2(np.stack([x, 3.0 * x[::-1]], axis=1))
         assert np.array_equal(WU[:, 0], ref) and np.array_equal(WU[:, 1], ref2), knobs
         op.close()
+    # a footprint of 49..64 granules a slice: the kernels' larger window (16 page loads), one code per run of three
+    W = P.block_band_3dof(1500, 120)
+    xw = rng.standard_normal(W.shape[0])
+    op = amd['device'].DeviceCSR(W, knobs={'PRCG_SELL_SIGMA': '64'})
+    assert op.schedule()['window_codes']
+    assert np.array_equal(op.matvec(xw)[0], W @ xw)
+    WU, _ = op.matmat2(np.stack([xw, 3.0 * xw[::-1]], axis=1))
+    assert np.array_equal(WU[:, 0], W @ xw) and np.array_equal(WU[:, 1], W @ (3.0 * xw[::-1]))
+    op.close()
+    # a window of 24 granules where the slices need up to 33: the planner cuts them (their other lanes idle)
+    op = amd['device'].DeviceCSR(A, knobs={'PRCG_SELL_WINDOW': '24', 'PRCG_SELL_SIGMA': '64', 'PRCG_SELL_MAX_OVERHEAD_PCT': '600'})
+    assert op.schedule()['window_codes']
+    assert np.array_equal(op.matvec(x)[0], ref)
+    WU, _ = op.matmat2(np.stack([x, 3.0 * x[::-1]], axis=1))
+    assert np.array_equal(WU[:, 0], ref) and np.array_equal(WU[:, 1], ref2)
+    op.close()
     # few slices, many waves (most waves of the launch own nothing)
     small = P.fem_like_3d(6, 3)
     op = amd['device'].DeviceCSR(small)
