@@ -215,6 +215,7 @@ struct prcg_handle {
     DevBuf m_val, m_col, m_slices, m_rows, m_wave_first, m_window, m_own, m_exch, m_slots, m_err;
     bool small = false;          // this session runs the one-workgroup solver (n <= 4096)
     int small_mode = 0;          // 0: matrix in LDS, 1: matrix in registers
+    bool small_hs = false;       // Hestenes-Stiefel session of a small system: the whole solve in one launch of one workgroup
     int max_row_len = 0;
     bool want_small = true;      // PRCG_SMALL=0 turns it off
     double* rs_cur = nullptr;    // fused: the current SpMM input pairs: rs / rs2 ((r,s)), with Jacobi rst / rst2 ((r~,s~))
@@ -2238,7 +2239,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
     h->pr_fused = false;
     h->pr_packed = false;
     h->hs_pend_mu = 0;
-    h->small = false;
+    h->small = false; h->small_hs = false;
     h->medium = false;
     h->gather = false;
     h->cb_session = h->cb != nullptr && inv_diag == nullptr;
@@ -2446,6 +2447,10 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->p.ensure((size_t)ne * D, h->sc));
         h->p_cur = h->p.d();
         h->hs_fused = variant == PRCG_HS && h->want_fused && !h->multi() && h->g == 0 && !h->cb_session;
+        // one-workgroup solver (k_small_hs): only when nothing but the recurrence residual is recorded
+        h->small_hs = h->hs_fused && h->want_small && !h->prec &&
+                      !(hist_mask & (PRCG_HIST_RESIDUAL_2_NORM | PRCG_HIST_ERROR_A_NORM | PRCG_HIST_ERROR_2_NORM)) &&
+                      small_fits(h->n, h->nnz, h->max_row_len, &h->small_mode);
         // r (r~) is the staged-window source of the Hestenes-Stiefel product launch: like every vector that feeds a
         // product it has the spare entries behind its end (a window page of the last tile may reach past row n)
         HIPCHK(h, h->r.ensure((size_t)(h->debug_short_sources ? n : ne) * D, h->sc));
@@ -2521,6 +2526,22 @@ int prcg_iterate(prcg_t* h, int iters) {
     if (h->fused_comm && *h->err_host != 0u)
         return fail(h, PRCG_ERCCL, "a one-launch iteration waited more than its bound for the other ranks (a peer stalled or died); "
                                    "the session's results are invalid -- PRCG_PEER=0 / PRCG_FUSED_COMM=0 select the two-kernel schedule");
+    if (h->small_hs && iters > 0) {
+        // Hestenes-Stiefel: all `iters` iterations inside one launch of one workgroup
+        hs_flush(h);
+        SmallArgs sa{};
+        sa.n = (int)h->n; sa.nnz = (int)h->nnz;
+        sa.indptr = h->indptr.i(); sa.col = h->col.i(); sa.val = h->val.d();
+        sa.xp = h->x.d(); sa.rs = h->r.d(); sa.hs_p = h->p_cur; sa.hs_s = h->s.d();
+        sa.dots = h->dots.d(); sa.coef = h->coef.d();
+        sa.k0 = h->k; sa.iters = iters; sa.meurant = 0;
+        bool on = false;
+        prof_begin(h, h->ev_spmv, h->n_ev_spmv, 0, on);
+        LAUNCHCHK(h, launch_small_hs(h->sc, sa, h->small_mode));
+        prof_end(h, h->ev_spmv, h->n_ev_spmv, on);
+        h->k += iters;
+        return PRCG_OK;
+    }
     if (h->small && iters > 0) {
         // all `iters` iterations inside one launch of one workgroup
         SmallArgs sa{};
@@ -2630,7 +2651,7 @@ int64_t prcg_operator_bytes(const prcg_t* h) {
 int prcg_schedule(const prcg_t* h) {
     if (!h) return -1;
     return ((h->fused || h->hs_fused || h->pr_fused || h->cg_fused) ? PRCG_SCHED_FUSED : 0) | (h->fused_comm ? PRCG_SCHED_FUSED_COMM : 0) |
-           (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | (h->small ? PRCG_SCHED_SMALL : 0) | (h->medium ? PRCG_SCHED_MEDIUM : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
+           (h->peer ? PRCG_SCHED_PEER : 0) | (h->sell ? PRCG_SCHED_SELL | PRCG_SCHED_COL16 : 0) | ((h->small || h->small_hs) ? PRCG_SCHED_SMALL : 0) | (h->medium ? PRCG_SCHED_MEDIUM : 0) | (h->comm ? PRCG_SCHED_COMM : 0) |
            (h->gather ? PRCG_SCHED_GATHER : 0) | (h->comm_halo ? PRCG_SCHED_DUAL_COMM : 0) | ((h->steps & 15) << 8) |
            (h->stream_stores ? PRCG_SCHED_STREAM_STORES : 0) | ((h->sell && h->sell_sigma > 64) ? PRCG_SCHED_SELL_SORTED : 0) |
            ((h->sell && h->sell_nt) ? PRCG_SCHED_NT_LOADS : 0) | ((h->sell && h->sell_window > 0) ? PRCG_SCHED_SELL_WINDOW : 0) |

@@ -349,9 +349,11 @@ struct SmallArgs {
     double* dots;      // [max_iter+1][kPartialStride]: row k0 is read, rows k0+1..k0+iters written
     double* coef;      // [max_iter+1][4]
     int k0, iters, meurant;
+    double* hs_p; double* hs_s;   // launch_small_hs: xp = x, rs = r, and the direction and its product
 };
 bool small_fits(int64_t n, int64_t nnz, int max_row_len, int* mode);
 int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode);
+int launch_small_hs(hipStream_t st, const SmallArgs& a, int mode);      // Hestenes-Stiefel, same storage
 
 // ---- mid-size systems: the whole pipelined solve in one launch of a few co-operating workgroups (prcg_medium.hip) ----
 constexpr int kMedSlices = 4;                   // 64-row slices per wave at most

@@ -814,6 +814,118 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_pipe_pr(SmallArgs a) {
     }
 }
 
+// ---- Hestenes-Stiefel, the whole solve of a SMALL system in one launch of one workgroup (hs_cg.py:54-62) ----
+// BASELINE config 1 is bcsstk03 (n = 112) under hs_cg: two launches and two kernel boundaries per iteration cost it 9-10 us each.
+// Same storage as k_small_pipe_pr (matrix in registers or LDS, the gather source in LDS: here the direction p, double-buffered);
+// x, r, p, s of a thread's rows live in its registers.  Per iteration, with the expressions and roundings of k_hs_update_xr /
+// k_hs_update_p / the row sums of csr_matvec:  a = nu / mu;  x += a p;  r -= a s;  nu' = r.r;  b = nu' / nu;  p = r + b p;
+// s = A p;  mu = p.s  -- two workgroup-wide sums (the two reductions that make Hestenes-Stiefel what it is), three barriers.
+// Scalars as the launches leave them: dots[k] = {mu_k, -, -, nu_k, rr_k}, coef[k] = {a_k, b_k}.
+template <int MODE>
+__global__ __launch_bounds__(kSmallThreads) void k_small_hs(SmallArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int ROWS = MODE == 1 ? 1 : kSmallRows;
+    const int n = a.n, nnz = a.nnz;
+    double* pA = reinterpret_cast<double*>(smem);
+    double* pB = pA + n;
+    double* red = pB + n + (n & 1);                              // [16 waves]
+    double* lval = red + 16;
+    int* lcol = reinterpret_cast<int*>(lval + (MODE == 0 ? nnz : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double xr[ROWS], rr_[ROWS], pr[ROWS], sr[ROWS];
+    int rbeg[ROWS], rend[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int row = tid + j * kSmallThreads;
+        xr[j] = 0.0; rr_[j] = 0.0; pr[j] = 0.0; sr[j] = 0.0; rbeg[j] = 0; rend[j] = 0;
+        if (row < n) {
+            xr[j] = a.xp[row]; rr_[j] = a.rs[row]; pr[j] = a.hs_p[row]; sr[j] = a.hs_s[row];
+            pA[row] = pr[j];
+            rbeg[j] = a.indptr[row]; rend[j] = a.indptr[row + 1];
+        }
+    }
+    double rv[kSmallRegLen];
+    int rc[kSmallRegLen];
+    int rlen = 0;
+    if constexpr (MODE == 1) {
+        rlen = rend[0] - rbeg[0];
+#pragma unroll
+        for (int q = 0; q < kSmallRegLen; ++q) {
+            const bool ok = q < rlen;
+            rv[q] = ok ? a.val[rbeg[0] + q] : 0.0;
+            rc[q] = ok ? a.col[rbeg[0] + q] : 0;
+        }
+    } else {
+        for (int q = tid; q < nnz; q += kSmallThreads) { lval[q] = a.val[q]; lcol[q] = a.col[q]; }
+    }
+    double mu = a.dots[(size_t)a.k0 * kPartialStride + 0], nu = a.dots[(size_t)a.k0 * kPartialStride + 3];
+    __syncthreads();
+
+    double* cur = pA;                                            // holds p_{k-1}
+    double* nxt = pB;
+    for (int it = 1; it <= a.iters; ++it) {
+        const double al = nu / mu;                               // a = nu / mu                       hs_cg.py:55
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            if (tid + j * kSmallThreads < n) {
+                xr[j] = xr[j] + al * pr[j];                      // x += a p
+                rr_[j] = rr_[j] - al * sr[j];                    // r -= a s
+                acc += rr_[j] * rr_[j];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red[wv] = acc;
+        lds_barrier();
+        const double nun = wave_sum16(red[lane & 15]);           // nu' = r.r                          :58
+        const double bt = nun / nu;                              // b = nu' / nu                       :59
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int row = tid + j * kSmallThreads;
+            if (row < n) { pr[j] = rr_[j] + bt * pr[j]; nxt[row] = pr[j]; }     // p = r + b p           :60
+        }
+        lds_barrier();                                           // the new direction is complete (and red has been read)
+        double accm = 0.0;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int row = tid + j * kSmallThreads;
+            if (row < n) {
+                double sp = 0.0;                                 // (A p)_i, left to right
+                if constexpr (MODE == 1) {
+                    double g[kSmallRegLen];
+#pragma unroll
+                    for (int q = 0; q < kSmallRegLen; ++q) g[q] = nxt[rc[q]];
+#pragma unroll
+                    for (int q = 0; q < kSmallRegLen; ++q)
+                        if (q < rlen) sp += rv[q] * g[q];
+                } else {
+                    for (int q = rbeg[j]; q < rend[j]; ++q) sp += lval[q] * nxt[lcol[q]];
+                }
+                sr[j] = sp;                                      // s = A p                            :61
+                accm += pr[j] * sp;
+            }
+        }
+        accm = wave_sum(accm);
+        if (lane == 0) red[wv] = accm;
+        lds_barrier();
+        mu = wave_sum16(red[lane & 15]);                         // mu = p.s                           :62
+        if (tid == 0) {
+            double* cf = a.coef + (size_t)(a.k0 + it) * 4;
+            cf[0] = al; cf[1] = bt;
+            double* d = a.dots + (size_t)(a.k0 + it) * kPartialStride;
+            d[0] = mu; d[3] = nun; d[4] = nun;
+        }
+        nu = nun;
+        lds_barrier();                                           // everybody has read red before it is rewritten
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int row = tid + j * kSmallThreads;
+        if (row < n) { a.xp[row] = xr[j]; a.rs[row] = rr_[j]; a.hs_p[row] = pr[j]; a.hs_s[row] = sr[j]; }
+    }
+}
+
 // ---- fixed-order final reduction of per-block partials --------------------------------
 constexpr int kFinalThreads = 256;   // same tree as the fused last-block reduction
 __global__ __launch_bounds__(kFinalThreads) void k_reduce_final(
@@ -1186,6 +1298,19 @@ bool small_fits(int64_t n, int64_t nnz, int max_row_len, int* mode) {
     const size_t cap = 156 * 1024;
     if (nnz < (1 << 20) && small_lds_bytes((int)n, (int)nnz, 0) <= cap && max_row_len <= 64) { *mode = 0; return true; }
     return false;
+}
+// (xp = x, rs = r, hs_p = p, hs_s = s: separate arrays, as the Hestenes-Stiefel sessions hold them)
+int launch_small_hs(hipStream_t st, const SmallArgs& a, int mode) {
+    const size_t lds = small_lds_bytes(a.n, a.nnz, mode);        // (sized for the pipelined solver's pairs: more than the directions need)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_hs<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_hs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (mode == 1) hipLaunchKernelGGL(k_small_hs<1>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    else hipLaunchKernelGGL(k_small_hs<0>, dim3(1), dim3(kSmallThreads), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 int launch_small_pipe_pr(hipStream_t st, const SmallArgs& a, int mode) {
     const size_t lds = small_lds_bytes(a.n, a.nnz, mode);

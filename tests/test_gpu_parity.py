@@ -841,7 +841,8 @@ def test_hestenes_stiefel_without_reduction_launches(amd, matrices, source, prec
         b = amd['problems'].reference_rhs(A, A.shape[0])[0]
     n = A.shape[0]
     inv_diag = (1 / A.diagonal()) if prec == 'jacobi' else None
-    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f)) for f in ('1', '0')]
+    # (PRCG_SMALL=0: the one-workgroup solver of small systems has its own summation order)
+    ops = [amd['device'].DeviceCSR(A, knobs=dict(knobs, PRCG_FUSED=f, PRCG_SMALL='0')) for f in ('1', '0')]
     total = 60
     for op, mask in zip(ops, (1, 1)):
         op.begin(L.HS, b, np.zeros(n), total + 1, inv_diag=inv_diag, hist_mask=mask)
@@ -866,20 +867,25 @@ def test_hestenes_stiefel_without_reduction_launches(amd, matrices, source, prec
         op.close()
 
 
+@pytest.mark.parametrize('variant', ['PIPE_PR', 'HS'])
 @pytest.mark.parametrize('matrix', ['bcsstk03', 'nos7', 'bcsstk14', 'model_48_8_3'])
-def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
+def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix, variant):
     """n <= 4096 and nothing but the recurrence residual recorded: the whole solve runs in one
-    launch of one workgroup ((r,s) in LDS, matrix in LDS when it fits -- bcsstk14's does not).
+    launch of one workgroup ((r,s) -- for Hestenes-Stiefel the direction p -- in LDS, matrix in LDS when it fits:
+    bcsstk14's does not).  The pipelined predict-and-recompute family (k_small_pipe_pr) and Hestenes-Stiefel (k_small_hs:
+    BASELINE config 1 is bcsstk03 under hs_cg).
     Per element the arithmetic is the one of the multi-launch schedules: from identical state
     vectors agree bit for bit, inner products to 1e-12; and it is deterministic."""
     import time
     L = amd['L']
     A, z = matrices[matrix]
     n = A.shape[0]
+    VAR = getattr(L, variant)
     small = amd['device'].DeviceCSR(A)                                  # default: one-workgroup solver
-    multi = amd['device'].DeviceCSR(A, knobs={'PRCG_SMALL': '0'})       # one launch per iteration
+    multi = amd['device'].DeviceCSR(A, knobs={'PRCG_SMALL': '0'})       # one (HS: two) launch(es) per iteration
     for op in (small, multi):
-        op.begin(L.PIPE_PR, z['b'], np.zeros(n), 64)
+        op.begin(VAR, z['b'], np.zeros(n), 64)
+    assert small.schedule()['small'] == (matrix != 'bcsstk14') and not multi.schedule()['small']
     worst = 0.0
     for k in range(30):
         for v in ('x', 'r', 'p', 's'):
@@ -889,15 +895,23 @@ def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
         small.iterate(1)
         multi.iterate(1)
         for v in ('x', 'r', 'p', 's'):
-            assert np.array_equal(small.get_vector(v), multi.get_vector(v)), (k, v)
-        a, b = small.get_scalars(k + 1)[:5], multi.get_scalars(k + 1)[:5]
+            if variant == 'HS' and v in ('p', 's') and small.schedule()['small']:
+                # Hestenes-Stiefel forms p with b = nu_k / nu_k1, nu_k summed INSIDE the iteration -- in the workgroup's order here,
+                # in the launches' order there: p and s = A p inherit b's last bit
+                # (absolute floor: an entry that cancels to a small fraction of its terms)
+                ref_v = multi.get_vector(v)
+                np.testing.assert_allclose(small.get_vector(v), ref_v, rtol=1e-12, atol=1e-13 * np.abs(ref_v).max(), err_msg=f'{k} {v}')
+            else:
+                assert np.array_equal(small.get_vector(v), multi.get_vector(v)), (k, v)
+        idx = [0, 3, 4] if variant == 'HS' else [0, 1, 2, 3, 4]
+        a, b = small.get_scalars(k + 1)[idx], multi.get_scalars(k + 1)[idx]
         worst = max(worst, float(np.max(np.abs(a - b) / np.abs(b))))
     assert worst <= 1e-12, worst
     # free-running: reproducible, and the same history whether run in one call or in pieces
     iters = 3000
     runs, times = [], []
     for chunks in ((iters,), (1000, 1, 1999)):
-        small.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
+        small.begin(VAR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
         t0 = time.perf_counter()
         for c in chunks:
             small.iterate(c)
@@ -905,14 +919,14 @@ def test_one_workgroup_solver_for_small_systems(amd, matrices, matrix):
         times.append(time.perf_counter() - t0)
         runs.append(small.history()['updated_residual_2_norm'])
     assert np.array_equal(runs[0], runs[1], equal_nan=True)
-    multi.begin(L.PIPE_PR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
+    multi.begin(VAR, z['b'], np.zeros(n), iters + 1, hist_mask=1)
     t0 = time.perf_counter()
     multi.iterate(iters)
     multi.sync()
     dt_multi = time.perf_counter() - t0
     prefix = PREFIX_FLOOR.get(matrix, 5)
     np.testing.assert_allclose(runs[0][:prefix], multi.history()['updated_residual_2_norm'][:prefix], rtol=1e-12)
-    print(f'{matrix} (n={n}): {iters} iterations in one launch {times[0] * 1e3:.2f} ms '
+    print(f'{matrix} (n={n}) {variant}: {iters} iterations in one launch {times[0] * 1e3:.2f} ms '
           f'({times[0] / iters * 1e6:.2f} us/iteration) vs one launch per iteration {dt_multi * 1e3:.2f} ms '
           f'({dt_multi / iters * 1e6:.2f} us/iteration); forced-step scalar deviation {worst:.1e}')
     small.close()
