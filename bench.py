@@ -462,6 +462,16 @@ def main():
                 if rec['traffic']:
                     rec['traffic_over_must_move'] = rec['traffic'] / rec['bytes_must_move']
                     rec['frac_physical'] = rec['traffic'] / (rec['avg_launch_ms'] * 1e-3) * 1e-9 / HBM_PEAK_GBS
+                # what the memory system delivers for THIS launch's byte mix with no arithmetic (prcg_mix_ceiling: the operator's
+                # stream per 64 rows beside the rows' 64 B of vector traffic): the ceiling of a kernel that moves it
+                try:
+                    kb64 = int(round(rec['operator_bytes'] / max(w2['n'], 1) * 64 / 1024))
+                    mc = d2.mix_ceiling(w2['n'], kb64, reps=6)
+                    rec['mix_ceiling_GBps'] = mc
+                    rec['mix_ceiling_stream_kb_per_64_rows'] = kb64
+                    rec['frac_of_mix_ceiling'] = rec['moved_GBps'] / mc if mc > 0 else None
+                except Exception as exc:
+                    rec['mix_ceiling_error'] = str(exc)[:200]
                 has_dict = d2.schedule()['value_dict']
                 d2.close()
                 if has_dict:
@@ -624,6 +634,14 @@ def main():
             roof['frac_physical_general_csr'] = roof['plain_values']['frac_physical']
             if roof.get('stream_ceiling'):
                 roof['plain_values']['frac_of_pure_read_ceiling'] = (mv2 / ms2 * 1e-6) / roof['stream_ceiling']['pure_read_2GB_GBps']
+            try:
+                kb64 = int(round(opb2 / max(n_local, 1) * 64 / 1024))
+                mc2 = dev.mix_ceiling(n_local, kb64, reps=6)
+                roof['plain_values']['mix_ceiling_GBps'] = mc2
+                roof['plain_values']['frac_of_mix_ceiling'] = (mv2 / ms2 * 1e-6) / mc2 if mc2 > 0 else None
+                roof['frac_of_mix_ceiling_general_csr'] = roof['plain_values']['frac_of_mix_ceiling']
+            except Exception as exc:
+                roof['plain_values']['mix_ceiling_error'] = str(exc)[:200]
             assert roof['plain_values']['frac'] <= 1.0
         if spmv:
             roof['spmv'] = spmv

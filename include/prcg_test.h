@@ -38,6 +38,11 @@ int prcg_peer_selftest(prcg_t* h, int k, const double* rows2n, const double* slo
  * loads in flight, eight waves per CU (tools/readpat.hip: 6.5-7.1 TB/s where mode 0's grid-stride pattern reads 5.1-5.5).
  * gbytes_per_s: bytes moved / time between HIP events around `reps` launches on the handle's compute stream. */
 int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* gbytes_per_s);
+/* ... and for the byte MIX of a one-launch iteration on an operator that streams stream_kb_per_64_rows KB per 64 rows (read once,
+ * nontemporal) beside the rows' vector traffic (two 16-byte pairs read, one rewritten in place, one written to another array with
+ * nontemporal stores), no arithmetic to speak of: the ceiling of a kernel that moves this mix -- row results written beside a large
+ * read stream cost the memory system far more than their bytes (tools/mixbench.hip).  gbytes_per_s counts stream + 64 B per row. */
+int prcg_mix_ceiling(prcg_t* h, int64_t n_rows, int stream_kb_per_64_rows, int reps, double* gbytes_per_s);
 
 /* ---- host-only planning helpers (no GPU needed; used by the CPU test-suite) ------ */
 /* CSR-adaptive tiling of rows [0,n): consecutive rows are packed into tiles of at most

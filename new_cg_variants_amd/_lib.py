@@ -80,6 +80,7 @@ _SIGNATURES = {
     'prcg_get_timings': (C.c_int, [_P, C.POINTER(Timings)]),
     'prcg_solve': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_uint32, _P, _P, C.POINTER(Timings)]),
     'prcg_stream_ceiling': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    'prcg_mix_ceiling': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     'prcg_plan_gather': (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int64, _P]),
     'prcg_plan_sell': (C.c_int64, [C.c_int64, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, _P,
                                     C.c_int64, _P]),

@@ -2196,6 +2196,33 @@ int prcg_stream_ceiling(prcg_t* h, int64_t n_pairs, int mode, int reps, double* 
     return PRCG_OK;
 }
 
+int prcg_mix_ceiling(prcg_t* h, int64_t n_rows, int stream_kb_per_64_rows, int reps, double* gbytes_per_s) {
+    if (!h) return PRCG_EINVAL;
+    CHECK(h, n_rows >= 4096 && stream_kb_per_64_rows >= 0 && stream_kb_per_64_rows <= 256 && reps >= 1 && gbytes_per_s, "prcg_mix_ceiling: bad argument");
+    HIPCHK(h, hipSetDevice(h->dev));
+    DevBuf v, x, r, rn;
+    const size_t pieces = (size_t)n_rows / 64;
+    const size_t vbytes = (pieces + 1) * (size_t)stream_kb_per_64_rows * 1024 + 4096, pbytes = ((size_t)n_rows + 64) * 16;
+    HIPCHK(h, v.alloc(vbytes));
+    HIPCHK(h, x.alloc(pbytes));
+    HIPCHK(h, r.alloc(pbytes));
+    HIPCHK(h, rn.alloc(pbytes));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch_stream_mix(h->sc, v.d(), x.d(), r.d(), rn.d(), (size_t)n_rows, stream_kb_per_64_rows);
+    HIPCHK(h, hipEventRecord(e0, h->sc));
+    for (int i = 0; i < reps; ++i) launch_stream_mix(h->sc, v.d(), x.d(), r.d(), rn.d(), (size_t)n_rows, stream_kb_per_64_rows);
+    HIPCHK(h, hipEventRecord(e1, h->sc));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double moved = ((double)pieces * stream_kb_per_64_rows * 1024.0 + 64.0 * (double)pieces * 64.0) * reps;
+    *gbytes_per_s = ms > 0.f ? moved / (ms * 1e-3) * 1e-9 : 0.0;
+    return PRCG_OK;
+}
+
 int prcg_spmv_ext(prcg_t* h, const double* x_ext, double* y) {
     if (!h) return PRCG_EINVAL;
     CHECK(h, h->have_csr, "no matrix: call prcg_set_csr first");

@@ -473,6 +473,7 @@ constexpr int kPubDoubles = 8 * kPubCopies;
 void launch_publish(hipStream_t st, const double* dots, double* pub, unsigned value);
 // one launch of the streaming probes (prcg_stream_ceiling): mode 0 reads a[0..n_pairs) pairs; 1 / 2: a read and rewritten,
 // b read, c written (plain / nontemporal stores)
+void launch_stream_mix(hipStream_t st, const double* v, double* x, const double* r, double* rn, size_t n_rows, int kb);
 void launch_stream_probe(hipStream_t st, int mode, double* a, double* b, double* c, size_t n_pairs);
 // one wave on `st` waits (bounded, ~2 ms) for the record to reach `want`; *err = 1 if it does not
 void launch_probe_wait(hipStream_t st, const double* pub, unsigned want, unsigned* err);

@@ -1501,6 +1501,49 @@ __global__ __launch_bounds__(256) void k_stream_read_chunks(const double2* __res
     }
     if (s == 123.456) out[0] = s;
 }
+// the byte MIX of a one-launch iteration with no arithmetic to speak of (tools/mixbench.hip): per piece of 64 rows a wave reads
+// `kb` KB of an operator stream (nontemporal, read once: 16 one-KB loads in flight, the next 16 requested before these are used),
+// reads the rows' two pairs and writes one in place and one to another array with nontemporal stores.  What the memory system
+// delivers for THIS mix is the ceiling of a kernel that moves it: 0.32 GB of row results beside a 1.3 GB stream cost 55-90 us
+// (read / write turnarounds), beside a 3 GB stream 76 us -- in the mix itself, not in the kernel.
+__global__ __launch_bounds__(256) void k_stream_mix(const double2* __restrict__ V_, double2* __restrict__ X_, const double2* __restrict__ R_,
+                                                    double2* __restrict__ Rn_, size_t n_rows, int kb) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* V = reinterpret_cast<const d2*>(V_);
+    d2* X = reinterpret_cast<d2*>(X_);
+    const d2* R = reinterpret_cast<const d2*>(R_);
+    d2* Rn = reinterpret_cast<d2*>(Rn_);
+    const int lane = threadIdx.x & 63;
+    const size_t W = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t pieces = n_rows / 64;
+    constexpr int CH = 16;
+    const int nch = (kb + CH - 1) / CH;
+    for (size_t p = w; p < pieces; p += W) {
+        const d2* base = V + p * (size_t)kb * 64 + lane;
+        const d2 x = X[p * 64 + lane], r = R[p * 64 + lane];
+        d2 a[CH], b[CH];
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a[u] = __builtin_nontemporal_load(base + (size_t)(u < kb ? u : 0) * 64);
+        for (int c = 1; c <= nch; ++c) {
+            if (c < nch) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { const int q = c * CH + u; b[u] = __builtin_nontemporal_load(base + (size_t)(q < kb ? q : 0) * 64); }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) s += a[u].x + a[u].y;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) a[u] = b[u];
+        }
+        const d2 xn = {x.x + 0.5 * x.y + s, r.x + 0.25 * x.y}, rn = {r.x - 0.5 * r.y, x.y + 0.25 * r.y};
+        __builtin_nontemporal_store(xn, X + p * 64 + lane);
+        __builtin_nontemporal_store(rn, Rn + p * 64 + lane);
+    }
+}
+void launch_stream_mix(hipStream_t st, const double* v, double* x, const double* r, double* rn, size_t n_rows, int kb) {
+    hipLaunchKernelGGL(k_stream_mix, dim3(512), dim3(256), 0, st, reinterpret_cast<const double2*>(v), reinterpret_cast<double2*>(x),
+                       reinterpret_cast<const double2*>(r), reinterpret_cast<double2*>(rn), n_rows, kb);
+}
 void launch_stream_probe(hipStream_t st, int mode, double* a, double* b, double* c, size_t n_pairs) {
     const dim3 grid(kMaxGridBlocks), block(256);
     if (mode == 3) { hipLaunchKernelGGL(k_stream_read_chunks, dim3(512), block, 0, st, reinterpret_cast<const double2*>(a), n_pairs, c); return; }

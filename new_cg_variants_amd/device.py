@@ -295,6 +295,13 @@ class DeviceCSR:
         self._check(self._lib.prcg_stream_ceiling(self._h, int(n_pairs), int(mode), int(reps), C.byref(g)))
         return float(g.value)
 
+    def mix_ceiling(self, n_rows, stream_kb_per_64_rows, reps=10):
+        """GB/s the memory system delivers for the byte mix of a one-launch iteration that streams that many KB of operator per 64
+        rows beside the rows' 64 B of vector traffic (prcg_test.h: prcg_mix_ceiling)."""
+        g = C.c_double()
+        self._check(self._lib.prcg_mix_ceiling(self._h, int(n_rows), int(stream_kb_per_64_rows), int(reps), C.byref(g)))
+        return float(g.value)
+
     def timings(self):
         t = L.Timings()
         self._check(self._lib.prcg_get_timings(self._h, C.byref(t)))

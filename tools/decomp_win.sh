@@ -6,7 +6,7 @@ log=gpurun_out/r4/decomp_win.log; : > $log
 for rep in 1 2; do
   for v in "$@"; do
     echo "## $v" >> $log
-    PRCG_LIB=$PWD/build_ab/libprcg_$v.so timeout -k 10 200 python tools/stencil_time.py $args >> $log 2>&1 || exit 1
+    PRCG_LIB=$PWD/build_ab/libprcg_$v.so timeout -k 10 200 python ${TOOL:-tools/stencil_time.py} $args >> $log 2>&1 || exit 1
   done
 done
-grep -v "^/opt\|^$" $log | paste - - | sed 's/\[.*pattern/pattern/' | cut -c1-200
+grep -v "^/opt\|^$" $log | paste - - | cut -c1-220
