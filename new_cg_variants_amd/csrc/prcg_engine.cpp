@@ -25,6 +25,7 @@
 #include <new>
 #include <utility>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/prcg.h"
@@ -149,6 +150,8 @@ struct prcg_handle {
                                          // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
     int sell_nt = 0;                     // the value / code streams are read with nontemporal loads: chosen per operator in prcg_set_csr
     int sell_nt_opt = -1;                // PRCG_SELL_NT=0|1 overrides
+    int place_k = 6;                     // PRCG_PLACE=k: the pipelined session's vectors are placed k times and the fastest placement is kept (place_session_vectors); 0 / 1: off
+    void* placed_xp = nullptr;           // ... the (x,p) allocation that has been through it
     int sell_gb = 0, sell_defer = 0;     // PRCG_SELL_GB=0|4|8, PRCG_SELL_DEFER=0|1: request orders inside the sliced-row kernels (prcg_sell.hip)
     int sell_sigma = 0, sell_planes = 0, sell_run = 1; // what the planner chose
     bool sell_runs_opt = true;           // PRCG_SELL_RUNS=0: a column code per nonzero even where the rows are runs of three
@@ -1322,6 +1325,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
     else if (k == "PRCG_SELL_WINDOW") h->sell_window_opt = v == 1 ? 64 : (v >= 0 && v <= 64) ? (int)v : 64;
     else if (k == "PRCG_SELL_MAX_OVERHEAD_PCT") h->sell_overhead_opt = (v >= 100 && v <= 800) ? (double)v / 100.0 : 0.0;
     else if (k == "PRCG_PR_PACK") h->want_pr_pack = v != 0 ? 1 : 0;
+    else if (k == "PRCG_PLACE") h->place_k = (v >= 0 && v <= 8) ? (int)v : 0;
     else if (k == "PRCG_SELL_GB") h->sell_gb = (v == 4 || v == 8) ? (int)v : 0;
     else if (k == "PRCG_SELL_DEFER") h->sell_defer = v != 0;
     else if (k == "PRCG_SELL_NT") { h->sell_nt_opt = v != 0; h->sell_nt = v != 0; }
@@ -1338,7 +1342,7 @@ bool apply_option(prcg_t* h, const char* key, const char* val) {
 const char* const kOptionKeys[] = {"PRCG_SIDE_STREAM", "PRCG_FUSED_FINAL", "PRCG_FUSED", "PRCG_SMALL", "PRCG_MEDIUM", "PRCG_COL16", "PRCG_COL8",
                                    "PRCG_VALDICT", "PRCG_GATHER", "PRCG_GATHER_MAX_BYTES", "PRCG_GRID_PER_CU", "PRCG_TILE_ORDER",
                                    "PRCG_TILE_STEPS", "PRCG_WIN", "PRCG_WIN_GRID_PER_CU", "PRCG_WIN_MAX_MEAN", "PRCG_FUSED_COMM", "PRCG_WIN_ROWS", "PRCG_EXT_SIGNAL", "PRCG_DEFER_GRID_PER_CU",
-                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_SELL_NT", "PRCG_SELL_GB", "PRCG_SELL_DEFER", "PRCG_SELL_RUNS", "PRCG_SELL_WINDOW", "PRCG_SELL_MAX_OVERHEAD_PCT", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
+                                   "PRCG_WIN_SHARE", "PRCG_DEBUG_SHORT_SOURCES", "PRCG_PEER", "PRCG_STREAM_STORES", "PRCG_SELL", "PRCG_SELL_GRID_PER_CU", "PRCG_SELL_SIGMA", "PRCG_SELL_PLANES", "PRCG_PLACE", "PRCG_SELL_NT", "PRCG_SELL_GB", "PRCG_SELL_DEFER", "PRCG_SELL_RUNS", "PRCG_SELL_WINDOW", "PRCG_SELL_MAX_OVERHEAD_PCT", "PRCG_PR_PACK", "PRCG_CG_ONE", "PRCG_WIN_ORDER", "PRCG_WIN_BIG", "PRCG_WIN_PAT", "PRCG_WIN_SWEEP", "PRCG_SWEEP_WAVES"};
 
 int h2d(prcg_t* h, double* dst, const double* src, int64_t count) {
     HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->sc));
@@ -2241,6 +2245,72 @@ int prcg_spmm2(prcg_t* h, const double* rs, double* wu, int reps, double* ms_avg
     return timed_product(h, 2, rs, wu, reps, ms_avg);
 }
 
+// What the row results of a one-launch iteration cost beside the operator's read stream depends on WHERE the written arrays lie:
+// the same byte mix runs at two speeds from process to process (tools/mixbench.hip: s4b's mix 467-477 or 530-560 us, the read
+// stream alone 443 either way; r04_sweeps.md D, K) and from allocation to allocation inside a process.  The session's three
+// large arrays -- (x,p), the (r,s) pairs and their second copy -- are therefore allocated k times, every placement is timed with
+// the mix probe against the operator's own stream (k_stream_mix: reads of the stream, reads of two pair arrays, nontemporal
+// writes of two), and the fastest is kept.  A few milliseconds per placement, once per handle (the allocations are kept for
+// later sessions).  Buffers are zeroed again afterwards; nothing has been written into them yet.
+int place_session_vectors(prcg_t* h, size_t xp_bytes, size_t rs_bytes) {
+    const int64_t n = h->n;
+    const double* stream = nullptr;
+    size_t stream_bytes = 0;
+    if (h->sell) { stream = h->val_sell(); stream_bytes = h->sval.bytes; }
+    else if (h->val.p && h->val.bytes >= (size_t)h->nnz * 8) { stream = h->val.d(); stream_bytes = (size_t)h->nnz * 8; }
+    const size_t pieces = (size_t)n / 64;
+    if (pieces < 4096 || rs_bytes < (size_t)n * 16 || xp_bytes < (size_t)n * 16) return PRCG_OK;      // (262,144 rows and more: smaller sessions are launch-bound)
+    // KB of stream per 64 rows, so that the probe stays inside the stream's allocation (and a dictionary operator: none)
+    int kb = 0;
+    if (stream && !(h->win && (h->win_vd || h->win_pat))) {
+        kb = (int)std::min<size_t>(stream_bytes / (pieces + 1) / 1024, 200);
+    }
+    if (kb == 0) stream = h->xp.d();               // (the probe's first loads read one line of it)
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    auto probe = [&](double* xp, double* rs, double* rs2, float* ms) -> int {
+        launch_stream_mix(h->sc, stream, xp, rs, rs2, (size_t)n, kb);
+        HIPCHK(h, hipEventRecord(e0, h->sc));
+        for (int i = 0; i < 3; ++i) launch_stream_mix(h->sc, stream, xp, rs, rs2, (size_t)n, kb);
+        HIPCHK(h, hipEventRecord(e1, h->sc));
+        HIPCHK(h, hipEventSynchronize(e1));
+        HIPCHK(h, hipEventElapsedTime(ms, e0, e1));
+        return PRCG_OK;
+    };
+    float best = 0.f;
+    int rc = probe(h->xp.d(), h->rs.d(), h->rs2.d(), &best);
+    if (rc) return rc;
+    if (getenv("PRCG_PLAN_DEBUG")) fprintf(stderr, "place_session_vectors: placement 0: %.1f us (stream %d KB per 64 rows)\n", best / 3 * 1e3, kb);
+    // (every placement stays allocated until the choice is made: a freed one would be handed out again for the next)
+    std::vector<std::array<DevBuf, 3>> cand((size_t)h->place_k - 1);
+    int best_c = -1;
+    for (int c = 0; c + 1 < h->place_k; ++c) {
+        DevBuf& cx = cand[(size_t)c][0]; DevBuf& cr = cand[(size_t)c][1]; DevBuf& cr2 = cand[(size_t)c][2];
+        if (cx.alloc(xp_bytes, false) != hipSuccess || cr.alloc(rs_bytes, false) != hipSuccess || cr2.alloc(rs_bytes, false) != hipSuccess) break;
+        HIPCHK(h, hipMemsetAsync(cx.p, 0, xp_bytes, h->sc));
+        HIPCHK(h, hipMemsetAsync(cr.p, 0, rs_bytes, h->sc));
+        HIPCHK(h, hipMemsetAsync(cr2.p, 0, rs_bytes, h->sc));
+        float ms = 0.f;
+        if ((rc = probe(cx.d(), cr.d(), cr2.d(), &ms))) return rc;
+        if (getenv("PRCG_PLAN_DEBUG")) fprintf(stderr, "place_session_vectors: placement %d: %.1f us\n", c + 1, ms / 3 * 1e3);
+        if (ms < best) { best = ms; best_c = c; }
+    }
+    if (best_c >= 0) {
+        DevBuf& cx = cand[(size_t)best_c][0]; DevBuf& cr = cand[(size_t)best_c][1]; DevBuf& cr2 = cand[(size_t)best_c][2];
+        std::swap(h->xp.p, cx.p); std::swap(h->xp.cap, cx.cap); std::swap(h->xp.bytes, cx.bytes);
+        std::swap(h->rs.p, cr.p); std::swap(h->rs.cap, cr.cap); std::swap(h->rs.bytes, cr.bytes);
+        std::swap(h->rs2.p, cr2.p); std::swap(h->rs2.cap, cr2.cap); std::swap(h->rs2.bytes, cr2.bytes);
+    }
+    cand.clear();                                   // (the others are freed)
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(h, hipMemsetAsync(h->xp.p, 0, h->xp.bytes, h->sc));
+    HIPCHK(h, hipMemsetAsync(h->rs.p, 0, h->rs.bytes, h->sc));
+    HIPCHK(h, hipMemsetAsync(h->rs2.p, 0, h->rs2.bytes, h->sc));
+    h->placed_xp = h->xp.p;
+    return PRCG_OK;
+}
+
 int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, int max_iter, const double* x_true,
                      const double* inv_diag, uint32_t hist_mask) {
     if (!h) return PRCG_EINVAL;
@@ -2319,6 +2389,10 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
         HIPCHK(h, h->rs2.ensure((h->fused && !h->prec) ? (size_t)2 * ne * D : 16, h->sc));
+        if (h->place_k > 1 && h->fused && !h->prec && !h->multi() && h->placed_xp != h->xp.p && h->rs.bytes == h->rs2.bytes) {
+            int prc = place_session_vectors(h, h->xp.bytes, h->rs.bytes);
+            if (prc) return prc;
+        }
         HIPCHK(h, h->rst2.ensure((h->fused && h->prec) ? (size_t)2 * ne * D : 16, h->sc));
         HIPCHK(h, h->wv.ensure((h->fused && !pipe_recompute(variant)) ? (size_t)n * D : 16, h->sc));
         HIPCHK(h, h->partC.ensure(h->fused ? (size_t)8192 * kPartialStride * sizeof(double) : 16, h->sc));

@@ -36,6 +36,43 @@ __global__ __launch_bounds__(256) void k(const d2* __restrict__ V, d2* __restric
     }
     if (keep == 123.456) Rn[0].x = keep;
 }
+// the same mix with the row results of BATCH consecutive pieces stored together: a wave takes BATCH neighbouring pieces one after
+// the other (their results: 2 x BATCH KB contiguous per array) and issues the 2 x BATCH stores behind the last one
+template <int VAL_KB, int BATCH>
+__global__ __launch_bounds__(256) void kb(const d2* __restrict__ V, d2* __restrict__ X, const d2* __restrict__ R, d2* __restrict__ Rn, long n) {
+    const int lane = threadIdx.x & 63;
+    const long W = (long)gridDim.x * 4, w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long groups = n / 64 / BATCH;
+    for (long g = w; g < groups; g += W) {
+        d2 xn[BATCH], rn[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const long p = g * BATCH + b;
+            d2 v[VAL_KB];
+#pragma unroll
+            for (int u = 0; u < VAL_KB; ++u) v[u] = __builtin_nontemporal_load(V + (p * VAL_KB + u) * 64 + lane);
+            const d2 x = X[p * 64 + lane], r = R[p * 64 + lane];
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < VAL_KB; ++u) s += v[u].x + v[u].y;
+            xn[b] = d2{x.x + 0.5 * x.y + s, r.x + 0.25 * x.y}; rn[b] = d2{r.x - 0.5 * r.y, x.y + 0.25 * r.y};
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) __builtin_nontemporal_store(xn[b], X + (g * BATCH + b) * 64 + lane);
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) __builtin_nontemporal_store(rn[b], Rn + (g * BATCH + b) * 64 + lane);
+    }
+}
+template <int VAL_KB, int BATCH>
+double runb(const d2* V, d2* X, d2* R, d2* Rn, long n, int grid) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((kb<VAL_KB, BATCH>), dim3(grid), dim3(256), 0, 0, V, X, R, Rn, n);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((kb<VAL_KB, BATCH>), dim3(grid), dim3(256), 0, 0, V, X, R, Rn, n);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / 10 * 1e3;
+}
 template <int VAL_KB, bool WRITE, bool AHEAD>
 double run(const d2* V, d2* X, d2* R, d2* Rn, long n, int grid) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -47,6 +84,35 @@ double run(const d2* V, d2* X, d2* R, d2* Rn, long n, int grid) {
     return ms / 10 * 1e3;
 }
 int main(int argc, char** argv) {
+    if (argc > 1 && atol(argv[1]) == 0) {         // `mixbench 0 [order]`: only the Queen-size mix, once -- is its speed a property of the process?
+        const long n2 = 4102893;
+        const int order = argc > 2 ? atoi(argv[2]) : 0;
+        d2 *V2 = nullptr, *X, *R, *Rn;
+        if (order == 0) CK(hipMalloc(&V2, (n2 / 64 + 1) * 46 * 1024));
+        CK(hipMalloc(&X, (n2 + 64) * 16)); CK(hipMalloc(&R, (n2 + 64) * 16)); CK(hipMalloc(&Rn, (n2 + 64) * 16));
+        if (order != 0) CK(hipMalloc(&V2, (n2 / 64 + 1) * 46 * 1024));
+        CK(hipMemset(V2, 0, (n2 / 64 + 1) * 46 * 1024)); CK(hipMemset(X, 0, (n2 + 64) * 16)); CK(hipMemset(R, 0, (n2 + 64) * 16)); CK(hipMemset(Rn, 0, (n2 + 64) * 16));
+        printf("s4b mix, stores of 1 / 4 / 8 / 16 neighbouring pieces together: %.1f / %.1f / %.1f / %.1f us\n", runb<46, 1>(V2, X, R, Rn, n2, 512),
+               runb<46, 4>(V2, X, R, Rn, n2, 512), runb<46, 8>(V2, X, R, Rn, n2, 512), runb<46, 16>(V2, X, R, Rn, n2, 512));
+        {   // the written array Rn at other offsets from X (same allocation order, one arena): does the RELATIVE placement of the
+            // streams that are accessed in lock step at equal offsets matter?
+            char* arena; const size_t vb = (size_t)(n2 + 64) * 16, room = (size_t)160 << 20;
+            CK(hipMalloc(&arena, 3 * (vb + room))); CK(hipMemset(arena, 0, 3 * (vb + room)));
+            const size_t offs[] = {0, 256, 4096, 65536, (size_t)1 << 20, ((size_t)1 << 20) + 4096, (size_t)8 << 20, ((size_t)33 << 20) + 8192};
+            printf("   arena, (R, Rn) shifted by k x offset against X:");
+            for (size_t o : offs) {
+                d2* Xa = reinterpret_cast<d2*>(arena);
+                d2* Ra = reinterpret_cast<d2*>(arena + ((vb + room) & ~(size_t)0x1fffff) + o);
+                d2* Rna = reinterpret_cast<d2*>(arena + (2 * (vb + room) & ~(size_t)0x1fffff) + 2 * o);
+                if ((char*)Ra + vb > arena + 2 * (vb + room) - ((size_t)2 << 20) || (char*)Rna + vb > arena + 3 * (vb + room)) { printf("  %zu: out of the arena", o); continue; }
+                printf("  %zu: %.1f", o, run<46, true, true>(V2, Xa, Ra, Rna, n2, 512));
+            }
+            printf("\n");
+        }
+        printf("s4b mix (order %d): %.1f us   without stores %.1f   V %p X %p R %p Rn %p\n", order, run<46, true, true>(V2, X, R, Rn, n2, 512),
+               run<46, false, true>(V2, X, R, Rn, n2, 512), (void*)V2, (void*)X, (void*)R, (void*)Rn);
+        return 0;
+    }
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
     d2 *V, *X, *R, *Rn;
     CK(hipMalloc(&V, (n / 64 + 1) * 8 * 1024)); CK(hipMalloc(&X, (n + 64) * 16)); CK(hipMalloc(&R, (n + 64) * 16)); CK(hipMalloc(&Rn, (n + 64) * 16));
