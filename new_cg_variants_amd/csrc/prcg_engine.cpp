@@ -150,7 +150,7 @@ struct prcg_handle {
                                          // interleaving 8 planes cost s4b at 80^3 nodes 9 % -- profiles/r04_sweeps.md)
     int sell_nt = 0;                     // the value / code streams are read with nontemporal loads: chosen per operator in prcg_set_csr
     int sell_nt_opt = -1;                // PRCG_SELL_NT=0|1 overrides
-    int place_k = 6;                     // PRCG_PLACE=k: the pipelined session's vectors are placed k times and the fastest placement is kept (place_session_vectors); 0 / 1: off
+    int place_k = 8;                     // PRCG_PLACE=k: the pipelined session's vectors are placed k times and the fastest placement is kept (place_session_vectors); 0 / 1: off
     void* placed_xp = nullptr;           // ... the (x,p) allocation that has been through it
     int sell_gb = 0, sell_defer = 0;     // PRCG_SELL_GB=0|4|8, PRCG_SELL_DEFER=0|1: request orders inside the sliced-row kernels (prcg_sell.hip)
     int sell_sigma = 0, sell_planes = 0, sell_run = 1; // what the planner chose

@@ -109,6 +109,22 @@ int main(int argc, char** argv) {
             }
             printf("\n");
         }
+        {   // six placements of the three vector arrays, all kept alive: allocated one by one, and as ONE allocation each
+            const size_t vb = (size_t)(n2 + 64) * 16;
+            printf("   placements, one by one:");
+            for (int c = 0; c < 6; ++c) {
+                d2 *a, *b, *cc; CK(hipMalloc(&a, vb)); CK(hipMalloc(&b, vb)); CK(hipMalloc(&cc, vb));
+                CK(hipMemset(a, 0, vb)); CK(hipMemset(b, 0, vb)); CK(hipMemset(cc, 0, vb));
+                printf("  %.1f", run<46, true, true>(V2, a, b, cc, n2, 512));
+            }
+            printf("\n   placements, one allocation for the three:");
+            for (int c = 0; c < 6; ++c) {
+                char* ar; const size_t step = (vb + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+                CK(hipMalloc(&ar, 3 * step)); CK(hipMemset(ar, 0, 3 * step));
+                printf("  %.1f", run<46, true, true>(V2, reinterpret_cast<d2*>(ar), reinterpret_cast<d2*>(ar + step), reinterpret_cast<d2*>(ar + 2 * step), n2, 512));
+            }
+            printf("\n");
+        }
         printf("s4b mix (order %d): %.1f us   without stores %.1f   V %p X %p R %p Rn %p\n", order, run<46, true, true>(V2, X, R, Rn, n2, 512),
                run<46, false, true>(V2, X, R, Rn, n2, 512), (void*)V2, (void*)X, (void*)R, (void*)Rn);
         return 0;
