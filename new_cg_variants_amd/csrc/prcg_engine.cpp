@@ -2389,7 +2389,7 @@ int prcg_solve_begin(prcg_t* h, int variant, const double* b, const double* x0, 
         HIPCHK(h, h->xp.ensure((size_t)2 * n * D, h->sc));
         HIPCHK(h, h->rs.ensure((size_t)2 * (h->prec ? n : ne) * D, h->sc));
         HIPCHK(h, h->rs2.ensure((h->fused && !h->prec) ? (size_t)2 * ne * D : 16, h->sc));
-        if (h->place_k > 1 && h->fused && !h->prec && !h->multi() && h->placed_xp != h->xp.p && h->rs.bytes == h->rs2.bytes) {
+        if (h->place_k > 1 && h->fused && !h->prec && h->placed_xp != h->xp.p && h->rs.bytes == h->rs2.bytes) {       // (every rank for itself: its vectors are its own)
             int prc = place_session_vectors(h, h->xp.bytes, h->rs.bytes);
             if (prc) return prc;
         }
