@@ -2287,7 +2287,10 @@ int place_session_vectors(prcg_t* h, size_t xp_bytes, size_t rs_bytes) {
     int best_c = -1;
     for (int c = 0; c + 1 < h->place_k; ++c) {
         DevBuf& cx = cand[(size_t)c][0]; DevBuf& cr = cand[(size_t)c][1]; DevBuf& cr2 = cand[(size_t)c][2];
-        if (cx.alloc(xp_bytes, false) != hipSuccess || cr.alloc(rs_bytes, false) != hipSuccess || cr2.alloc(rs_bytes, false) != hipSuccess) break;
+        if (cx.alloc(xp_bytes, false) != hipSuccess || cr.alloc(rs_bytes, false) != hipSuccess || cr2.alloc(rs_bytes, false) != hipSuccess) {
+            (void)hipGetLastError();                 // (no room for another placement: the ones so far compete; the error is not the session's)
+            break;
+        }
         HIPCHK(h, hipMemsetAsync(cx.p, 0, xp_bytes, h->sc));
         HIPCHK(h, hipMemsetAsync(cr.p, 0, rs_bytes, h->sc));
         HIPCHK(h, hipMemsetAsync(cr2.p, 0, rs_bytes, h->sc));
