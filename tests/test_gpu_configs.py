@@ -821,3 +821,30 @@ def test_sweep_tables_keep_shared_pages_in_lds(amd):
             op.close()
         for (tag, variant), h in hist.items():
             np.testing.assert_allclose(h, hist[('row order', variant)], rtol=1e-9, err_msg=f'{name} {tag} {variant}')
+
+
+@pytest.mark.gpu
+def test_placement_of_the_session_vectors_changes_no_bit(amd):
+    """place_session_vectors (prcg_engine.cpp): a pipelined session of 262,144 rows and more allocates its (x,p), (r,s) and second
+    (r,s) arrays several times, times every placement with the iteration's byte mix against the operator's own stream and keeps
+    the fastest (the price of the row stores depends on where the written arrays lie: profiles/r04_sweeps.md L).  Where the
+    vectors lie changes no number: free-running solves with the choice off, with three and with eight placements agree bit
+    for bit in every vector and scalar -- window kernels (a band) and sliced rows with window codes (FEM-like); a second session
+    on the same handle keeps the placement."""
+    L, P = amd['L'], amd['problems']
+    for A in (P.banded_ex2b(400_000, 7), P.fem_like_3d(46, 3)):
+        n = A.shape[0]
+        assert n >= 262_144
+        b, x0, _ = P.reference_rhs(A, n)
+        ref = None
+        for place in ('0', '3', '8'):
+            op = amd['device'].DeviceCSR(A, knobs={'PRCG_PLACE': place})
+            for session in range(2):
+                op.begin(L.PIPE_PR, b, x0, 40)
+                op.iterate(30); op.sync()
+                got = [op.get_vector(v) for v in ('x', 'r', 'p', 's')] + [op.get_scalars(30)]
+                if ref is None:
+                    ref = got
+                for g, r_ in zip(got, ref):
+                    assert np.array_equal(g, r_, equal_nan=True), (place, session)
+            op.close()
